@@ -1,0 +1,142 @@
+/* sohit.h -- C ABI of libsohit.so, the MI355X-native replacement for SwiftOrtho's
+ * seed-and-extend search core.
+ *
+ * What it replaces.  The reference has no in-process API for this path: its
+ * bin/find_hit.py shells out to the RPython-built native `lib/fsearch-c`, one process
+ * per query block (find_hit.py:119-132, 191-192), and the native's whole interface is
+ * its flag list (lib/fsearch.py:3187-3188, 3215-3216) plus the 16-column row it prints
+ * (fsearch.py:3242-3243).  Each entry point below therefore cites the piece of that
+ * process boundary it stands in for.  bin/find_hit.py of THIS repository binds these
+ * symbols with ctypes; INTEGRATION.md shows the stub a SwiftOrtho maintainer would add.
+ *
+ * Conventions: plain C types only; inputs are borrowed, result buffers are allocated
+ * by the library and released with so_free_hits(); every function that can fail
+ * returns 0 on success / non-zero on error and leaves a message retrievable with
+ * so_last_error(); nothing aborts.  One so_ctx per GPU per process; a ctx is not
+ * thread-safe.  There is NO CPU fallback: without a usable HIP device so_create()
+ * fails.
+ */
+#ifndef SOHIT_H
+#define SOHIT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOHIT_ABI_VERSION 1
+
+typedef struct so_ctx so_ctx;
+
+/* The native's flags (fsearch.py:3187-3188; defaults as driven by find_hit.py:227-228). */
+typedef struct so_params {
+    const char *seeds;    /* -s  comma-separated spaced-seed patterns, e.g. "111111"          */
+    const char *alphabet; /* -r  reduced alphabet groups; '/' separates several alphabets     */
+    int64_t nc;           /* -M  number of hash buckets NC (fsearch.py:2230); must be >= 1    */
+    int64_t chunk;        /* -c  reference sequences per index chunk (fsearch.py:2283-2295)   */
+    int64_t step;         /* -j  reference seed step (2244); queries always use step 1 (2658) */
+    int64_t max_hits;     /* -v  rows reported per query                                      */
+    int64_t thr;          /* -t  >=1 overrides the per-chunk mu+2sd seed-frequency threshold  */
+    double expect;        /* -e  e-value cutoff                                               */
+    double max_miss;      /* -m  early-stop ratio (fsearch.py:2970, 3052-3054)                */
+    int32_t filter;       /* -F  1 = SEG-like query masking ('T'), 0 = off                    */
+    int32_t profile;      /* 1 = time the headline kernels with HIP events (so_get_counters)  */
+} so_params;
+
+/* One reported alignment == one output row (fsearch.py:3074-3076, 3242-3243).
+ * qst/sst are the 1-based starts exactly as printed (reference prints qst+1, sst+1). */
+typedef struct so_hit {
+    int64_t qidx;     /* query ordinal in the query file (column 15)            */
+    int64_t sidx;     /* subject ordinal in the reference file                  */
+    double identity;  /* matches * (100. / aln), full precision (column 3 is truncated text) */
+    double evalue;    /* D * qlen * slen * 2^-bit (column 11)                   */
+    int32_t aln;      /* alignment length (column 4)                            */
+    int32_t mis;      /* non-identical columns, gaps included (column 5)        */
+    int32_t gap;      /* gap "openings": ceil(run/2) per gap run (column 6)     */
+    int32_t qst, qed; /* columns 7, 8                                           */
+    int32_t sst, sed; /* columns 9, 10                                          */
+    int32_t bit;      /* truncated integer bit score (column 12)                */
+    int32_t qlen;     /* column 13                                              */
+    int32_t slen;     /* column 14                                              */
+    int32_t matches;  /* identical columns                                      */
+    int32_t ungapped; /* ungapped (seed-stage) score of the candidate           */
+} so_hit;
+
+/* Work and time counters of the last so_build_index()/so_search*() calls. */
+typedef struct so_counters {
+    int64_t n_queries, query_aa;       /* queries searched, their residues                 */
+    int64_t ref_seqs, ref_aa, n_chunks;
+    int64_t seed_windows;              /* query seed windows hashed                        */
+    int64_t seed_hits;                 /* index entries visited by the lookup kernel (H)   */
+    int64_t groups;                    /* distinct (subject, diagonal) groups              */
+    int64_t candidates;                /* candidates with ungapped score >= 25             */
+    int64_t alignments;                /* banded alignments computed                       */
+    int64_t cells;                     /* banded DP cells computed                         */
+    int64_t rows;                      /* reported rows                                    */
+    int64_t index_entries;             /* sum of index entries over chunks                 */
+    /* headline-kernel timing (HIP events on the ctx stream; only when params.profile)     */
+    int64_t lookup_launches;           /* launches of the seed-lookup kernel               */
+    double lookup_ms;                  /* their summed duration                            */
+    int64_t lookup_bytes;              /* algorithmic bytes read by them       */
+    int64_t bounds_launches;           /* launches of the query hash+bucket-bounds kernel  */
+    double bounds_ms;
+    int64_t bounds_bytes;
+    int64_t align_launches;
+    double align_ms;
+    double index_ms, seed_ms, group_ms, phase2_ms, total_ms; /* host-side stage wall times */
+} so_counters;
+
+/* Lifetime.  Replaces: spawning `fsearch-c` with its flags (find_hit.py:119-123). */
+so_ctx *so_create(int device, const so_params *params);
+void so_destroy(so_ctx *ctx);
+const char *so_last_error(const so_ctx *ctx); /* ctx may be NULL: last so_create() error */
+int so_abi_version(void);
+
+/* Reference side.  Replaces: Fasta(open(ref)) + DB.makedb()/build_msav() per chunk
+ * (fsearch.py:2975-2979, 2990, 2208-2295).  r_lo/r_hi are -L/-U (-1 = all).
+ * so_load_ref* parses the FASTA and makes the residues resident in HBM;
+ * so_build_index builds every chunk's index on the device (idempotent until the next load). */
+int so_load_ref(so_ctx *ctx, const char *fasta_path, int64_t r_lo, int64_t r_hi);
+int so_load_ref_mem(so_ctx *ctx, const char *fasta_bytes, int64_t nbytes, int64_t r_lo, int64_t r_hi);
+int so_build_index(so_ctx *ctx);
+
+/* Query side.  Replaces: Fasta(open(qry)) (fsearch.py:2971-2973).  Parses the FASTA and
+ * makes the query residues resident in HBM. */
+int so_load_queries(so_ctx *ctx, const char *fasta_path);
+int so_load_queries_mem(so_ctx *ctx, const char *fasta_bytes, int64_t nbytes);
+int64_t so_num_queries(const so_ctx *ctx);
+int64_t so_num_refs(const so_ctx *ctx);
+int64_t so_query_len(const so_ctx *ctx, int64_t qidx);
+
+/* The search.  Replaces: blastp(qry, ref, ..., st=-l, ed=-u) (fsearch.py:2968-3121):
+ * queries [q_lo, q_hi) of the loaded query file against the loaded reference; rows come
+ * back in the order the reference yields them (ascending query, descending bit).
+ * so_search() = so_load_queries() + so_build_index() (if needed) + so_search_loaded(). */
+int so_search_loaded(so_ctx *ctx, int64_t q_lo, int64_t q_hi, so_hit **hits, int64_t *n_hits);
+int so_search(so_ctx *ctx, const char *qry_fasta_path, int64_t q_lo, int64_t q_hi, so_hit **hits, int64_t *n_hits);
+void so_free_hits(so_hit *hits);
+
+/* Output.  Replaces: the row formatter of entry_point (fsearch.py:3234-3258; f2s 43-61):
+ * writes the 16-column tab-separated rows for hits of the currently loaded query and
+ * reference files.  mode "w" or "a" (-O).  so_format_hit() renders one row into buf. */
+int so_write_sc(so_ctx *ctx, const so_hit *hits, int64_t n_hits, const char *path, const char *mode);
+int64_t so_format_hit(so_ctx *ctx, const so_hit *hit, char *buf, int64_t cap);
+
+/* Introspection (tests, bench). */
+int so_get_counters(const so_ctx *ctx, so_counters *out);
+int so_reset_counters(so_ctx *ctx);
+int64_t so_chunk_threshold(const so_ctx *ctx, int64_t chunk);
+int64_t so_chunk_entries(const so_ctx *ctx, int64_t chunk);
+/* copies start[0..NC] (uint32, NC+1 values) / entries (uint64) of one chunk's index to host */
+int so_chunk_download(so_ctx *ctx, int64_t chunk, uint32_t *start, uint64_t *entries);
+/* masked (SEG-filtered, upper-cased) bytes of query qidx as used for seeding and alignment */
+int64_t so_masked_query(so_ctx *ctx, int64_t qidx, char *buf, int64_t cap);
+/* candidates [subject, ungapped score, qi, qj] x uint32 of query qidx from the last
+ * so_search_loaded() call, in the order the reference's spill file holds them (chunk-major) */
+int64_t so_query_candidates(so_ctx *ctx, int64_t qidx, uint32_t *out4, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOHIT_H */

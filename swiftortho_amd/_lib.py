@@ -1,0 +1,89 @@
+"""ctypes binding of libsohit.so (include/sohit.h).  No fallback: if the HIP library is
+missing or no GPU is usable, importing/creating a context raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(HERE, "libsohit.so")
+
+
+class SoParams(C.Structure):
+    _fields_ = [("seeds", C.c_char_p), ("alphabet", C.c_char_p), ("nc", C.c_int64), ("chunk", C.c_int64), ("step", C.c_int64),
+                ("max_hits", C.c_int64), ("thr", C.c_int64), ("expect", C.c_double), ("max_miss", C.c_double),
+                ("filter", C.c_int32), ("profile", C.c_int32)]
+
+
+class SoHit(C.Structure):
+    _fields_ = [("qidx", C.c_int64), ("sidx", C.c_int64), ("identity", C.c_double), ("evalue", C.c_double), ("aln", C.c_int32),
+                ("mis", C.c_int32), ("gap", C.c_int32), ("qst", C.c_int32), ("qed", C.c_int32), ("sst", C.c_int32),
+                ("sed", C.c_int32), ("bit", C.c_int32), ("qlen", C.c_int32), ("slen", C.c_int32), ("matches", C.c_int32),
+                ("ungapped", C.c_int32)]
+
+
+class SoCounters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_queries", "query_aa", "ref_seqs", "ref_aa", "n_chunks", "seed_windows", "seed_hits",
+                                         "groups", "candidates", "alignments", "cells", "rows", "index_entries")] + \
+               [("lookup_launches", C.c_int64), ("lookup_ms", C.c_double), ("lookup_bytes", C.c_int64),
+                ("bounds_launches", C.c_int64), ("bounds_ms", C.c_double), ("bounds_bytes", C.c_int64),
+                ("align_launches", C.c_int64), ("align_ms", C.c_double),
+                ("index_ms", C.c_double), ("seed_ms", C.c_double), ("group_ms", C.c_double), ("phase2_ms", C.c_double),
+                ("total_ms", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/sohit.h declares
+EXPORTS = ["so_abi_version", "so_create", "so_destroy", "so_last_error", "so_load_ref", "so_load_ref_mem", "so_build_index",
+           "so_load_queries", "so_load_queries_mem", "so_num_queries", "so_num_refs", "so_query_len", "so_search_loaded",
+           "so_search", "so_free_hits", "so_write_sc", "so_format_hit", "so_get_counters", "so_reset_counters",
+           "so_chunk_threshold", "so_chunk_entries", "so_chunk_download", "so_masked_query", "so_query_candidates"]
+
+_lib = None
+
+
+def load():
+    """Load libsohit.so (never builds, never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIBPATH):
+        raise ImportError("libsohit.so is missing (%s): run `python -m swiftortho_amd.build` -- there is no CPU fallback" % LIBPATH)
+    L = C.CDLL(LIBPATH)
+    vp, i64, cp = C.c_void_p, C.c_int64, C.c_char_p
+    L.so_abi_version.restype = C.c_int
+    L.so_create.restype = vp
+    L.so_create.argtypes = [C.c_int, C.POINTER(SoParams)]
+    L.so_destroy.argtypes = [vp]
+    L.so_last_error.restype = cp
+    L.so_last_error.argtypes = [vp]
+    L.so_load_ref.argtypes = [vp, cp, i64, i64]
+    L.so_load_ref_mem.argtypes = [vp, cp, i64, i64, i64]
+    L.so_build_index.argtypes = [vp]
+    L.so_load_queries.argtypes = [vp, cp]
+    L.so_load_queries_mem.argtypes = [vp, cp, i64]
+    for f in ("so_num_queries", "so_num_refs"):
+        getattr(L, f).restype = i64
+        getattr(L, f).argtypes = [vp]
+    L.so_query_len.restype = i64
+    L.so_query_len.argtypes = [vp, i64]
+    L.so_search_loaded.argtypes = [vp, i64, i64, C.POINTER(C.POINTER(SoHit)), C.POINTER(i64)]
+    L.so_search.argtypes = [vp, cp, i64, i64, C.POINTER(C.POINTER(SoHit)), C.POINTER(i64)]
+    L.so_free_hits.argtypes = [C.POINTER(SoHit)]
+    L.so_write_sc.argtypes = [vp, C.POINTER(SoHit), i64, cp, cp]
+    L.so_format_hit.restype = i64
+    L.so_format_hit.argtypes = [vp, C.POINTER(SoHit), cp, i64]
+    L.so_get_counters.argtypes = [vp, C.POINTER(SoCounters)]
+    L.so_reset_counters.argtypes = [vp]
+    for f in ("so_chunk_threshold", "so_chunk_entries"):
+        getattr(L, f).restype = i64
+        getattr(L, f).argtypes = [vp, i64]
+    L.so_chunk_download.argtypes = [vp, i64, vp, vp]
+    L.so_masked_query.restype = i64
+    L.so_masked_query.argtypes = [vp, i64, cp, i64]
+    L.so_query_candidates.restype = i64
+    L.so_query_candidates.argtypes = [vp, i64, vp, i64]
+    if L.so_abi_version() != 1:
+        raise ImportError("libsohit.so ABI version mismatch")
+    _lib = L
+    return L

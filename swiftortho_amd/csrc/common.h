@@ -1,0 +1,119 @@
+// common.h -- shared declarations of libsohit.so (host orchestration + HIP kernels, gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+typedef int64_t i64;
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint16_t u16;
+typedef uint8_t u8;
+
+struct SoError : std::runtime_error {
+    explicit SoError(const std::string& m) : std::runtime_error(m) {}
+};
+
+#define HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            throw SoError(std::string("HIP error ") + hipGetErrorString(_e) + " at " + __FILE__ + ":" +   \
+                          std::to_string(__LINE__) + " in " #expr);                                       \
+    } while (0)
+
+// Grow-only device buffer.
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n, bool keep = false, hipStream_t st = 0) {
+        if (n <= cap) return;
+        size_t nc = n + n / 8 + 64;
+        T* np_ = nullptr;
+        HIP_CHECK(hipMalloc((void**)&np_, nc * sizeof(T)));
+        if (keep && p && cap) {
+            HIP_CHECK(hipMemcpyAsync(np_, p, cap * sizeof(T), hipMemcpyDeviceToDevice, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        if (p) (void)hipFree(p);
+        p = np_;
+        cap = nc;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Residue classes
+//   hash class (5 bit, packed):  0..29 = distinct values of code[byte] present in the run's alphabet
+//                                 map, 30 = sequence separator, 31 = 'x'/'X' (window rejected);
+//                                 both 30 and 31 invalidate a seed window (fsearch.py:538-540).
+//   score class (8 bit array):    0..22 = the 23 BLOSUM62 letters (either case), 23 = anything else (-4)
+// ------------------------------------------------------------------------------------------------
+#define HCLS_SEP 30
+#define HCLS_X 31
+#define SCLS_N 24
+#define MAX_PATTERNS 8   // seed patterns per run (S)
+#define MAX_ALPHA 4      // alphabets per run (A)
+#define MAX_SEEDLEN 32   // longest spaced-seed pattern
+#define MIN_UNGAP 25     // self.min, fsearch.py:2224
+#define DROPX 30
+
+struct SeedCfg {
+    int S, A;                       // #patterns, #alphabets
+    int klen[MAX_PATTERNS];         // pattern lengths
+    u32 care[MAX_PATTERNS];         // bit j set = position j is a '1' (care) position
+    int mink;                       // shortest pattern length (fsearch.py:2219)
+    u32 lut[MAX_ALPHA][32];         // hash class -> code[ch] value per alphabet (fsearch.py:543-547)
+    u32 nc;                         // bucket count
+};
+
+// Sort-key layout of one seed hit: [q | subj | diag | qpos | as | tag] from MSB to LSB.
+struct KeyLayout {
+    int bq, bs, bd, bp, ba;         // bit widths
+    int sh_tag, sh_as, sh_qpos, sh_diag, sh_subj, sh_q;
+    int total;
+    i64 diag_off;                   // added to (qpos - sst) to make it non-negative
+    void finish() {
+        sh_tag = 0;
+        sh_as = ba;
+        sh_qpos = 2 * ba;
+        sh_diag = sh_qpos + bp;
+        sh_subj = sh_diag + bd;
+        sh_q = sh_subj + bs;
+        total = sh_q + bq;
+    }
+};
+
+// One alignment task / result (phase 2).
+struct AlnTask {
+    u32 q;        // query index local to the batch
+    u32 subj;     // global subject id
+    u32 qi, qj;   // start offsets (fsearch.py:3063, 3069-3070)
+    u32 score;    // ungapped candidate score
+    u32 rank;     // position in the query's sorted candidate list
+};
+
+struct AlnRes {
+    int maxscore, aln, matches, gap;
+    int qst, qed, sst, sed;  // 0-based start (exclusive) / end as kswat_st returns them
+    int cells;
+    int pad;
+};
+
+static inline int ceil_log2(u64 x) {  // bits needed to hold values in [0, x)
+    int b = 0;
+    while ((1ull << b) < x) ++b;
+    return b < 1 ? 1 : b;
+}

@@ -1,0 +1,1161 @@
+// host.hip -- libsohit.so host side: context, FASTA sets resident in HBM, per-chunk index build,
+// the batched search pipeline, row formatting and the C ABI of include/sohit.h.
+//
+// Product code.  Nothing here may call into oracle/ (the CPU restatement is test infrastructure);
+// there is no CPU fallback for any device stage.  Host-side work is limited to what the reference
+// also does outside its hot loops: FASTA indexing (fsearch.py:1543-1553, 2182-2199), SEG-like
+// query masking (2872-2928; table-driven, bit-identical libm logs), the per-chunk mu+2sd threshold
+// from exact device-side integer sums (746-761, 2248-2250), and text formatting (43-61, 3234-3243).
+#include "common.h"
+#include "kernels.h"
+#include "seedhash.h"
+#include "../../include/sohit.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <unordered_map>
+
+namespace {
+
+double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// libm entry points reached through volatile pointers so that no compiler folds pow(x, 2) / log
+double (*volatile p_pow)(double, double) = pow;
+double (*volatile p_log)(double) = log;
+double (*volatile p_log10)(double) = log10;
+double (*volatile p_sqrt)(double) = sqrt;
+
+std::vector<std::string> split(const std::string& s, char sep) {
+    std::vector<std::string> out;
+    size_t p = 0;
+    for (;;) {
+        size_t q = s.find(sep, p);
+        if (q == std::string::npos) {
+            out.push_back(s.substr(p));
+            break;
+        }
+        out.push_back(s.substr(p, q - p));
+        p = q + 1;
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BLOSUM62 by score class (fsearch.py:330-346).  Classes 0..22 = ARNDCQEGHILKMFPSTWYVBZX in either
+// case, class 23 = every other byte (-4 against everything, itself included).
+// ---------------------------------------------------------------------------------------------
+const char B62_ORDER[] = "ARNDCQEGHILKMFPSTWYVBZX";
+const signed char B62_ROWS[23][23] = {
+    {4, -1, -2, -2, 0, -1, -1, 0, -2, -1, -1, -1, -1, -2, -1, 1, 0, -3, -2, 0, -2, -1, 0},
+    {-1, 5, 0, -2, -3, 1, 0, -2, 0, -3, -2, 2, -1, -3, -2, -1, -1, -3, -2, -3, -1, 0, -1},
+    {-2, 0, 6, 1, -3, 0, 0, 0, 1, -3, -3, 0, -2, -3, -2, 1, 0, -4, -2, -3, 3, 0, -1},
+    {-2, -2, 1, 6, -3, 0, 2, -1, -1, -3, -4, -1, -3, -3, -1, 0, -1, -4, -3, -3, 4, 1, -1},
+    {0, -3, -3, -3, 9, -3, -4, -3, -3, -1, -1, -3, -1, -2, -3, -1, -1, -2, -2, -1, -3, -3, -2},
+    {-1, 1, 0, 0, -3, 5, 2, -2, 0, -3, -2, 1, 0, -3, -1, 0, -1, -2, -1, -2, 0, 3, -1},
+    {-1, 0, 0, 2, -4, 2, 5, -2, 0, -3, -3, 1, -2, -3, -1, 0, -1, -3, -2, -2, 1, 4, -1},
+    {0, -2, 0, -1, -3, -2, -2, 6, -2, -4, -4, -2, -3, -3, -2, 0, -2, -2, -3, -3, -1, -2, -1},
+    {-2, 0, 1, -1, -3, 0, 0, -2, 8, -3, -3, -1, -2, -1, -2, -1, -2, -2, 2, -3, 0, 0, -1},
+    {-1, -3, -3, -3, -1, -3, -3, -4, -3, 4, 2, -3, 1, 0, -3, -2, -1, -3, -1, 3, -3, -3, -1},
+    {-1, -2, -3, -4, -1, -2, -3, -4, -3, 2, 4, -2, 2, 0, -3, -2, -1, -2, -1, 1, -4, -3, -1},
+    {-1, 2, 0, -1, -3, 1, 1, -2, -1, -3, -2, 5, -1, -3, -1, 0, -1, -3, -2, -2, 0, 1, -1},
+    {-1, -1, -2, -3, -1, 0, -2, -3, -2, 1, 2, -1, 5, 0, -2, -1, -1, -1, -1, 1, -3, -1, -1},
+    {-2, -3, -3, -3, -2, -3, -3, -3, -1, 0, 0, -3, 0, 6, -4, -2, -2, 1, 3, -1, -3, -3, -1},
+    {-1, -2, -2, -1, -3, -1, -1, -2, -2, -3, -3, -1, -2, -4, 7, -1, -1, -4, -3, -2, -2, -1, -2},
+    {1, -1, 1, 0, -1, 0, 0, 0, -1, -2, -2, 0, -1, -2, -1, 4, 1, -3, -2, -2, 0, 0, 0},
+    {0, -1, 0, -1, -1, -1, -1, -2, -2, -1, -1, -1, -1, -2, -1, 1, 5, -2, -2, 0, -1, -1, 0},
+    {-3, -3, -4, -4, -2, -2, -3, -2, -2, -3, -2, -3, -1, 1, -4, -3, -2, 11, 2, -3, -4, -3, -2},
+    {-2, -2, -2, -3, -2, -1, -2, -3, 2, -1, -1, -2, -1, 3, -3, -2, -2, 2, 7, -1, -3, -2, -1},
+    {0, -3, -3, -3, -1, -2, -2, -3, -3, 3, 1, -2, 1, -1, -2, -2, 0, -3, -1, 4, -3, -2, -1},
+    {-2, -1, 3, 4, -3, 0, 1, -1, 0, -3, -4, 0, -3, -3, -2, 0, -1, -4, -3, -3, 4, 1, -1},
+    {-1, 0, 0, 1, -3, 3, 4, -2, 0, -3, -3, 1, -1, -3, -1, 0, -1, -3, -2, -2, 1, 4, -1},
+    {0, -1, -1, -1, -2, -1, -1, -1, -1, -1, -1, -1, -1, -1, -2, 0, 0, -2, -1, -1, -1, -1, -1},
+};
+
+void build_score_maps(u8 smap[256], signed char b62c[SCLS_N * SCLS_N]) {
+    for (int i = 0; i < 256; ++i) smap[i] = SCLS_N - 1;
+    for (int k = 0; k < 23; ++k) {
+        smap[(u8)B62_ORDER[k]] = (u8)k;
+        smap[(u8)(B62_ORDER[k] + 32)] = (u8)k;
+    }
+    for (int a = 0; a < SCLS_N; ++a)
+        for (int b = 0; b < SCLS_N; ++b) b62c[a * SCLS_N + b] = (a < 23 && b < 23) ? B62_ROWS[a][b] : -4;
+}
+
+// generate_nr_tbl (fsearch.py:406-422), bytes 0..255 only
+void nr_table(const std::string& gaa, int tbl[256]) {
+    for (int i = 0; i < 256; ++i) tbl[i] = i;
+    std::string up = gaa;
+    for (auto& c : up) c = (char)toupper((unsigned char)c);
+    for (auto& grp : split(up, ',')) {
+        int flag = 1024;
+        for (unsigned char c : grp) flag = std::min(flag, (int)c);
+        for (unsigned char c : grp) {
+            tbl[c] = flag;
+            tbl[(unsigned char)tolower(c)] = flag;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FASTA set: host index (fsearch.py:1543-1553) + device-resident arrays
+// ---------------------------------------------------------------------------------------------
+struct SeqSet {
+    std::string data;            // raw file bytes
+    std::vector<i64> rec;        // record offsets (idx)
+    std::vector<u32> hd_beg, hd_len;  // header span of each record (without '>')
+    i64 N = 0;
+    std::vector<u32> off;        // [N+1] residue offsets
+    std::vector<u8> res;         // concatenated residues (raw bytes)
+    u32 maxlen = 0;
+    // device
+    DevBuf<u8> d_res, d_scls;
+    DevBuf<u32> d_off, d_words, d_pseq;
+    u32 P = 0, Ppad = 0;
+    HashLut lut;
+
+    void parse() {
+        rec.clear();
+        rec.push_back(0);
+        const i64 n = (i64)data.size();
+        for (i64 i = 1; i < n; ++i)
+            if (data[i] == '>' && data[i - 1] == '\n') rec.push_back(i);
+        N = (i64)rec.size();
+        off.assign((size_t)N + 1, 0);
+        hd_beg.resize((size_t)N);
+        hd_len.resize((size_t)N);
+        res.clear();
+        res.reserve(data.size());
+        maxlen = 0;
+        for (i64 x = 0; x < N; ++x) {
+            i64 st = rec[x], ed = (x == N - 1) ? n : rec[x + 1];
+            i64 p = st;
+            while (p < ed && data[p] != '\n') ++p;
+            hd_beg[x] = (u32)std::min<i64>(st + 1, p);
+            hd_len[x] = (u32)(p > st ? p - st - 1 : 0);
+            ++p;
+            while (p < ed) {
+                i64 q = p;
+                while (q < ed && data[q] != '\n') ++q;
+                res.insert(res.end(), data.begin() + p, data.begin() + q);
+                p = q + 1;
+            }
+            if (res.size() >= 0xFFFFFF00ull) throw SoError("sequence set exceeds 4 Gi residues");
+            off[x + 1] = (u32)res.size();
+            maxlen = std::max(maxlen, off[x + 1] - off[x]);
+        }
+    }
+    std::string header(i64 x) const { return data.substr(hd_beg[x], hd_len[x]); }
+    std::string ident(i64 x) const {
+        std::string h = header(x);
+        return h.substr(0, h.find(' '));
+    }
+    u32 len(i64 x) const { return off[x + 1] - off[x]; }
+};
+
+// 5-bit hash classes for one residue array under the run's alphabets
+void build_hash_classes(const u8* bytes, size_t n, const std::vector<std::array<int, 256>>& codes, u8 hmap[256], HashLut& lut) {
+    bool present[256] = {false};
+    for (size_t i = 0; i < n; ++i) present[bytes[i]] = true;
+    memset(&lut, 0, sizeof lut);
+    std::vector<std::vector<int>> tuples;
+    for (int b = 0; b < 256; ++b) {
+        hmap[b] = HCLS_X;  // absent bytes never occur; x/X reject the window
+        if (!present[b] || b == 'x' || b == 'X') continue;
+        std::vector<int> t;
+        for (auto& c : codes) t.push_back(c[b]);
+        size_t k = 0;
+        for (; k < tuples.size(); ++k)
+            if (tuples[k] == t) break;
+        if (k == tuples.size()) {
+            if (tuples.size() >= HCLS_SEP)
+                throw SoError("more than 30 distinct residue codes in the input: cannot pack hash classes into 5 bits");
+            tuples.push_back(t);
+            for (size_t a = 0; a < codes.size(); ++a) lut.v[a][k] = (u32)t[a];
+        }
+        hmap[b] = (u8)k;
+    }
+}
+
+struct ChunkIndex {
+    i64 seq_lo = 0, seq_hi = 0;
+    u32 p_lo = 0, p_hi = 0;
+    u32 E = 0;
+    i64 threshold = 0;
+    u32 maxslen = 0;
+    DevBuf<u32> start;    // NC + 1
+    DevBuf<u64> entries;  // E
+};
+
+}  // namespace
+
+struct so_ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    // params
+    std::string seeds, alphabet;
+    i64 nc = 0, chunk = 50000, step = 1, v = 500, thr = -1;
+    double expect = 1e-3, max_miss = 1e-3;
+    bool filter = true, profile = false;
+    SeedCfg cfg;
+    std::vector<std::array<int, 256>> codes;
+    std::string err;
+    // constant device tables
+    DevBuf<u8> d_smap, d_hmap;
+    DevBuf<signed char> d_b62c;
+    DevBuf<int> d_bittab;
+    u8 smap[256];
+    signed char b62c[SCLS_N * SCLS_N];
+    static const int BITTAB_N = 1 << 16;
+    // sets
+    SeqSet ref, qry;
+    bool ref_loaded = false, qry_loaded = false, index_built = false;
+    i64 r_lo = -1, r_hi = -1;
+    std::vector<std::unique_ptr<ChunkIndex>> chunks;
+    // masked query cache of the last batch / search (for so_masked_query)
+    std::vector<std::string> masked;     // indexed by qidx - masked_lo
+    i64 masked_lo = 0;
+    std::vector<std::vector<u32>> last_cands;  // per query of last search: 4 x u32 per cand
+    i64 last_q_lo = 0;
+    so_counters cnt;
+    // scratch
+    DevBuf<u32> d_scan_tmp, d_tmp32a, d_tmp32b;
+    DevBuf<u64> d_stats;
+    DevBuf<u8> d_pcls;
+    DevBuf<u8> d_sort_tmp;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    size_t max_hits_per_pass = (size_t)1 << 30;
+    u32 max_batch = 16384;
+};
+
+namespace {
+
+std::string g_create_err;
+
+void set_params(so_ctx* c, const so_params* p) {
+    c->seeds = p->seeds ? p->seeds : "111111";
+    c->alphabet = p->alphabet ? p->alphabet : "AST,CFILMVY,DN,EQ,G,H,KR,P,W";
+    if (c->alphabet == "aa9") c->alphabet = "AST,CFILMVY,DN,EQ,G,H,KR,P,W";
+    if (c->alphabet == "aa20") c->alphabet = "A,S,T,C,F,I,L,M,V,Y,D,N,E,Q,G,H,K,R,P,W";
+    c->nc = p->nc;
+    c->chunk = p->chunk > 0 ? p->chunk : 50000;
+    c->step = p->step;
+    c->v = p->max_hits;
+    c->thr = p->thr;
+    c->expect = p->expect;
+    c->max_miss = std::max(p->max_miss, 1e-3);  // fsearch.py:2970
+    c->filter = p->filter != 0;
+    c->profile = p->profile != 0;
+    if (c->nc < 1 || c->nc > 0xFFFFFFF0ll) throw SoError("-M (bucket count) must be in [1, 2^32)");
+    if (c->step < 1) throw SoError("-j (seed step) must be >= 1");
+    auto pats = split(c->seeds, ',');
+    auto alphas = split(c->alphabet, '/');
+    if (pats.empty() || (int)pats.size() > MAX_PATTERNS) throw SoError("1.." + std::to_string(MAX_PATTERNS) + " seed patterns supported");
+    if (alphas.empty() || (int)alphas.size() > MAX_ALPHA) throw SoError("1.." + std::to_string(MAX_ALPHA) + " alphabets supported");
+    memset(&c->cfg, 0, sizeof c->cfg);
+    c->cfg.S = (int)pats.size();
+    c->cfg.A = (int)alphas.size();
+    c->cfg.nc = (u32)c->nc;
+    c->cfg.mink = 1 << 30;
+    for (int s = 0; s < c->cfg.S; ++s) {
+        const std::string& sp = pats[s];
+        if (sp.empty() || sp.size() > MAX_SEEDLEN) throw SoError("seed pattern length must be 1.." + std::to_string(MAX_SEEDLEN));
+        c->cfg.klen[s] = (int)sp.size();
+        c->cfg.mink = std::min(c->cfg.mink, (int)sp.size());
+        u32 care = 0;
+        for (size_t j = 0; j < sp.size(); ++j)
+            if (sp[j] != '0') care |= 1u << j;  // fsearch.py:541 `space[j] != '0'`
+        c->cfg.care[s] = care;
+    }
+    c->codes.clear();
+    for (auto& a : alphas) {
+        std::array<int, 256> t;
+        nr_table(a, t.data());
+        c->codes.push_back(t);
+    }
+}
+
+void upload_constants(so_ctx* c) {
+    build_score_maps(c->smap, c->b62c);
+    c->d_smap.ensure(256);
+    c->d_hmap.ensure(256);
+    c->d_b62c.ensure(SCLS_N * SCLS_N);
+    HIP_CHECK(hipMemcpy(c->d_smap.p, c->smap, 256, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(c->d_b62c.p, c->b62c, SCLS_N * SCLS_N, hipMemcpyHostToDevice));
+    // score2bit (fsearch.py:1066-1071) tabulated on the host: the device never evaluates it
+    std::vector<int> bt(so_ctx::BITTAB_N);
+    for (int s = 0; s < so_ctx::BITTAB_N; ++s) bt[s] = (int)((.267 * (double)s + 3.1941832122778293) / 0.69314718055994529);
+    c->d_bittab.ensure(so_ctx::BITTAB_N);
+    HIP_CHECK(hipMemcpy(c->d_bittab.p, bt.data(), bt.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->d_stats.ensure(8);
+}
+
+// device-resident arrays of a sequence set given its (possibly masked) residues
+void upload_set(so_ctx* c, SeqSet& s, const u8* residues, const std::vector<u32>& off, u32 nseq, bool want_pseq) {
+    const size_t nres = off[nseq];
+    u8 hmap[256];
+    build_hash_classes(residues, nres, c->codes, hmap, s.lut);
+    s.d_res.ensure(nres + 64);
+    s.d_scls.ensure(nres + 64);
+    s.d_off.ensure((size_t)nseq + 1);
+    HIP_CHECK(hipMemcpyAsync(s.d_res.p, residues, nres, hipMemcpyHostToDevice, c->st));
+    HIP_CHECK(hipMemcpyAsync(s.d_off.p, off.data(), ((size_t)nseq + 1) * sizeof(u32), hipMemcpyHostToDevice, c->st));
+    HIP_CHECK(hipMemcpyAsync(c->d_hmap.p, hmap, 256, hipMemcpyHostToDevice, c->st));
+    launch_scls(s.d_res.p, nres, c->d_smap.p, s.d_scls.p, c->st);
+    if ((u64)nres + nseq + 64 > 0xFFFFFFF0ull) throw SoError("sequence set too large for 32-bit packed positions");
+    s.P = (u32)(nres + nseq);
+    s.Ppad = (s.P + 31u) & ~31u;
+    if (s.Ppad == 0) s.Ppad = 32;
+    s.d_words.ensure((size_t)s.Ppad / 32 * 5 + 4);
+    HIP_CHECK(hipMemsetAsync(s.d_words.p, 0, ((size_t)s.Ppad / 32 * 5 + 4) * sizeof(u32), c->st));
+    s.d_pseq.ensure(s.Ppad);
+    c->d_pcls.ensure(s.Ppad);
+    launch_layout(s.d_res.p, s.d_off.p, nseq, s.P, s.Ppad, c->d_hmap.p, s.d_pseq.p, c->d_pcls.p, s.d_words.p, c->st);
+    HIP_CHECK(hipStreamSynchronize(c->st));  // hmap (stack) and host buffers must outlive the copies
+    (void)want_pseq;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SEG-like masking (fsearch.py:2872-2928; entropy 2854-2868; Counter 157-177).  Only output[:n]
+// is used downstream (2996, 3034).  Logs come from a table of libm values so the arithmetic is
+// bit-identical to evaluating log() in place.
+// ---------------------------------------------------------------------------------------------
+struct SegTables {
+    double lg12[64];      // log(k / 12.)
+    double lgn[13][32];   // log(j / n), n = first-window length (1..12)
+    double log2v;
+    SegTables() {
+        log2v = p_log(2);
+        for (int k = 1; k < 64; ++k) lg12[k] = p_log((double)k / 12.);
+        lg12[0] = 0;
+        for (int n = 1; n <= 12; ++n)
+            for (int j = 1; j < 32; ++j) lgn[n][j] = p_log((double)j / ((double)n * 1.));
+    }
+};
+const SegTables& seg_tables() {
+    static SegTables t;
+    return t;
+}
+
+void seg_mask(const u8* S, int n, u8* out) {
+    const SegTables& T = seg_tables();
+    const double minent = 2.2, window = 12.;
+    if (n <= 0) return;
+    std::vector<u8> s((size_t)n);
+    for (int i = 0; i < n; ++i) s[i] = (S[i] >= 'a' && S[i] <= 'z') ? (u8)(S[i] - 32) : S[i];
+    int counts[256];
+    int order[12], norder = 0;
+    const int w = std::min(n, 12);
+    bool seen[256];
+    for (int i = 0; i < w; ++i) seen[s[i]] = false, counts[s[i]] = 0;
+    // Counter(seq): first occurrence 0, then +1 each; the explicit loop adds 1 per char -> 2*occ - 1
+    for (int i = 0; i < w; ++i) {
+        u8 c = s[i];
+        if (!seen[c]) seen[c] = true, counts[c] = 0, order[norder++] = c;
+        else counts[c] += 1;
+    }
+    for (int i = 0; i < w; ++i) counts[s[i]] += 1;
+    double ent = 0;
+    for (int k = 0; k < norder; ++k) {
+        int j = counts[order[k]];
+        double freq = (double)j / ((double)w * 1.);
+        ent -= freq * T.lgn[w][j];
+    }
+    ent /= T.log2v;
+    // characters entering later start from 0
+    std::vector<u8> mask((size_t)n, 0);
+    if (ent < minent) mask[0] = 1;
+    bool touched[256];
+    memset(touched, 0, sizeof touched);
+    for (int k = 0; k < norder; ++k) touched[order[k]] = true;
+    for (int i = 1; i < n - 12 + 1; ++i) {
+        const u8 pre = s[i - 1], cur = s[i + 11];
+        if (pre == cur) {
+            mask[i] = mask[i - 1];
+            continue;
+        }
+        if (!touched[cur]) touched[cur] = true, counts[cur] = 0;
+        const int pre_count = counts[pre];
+        counts[pre] -= 1;
+        const int cur_count = counts[cur];
+        counts[cur] += 1;
+        double a = (double)pre_count / window, b = (double)counts[pre] / window;
+        double t;
+        if (counts[pre] != 0) {
+            t = (a * T.lg12[pre_count] - b * T.lg12[counts[pre]]) / T.log2v;
+            if (t == 0) t = a * T.lg12[pre_count] / T.log2v;
+        } else {
+            t = a * T.lg12[pre_count] / T.log2v;
+        }
+        ent += t;
+        a = (double)cur_count / window;
+        b = (double)counts[cur] / window;
+        if (cur_count != 0) {
+            t = (a * T.lg12[cur_count] - b * T.lg12[counts[cur]]) / T.log2v;
+            if (t == 0) t = -b * T.lg12[counts[cur]] / T.log2v;
+        } else {
+            t = -b * T.lg12[counts[cur]] / T.log2v;
+        }
+        ent += t;
+        if (ent < minent) mask[i] = 1;
+    }
+    const int Nws = std::max(0, n - 12);
+    if (mask[Nws] == 1)
+        for (int i = Nws; i < n; ++i) mask[i] = 1;
+    int st = 0, o = 0;
+    while (st < n) {
+        if (mask[st] == 0) {
+            out[o++] = s[st];
+            st += 1;
+        } else {
+            for (int k = 0; k < 12 && o < n; ++k) out[o++] = 'x';
+            st += 12;
+        }
+    }
+}
+
+template <class F>
+void parallel_for(i64 n, F f) {
+    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (n < 256 || nt == 1) {
+        for (i64 i = 0; i < n; ++i) f(i);
+        return;
+    }
+    std::atomic<i64> next(0);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&] {
+            for (;;) {
+                i64 b = next.fetch_add(64);
+                if (b >= n) break;
+                for (i64 i = b; i < std::min(n, b + 64); ++i) f(i);
+            }
+        });
+    for (auto& t : th) t.join();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reference side
+// ---------------------------------------------------------------------------------------------
+void load_ref_common(so_ctx* c, i64 r_lo, i64 r_hi) {
+    c->ref.parse();
+    c->r_lo = r_lo, c->r_hi = r_hi;
+    upload_set(c, c->ref, c->ref.res.data(), c->ref.off, (u32)c->ref.N, true);
+    c->ref_loaded = true;
+    c->index_built = false;
+    c->chunks.clear();
+    c->cnt.ref_seqs = c->ref.N;
+    c->cnt.ref_aa = (i64)c->ref.res.size();
+}
+
+// threshold = int(mu + 2 sd) (fsearch.py:2248-2250, 746-761) from exact integer sums; when the
+// value is too close to an integer for that to be safe, replay the reference's sequential
+// floating-point loops over the counts in bucket order.
+i64 chunk_threshold(so_ctx* c, const u32* d_counts, u64 s1, u64 s2, u64 nn) {
+    const double N = (double)(nn + 1);
+    const double mu = (double)s1 / N;
+    long double lm = (long double)mu;
+    long double ss = (long double)s2 - 2.0L * lm * (long double)s1 + (long double)nn * lm * lm;
+    if (ss < 0) ss = 0;
+    long double T = lm + 2.0L * sqrtl(ss / (long double)N);
+    long double fl = floorl(T);
+    long double margin = ((long double)nn * 8e-16L + 1e-11L) * (T + 1.0L);
+    const bool forced = getenv("SOHIT_EXACT_THRESHOLD") != nullptr;
+    if (!forced && T - fl > margin && (fl + 1.0L) - T > margin) return (i64)fl;
+    // exact replay
+    std::vector<u32> counts((size_t)c->nc);
+    HIP_CHECK(hipMemcpyAsync(counts.data(), d_counts, (size_t)c->nc * sizeof(u32), hipMemcpyDeviceToHost, c->st));
+    HIP_CHECK(hipStreamSynchronize(c->st));
+    i64 Nn = 1;
+    double m = 0.;
+    for (u32 v : counts)
+        if (v > 0) m += (double)v, Nn += 1;
+    m /= (double)Nn;
+    double sd = 0.;
+    for (u32 v : counts)
+        if (v > 0) sd += p_pow((double)v - m, 2);
+    sd = p_sqrt(sd / (double)Nn);
+    return (i64)(m + 2 * sd);
+}
+
+void build_index(so_ctx* c) {
+    if (!c->ref_loaded) throw SoError("so_build_index: no reference loaded");
+    if (c->index_built) return;
+    const double t0 = wall();
+    c->chunks.clear();
+    const i64 N = c->ref.N;
+    i64 Start = c->r_lo == -1 ? 0 : std::max<i64>(0, c->r_lo);   // makedb, fsearch.py:2286-2288
+    i64 End = c->r_hi == -1 ? N : c->r_hi;
+    const u32 NC = (u32)c->nc;
+    c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)NC + 1) + 8);
+    c->cnt.index_entries = 0;
+    for (i64 s = Start; s < End; s += c->chunk) {
+        auto ch = std::make_unique<ChunkIndex>();
+        i64 e = std::min(s + c->chunk, End);
+        ch->seq_lo = std::min<i64>(std::max<i64>(0, s), N);  // build_msav clamps, 2233-2234
+        ch->seq_hi = std::min<i64>(e, N);
+        if (ch->seq_hi < ch->seq_lo) ch->seq_hi = ch->seq_lo;
+        ch->p_lo = c->ref.off[ch->seq_lo] + (u32)ch->seq_lo;
+        ch->p_hi = c->ref.off[ch->seq_hi] + (u32)ch->seq_hi;
+        ch->maxslen = 0;
+        for (i64 j = ch->seq_lo; j < ch->seq_hi; ++j) ch->maxslen = std::max(ch->maxslen, c->ref.len(j));
+        ch->start.ensure((size_t)NC + 4);
+        HIP_CHECK(hipMemsetAsync(ch->start.p, 0, ((size_t)NC + 4) * sizeof(u32), c->st));
+        launch_index_count(c->ref.d_words.p, c->ref.d_pseq.p, c->ref.d_off.p, ch->p_lo, ch->p_hi, c->ref.Ppad, (u32)ch->seq_lo, c->cfg,
+                           c->ref.lut, (u32)c->step, ch->start.p, c->st);
+        launch_index_stats(ch->start.p, NC, c->d_stats.p, c->st);
+        u64 stats[4];
+        HIP_CHECK(hipMemcpyAsync(stats, c->d_stats.p, sizeof stats, hipMemcpyDeviceToHost, c->st));
+        HIP_CHECK(hipStreamSynchronize(c->st));
+        const u64 E64 = stats[0];
+        if (E64 >= 0xFFFFFFF0ull) throw SoError("chunk index exceeds 2^32 entries; lower -c");
+        ch->E = (u32)E64;
+        ch->threshold = chunk_threshold(c, ch->start.p, stats[0], stats[1], stats[2]);
+        // inclusive scan in place: start[b] = end of bucket b; the fill pass walks it back to the begin
+        scan_u32(ch->start.p, ch->start.p, NC, true, c->d_scan_tmp.p, c->st);
+        HIP_CHECK(hipMemcpyAsync(ch->start.p + NC, &ch->E, sizeof(u32), hipMemcpyHostToDevice, c->st));
+        ch->entries.ensure((size_t)ch->E + 4);
+        launch_index_fill(c->ref.d_words.p, c->ref.d_pseq.p, c->ref.d_off.p, ch->p_lo, ch->p_hi, c->ref.Ppad, (u32)ch->seq_lo, c->cfg,
+                          c->ref.lut, (u32)c->step, ch->start.p, ch->entries.p, c->st);
+        if (ch->E > 0 && stats[3] > 0) launch_index_fixlast(ch->start.p, ch->entries.p, (u32)(stats[3] - 1), ch->E, c->st);
+        HIP_CHECK(hipStreamSynchronize(c->st));
+        c->cnt.index_entries += ch->E;
+        c->chunks.push_back(std::move(ch));
+    }
+    c->cnt.n_chunks = (i64)c->chunks.size();
+    c->index_built = true;
+    c->cnt.index_ms += (wall() - t0) * 1e3;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Search
+// ---------------------------------------------------------------------------------------------
+struct Batch {
+    i64 q_lo = 0, q_hi = 0;  // absolute query ordinals
+    u32 nq = 0;
+    std::vector<u8> h_res;   // masked residues
+    std::vector<u32> h_off;  // [nq+1]
+    u32 maxqlen = 0;
+    SeqSet dev;              // device arrays only (d_res = masked raw, d_scls, d_off, d_words, d_pseq)
+    DevBuf<u32> qbucket, korder, sbeg, scnt, pcnt, eff, nz, hoff, cidx;
+    DevBuf<int> ksc;
+    DevBuf<u8> mark;
+    DevBuf<u32> cs_hoff, cs_beg, cs_q, cs_qa, blk_first;
+    DevBuf<u64> keys, keys2;
+    DevBuf<u32> flags, gidx, ghead;
+    DevBuf<u64> p_qs, p_sd, p_ft, p_qs2, tmp64;
+    DevBuf<u32> pidx, pidx2, shead;
+    DevBuf<u64> c_ft, c_ft2;
+    DevBuf<u32> c_q, c_rec, order, order2;
+    DevBuf<u32> counters;  // [0] pass count, [1] hvalid
+    DevBuf<unsigned long long> ucount;  // [0] ungap steps, [1] cells
+    // candidate store
+    DevBuf<u32> cand_q, cand_rec;             // all chunks' regions concatenated
+    std::vector<u32> chunk_base;              // region start per chunk (+ total)
+    DevBuf<u32> ccnt;                         // [nchunks][nq] per-query counts
+    DevBuf<u32> cqoff, prior, qtot, qcoff, fin_rec, perm, ntask, toff, sel, nout, ooff;
+    DevBuf<AlnTask> tasks;
+    DevBuf<AlnRes> ares;
+    DevBuf<int> bits, outrec;
+    DevBuf<u32> trace;
+};
+
+void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
+    b.q_lo = q_lo, b.q_hi = q_hi, b.nq = (u32)(q_hi - q_lo);
+    const SeqSet& Q = c->qry;
+    b.h_off.assign((size_t)b.nq + 1, 0);
+    b.maxqlen = 0;
+    for (u32 i = 0; i < b.nq; ++i) {
+        u32 ln = Q.len(q_lo + i);
+        b.h_off[i + 1] = b.h_off[i] + ln;
+        b.maxqlen = std::max(b.maxqlen, ln);
+    }
+    b.h_res.resize(b.h_off[b.nq] + 16);
+    const u8* src = Q.res.data();
+    if (c->filter) {
+        parallel_for((i64)b.nq, [&](i64 i) {
+            seg_mask(src + Q.off[q_lo + i], (int)Q.len(q_lo + i), b.h_res.data() + b.h_off[i]);
+        });
+    } else if (b.h_off[b.nq]) {
+        memcpy(b.h_res.data(), src + Q.off[q_lo], b.h_off[b.nq]);
+    }
+    c->masked_lo = q_lo;
+    upload_set(c, b.dev, b.h_res.data(), b.h_off, b.nq, true);
+    const int AS = c->cfg.A * c->cfg.S;
+    const u32 Ppad = b.dev.Ppad;
+    const size_t T = (size_t)AS * Ppad;
+    b.qbucket.ensure(T);
+    launch_qhash(b.dev.d_words.p, Ppad, c->cfg, b.dev.lut, b.qbucket.p, c->st);
+    const size_t nres = b.h_off[b.nq];
+    b.ksc.ensure(nres + 1);
+    b.korder.ensure(nres + 1);
+    launch_ksc_order(b.dev.d_scls.p, b.dev.d_off.p, b.nq, c->cfg.mink, c->d_b62c.p, b.ksc.p, b.korder.p, c->st);
+    b.sbeg.ensure(T), b.scnt.ensure(T), b.eff.ensure(T + 4), b.nz.ensure(T + 4), b.hoff.ensure(T + 4), b.cidx.ensure(T + 4);
+    b.pcnt.ensure(Ppad), b.mark.ensure(Ppad);
+    b.counters.ensure(8);
+    b.ucount.ensure(4);
+    HIP_CHECK(hipMemsetAsync(b.ucount.p, 0, 4 * sizeof(unsigned long long), c->st));
+    c->d_scan_tmp.ensure(scan_u32_temp_elems(std::max<size_t>(T, (size_t)c->nc + 1)) + 8);
+    // seed windows hashed (valid or not): one per (as, residue)
+    c->cnt.seed_windows += (i64)AS * (i64)nres;
+}
+
+u32 d2h_u32(so_ctx* c, const u32* p) {
+    u32 v;
+    HIP_CHECK(hipMemcpyAsync(&v, p, sizeof v, hipMemcpyDeviceToHost, c->st));
+    HIP_CHECK(hipStreamSynchronize(c->st));
+    return v;
+}
+
+void ensure_sort_tmp(so_ctx* c, size_t bytes) { c->d_sort_tmp.ensure(bytes + 256); }
+
+struct ProfTimer {
+    so_ctx* c;
+    double* ms;
+    int64_t* launches;
+    bool on;
+    ProfTimer(so_ctx* c_, double* ms_, int64_t* l_) : c(c_), ms(ms_), launches(l_), on(c_->profile) {
+        if (on) HIP_CHECK(hipEventRecord(c->ev0, c->st));
+    }
+    void stop() {
+        if (!on) return;
+        HIP_CHECK(hipEventRecord(c->ev1, c->st));
+        HIP_CHECK(hipEventSynchronize(c->ev1));
+        float t = 0;
+        HIP_CHECK(hipEventElapsedTime(&t, c->ev0, c->ev1));
+        *ms += t;
+        *launches += 1;
+        on = false;
+    }
+};
+
+// seed stage of one (batch, chunk): candidates appended to the batch's candidate store
+void seed_stage(so_ctx* c, Batch& b, int ci) {
+    ChunkIndex& ch = *c->chunks[ci];
+    const int AS = c->cfg.A * c->cfg.S;
+    const u32 Ppad = b.dev.Ppad, NC = (u32)c->nc;
+    const size_t T = (size_t)AS * Ppad;
+    const u32 nseq_chunk = (u32)(ch.seq_hi - ch.seq_lo);
+    u32* qcnt = b.ccnt.p + (size_t)ci * b.nq;
+    b.chunk_base.push_back(b.chunk_base.empty() ? 0u : b.chunk_base.back());
+    if (nseq_chunk == 0 || ch.E == 0 || b.nq == 0) return;
+    const double t0 = wall();
+    {
+        ProfTimer pt(c, &c->cnt.bounds_ms, &c->cnt.bounds_launches);
+        launch_bounds(b.qbucket.p, Ppad, AS, ch.start.p, NC, ch.E, b.sbeg.p, b.scnt.p, b.pcnt.p, c->st);
+        pt.stop();
+        if (c->profile) c->cnt.bounds_bytes += (i64)8 * AS * (i64)b.h_off[b.nq];
+    }
+    HIP_CHECK(hipMemsetAsync(b.mark.p, 0, Ppad, c->st));
+    i64 threshold = ch.threshold;
+    if (c->thr >= 1 || threshold == 0) threshold = c->thr;  // `thr < 1 and DB.threshold or thr`, fsearch.py:2992
+    launch_cap(b.korder.p, b.dev.d_off.p, b.nq, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, c->st);
+    launch_effcnt(b.mark.p, b.scnt.p, Ppad, AS, b.eff.p, b.nz.p, c->st);
+    const u32* dH = scan_u32(b.eff.p, b.hoff.p, T, false, c->d_scan_tmp.p, c->st);
+    // NOTE: the scan's total lives in d_scan_tmp; fetch before the next scan overwrites it
+    u64 Hcheck = 0;
+    const u32 H = d2h_u32(c, dH);
+    (void)Hcheck;
+    const u32* dK = scan_u32(b.nz.p, b.cidx.p, T, false, c->d_scan_tmp.p, c->st);
+    const u32 K = d2h_u32(c, dK);
+    c->cnt.seed_hits += H;
+    if (H == 0 || K == 0) {
+        c->cnt.seed_ms += (wall() - t0) * 1e3;
+        return;
+    }
+    if ((size_t)H > c->max_hits_per_pass * 3) throw SoError("seed hits of one (batch, chunk) exceed the pass budget; lower SOHIT_BATCH");
+    // key layout
+    KeyLayout kl;
+    kl.bq = ceil_log2((u64)b.nq + 1);
+    kl.bs = ceil_log2(nseq_chunk);
+    kl.bp = ceil_log2(std::max<u32>(b.maxqlen, 2));
+    kl.bd = ceil_log2((u64)b.maxqlen + ch.maxslen + 1);
+    kl.ba = AS > 1 ? ceil_log2((u64)AS) : 0;
+    kl.diag_off = ch.maxslen;
+    kl.finish();
+    const int bsp = ceil_log2((u64)ch.maxslen + 1);
+    const int ft_bits_entry = (kl.bs + 1) + kl.ba + bsp;
+    if (kl.total > 64) throw SoError("sort key needs " + std::to_string(kl.total) + " bits (> 64): lower SOHIT_BATCH or -c");
+    if (kl.ba + kl.bp + ft_bits_entry > 64) throw SoError("first-touch key exceeds 64 bits: sequences too long for this build");
+    b.cs_hoff.ensure((size_t)K + 2), b.cs_beg.ensure((size_t)K + 2), b.cs_q.ensure((size_t)K + 2), b.cs_qa.ensure((size_t)K + 2);
+    launch_compact_seeds(b.eff.p, b.hoff.p, b.cidx.p, b.sbeg.p, b.dev.d_pseq.p, b.dev.d_off.p, Ppad, AS, b.cs_hoff.p, b.cs_beg.p,
+                         b.cs_q.p, b.cs_qa.p, c->st);
+    b.blk_first.ensure((size_t)lookup_num_blocks(H) + 2);
+    launch_lookup_blockfirst(b.cs_hoff.p, K, H, b.blk_first.p, c->st);
+    b.keys.ensure((size_t)H + 2), b.keys2.ensure((size_t)H + 2);
+    {
+        ProfTimer pt(c, &c->cnt.lookup_ms, &c->cnt.lookup_launches);
+        launch_lookup(b.cs_hoff.p, b.cs_beg.p, b.cs_q.p, b.cs_qa.p, b.blk_first.p, K, H, ch.entries.p, c->ref.d_off.p + ch.seq_lo, kl,
+                      b.keys.p, c->st);
+        pt.stop();
+        if (c->profile) c->cnt.lookup_bytes += (i64)8 * (i64)H;
+    }
+    const double t1 = wall();
+    // diagonal binning: sort keys, find group heads
+    ensure_sort_tmp(c, sort_keys_u64_temp_bytes(H, kl.total));
+    sort_keys_u64(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.keys.p, b.keys2.p, H, kl.total, c->st);
+    b.flags.ensure((size_t)H + 4), b.gidx.ensure((size_t)H + 4);
+    launch_group_flags(b.keys2.p, H, kl, b.flags.p, b.counters.p + 1, c->st);
+    c->d_scan_tmp.ensure(scan_u32_temp_elems(H) + 8);
+    const u32* dG = scan_u32(b.flags.p, b.gidx.p, H, false, c->d_scan_tmp.p, c->st);
+    const u32 G = d2h_u32(c, dG);
+    const u32 Hvalid = d2h_u32(c, b.counters.p + 1);
+    c->cnt.groups += G;
+    if (G == 0) {
+        c->cnt.seed_ms += (t1 - t0) * 1e3;
+        c->cnt.group_ms += (wall() - t1) * 1e3;
+        return;
+    }
+    b.ghead.ensure((size_t)G + 2);
+    launch_group_list(b.flags.p, b.gidx.p, H, b.ghead.p, c->st);
+    b.p_qs.ensure((size_t)G + 2), b.p_sd.ensure((size_t)G + 2), b.p_ft.ensure((size_t)G + 2);
+    HIP_CHECK(hipMemsetAsync(b.counters.p, 0, sizeof(u32), c->st));
+    launch_ungap(b.keys2.p, b.ghead.p, G, Hvalid, kl, ft_bits_entry, bsp, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls.p,
+                 c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.counters.p, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.ucount.p, c->st);
+    const u32 NP = d2h_u32(c, b.counters.p);
+    if (NP == 0) {
+        c->cnt.seed_ms += (t1 - t0) * 1e3;
+        c->cnt.group_ms += (wall() - t1) * 1e3;
+        return;
+    }
+    // best diagonal per (query, subject): sort pass records by (q, subject)
+    b.pidx.ensure((size_t)NP + 2), b.pidx2.ensure((size_t)NP + 2), b.p_qs2.ensure((size_t)NP + 2);
+    launch_iota(b.pidx.p, NP, c->st);
+    ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(NP, 64));
+    sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.p_qs.p, b.p_qs2.p, b.pidx.p, b.pidx2.p, NP, 32 + kl.bq, c->st);
+    b.flags.ensure((size_t)NP + 4), b.gidx.ensure((size_t)NP + 4);
+    launch_seg_flags(b.p_qs2.p, NP, b.flags.p, c->st);
+    const u32* dS = scan_u32(b.flags.p, b.gidx.p, NP, false, c->d_scan_tmp.p, c->st);
+    const u32 NS = d2h_u32(c, dS);
+    b.shead.ensure((size_t)NS + 2);
+    launch_group_list(b.flags.p, b.gidx.p, NP, b.shead.p, c->st);
+    b.c_ft.ensure((size_t)NS + 2), b.c_ft2.ensure((size_t)NS + 2), b.c_q.ensure((size_t)NS + 2), b.c_rec.ensure(4 * (size_t)NS + 8);
+    launch_best(b.p_qs2.p, b.pidx2.p, b.shead.p, NS, NP, b.p_sd.p, b.p_ft.p, (u32)ch.seq_lo, b.c_ft.p, b.c_q.p, b.c_rec.p, c->st);
+    // order candidates by (query, first-touch): sort by first-touch, then stable sort by query
+    b.order.ensure((size_t)NS + 2), b.order2.ensure((size_t)NS + 2), b.tmp64.ensure((size_t)NS + 2);
+    launch_iota(b.order.p, NS, c->st);
+    sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.c_ft.p, b.c_ft2.p, b.order.p, b.order2.p, NS, 64, c->st);
+    launch_gather_u32_as_u64(b.c_q.p, b.order2.p, NS, b.tmp64.p, c->st);
+    sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, b.order2.p, b.order.p, NS, kl.bq, c->st);
+    // append to the candidate store
+    const u32 base = b.chunk_base.back();
+    b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
+    b.cand_rec.ensure(4 * ((size_t)base + NS) + 16, true, c->st);
+    launch_emit_cands(b.order.p, NS, b.c_q.p, b.c_rec.p, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, c->st);
+    b.chunk_base.back() = base + NS;
+    c->cnt.candidates += NS;
+    HIP_CHECK(hipStreamSynchronize(c->st));
+    c->cnt.seed_ms += (t1 - t0) * 1e3;
+    c->cnt.group_ms += (wall() - t1) * 1e3;
+}
+
+struct HostRow {
+    int v[12];
+};
+
+void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
+    const double t0 = wall();
+    const int nchunks = (int)c->chunks.size();
+    const u32 nq = b.nq;
+    if (nq == 0) return;
+    const u32 Ntot = b.chunk_base.empty() ? 0u : b.chunk_base.back();
+    b.qtot.ensure((size_t)nq + 4), b.qcoff.ensure((size_t)nq + 4), b.prior.ensure((size_t)nq + 4), b.cqoff.ensure((size_t)nq + 4);
+    HIP_CHECK(hipMemsetAsync(b.qtot.p, 0, ((size_t)nq + 4) * sizeof(u32), c->st));
+    for (int ci = 0; ci < nchunks; ++ci) launch_add_u32(b.qtot.p, b.ccnt.p + (size_t)ci * nq, nq, c->st);
+    c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)nq + 1) + 8);
+    scan_u32(b.qtot.p, b.qcoff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
+    b.fin_rec.ensure(4 * (size_t)Ntot + 16);
+    HIP_CHECK(hipMemsetAsync(b.prior.p, 0, ((size_t)nq + 4) * sizeof(u32), c->st));
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const u32 lo = ci == 0 ? 0u : b.chunk_base[ci - 1], hi = b.chunk_base[ci];
+        const u32* cc = b.ccnt.p + (size_t)ci * nq;
+        if (hi > lo) {
+            scan_u32(cc, b.cqoff.p, nq, false, c->d_scan_tmp.p, c->st);
+            launch_gather_cands(b.cand_q.p + lo, b.cand_rec.p + 4 * (size_t)lo, hi - lo, b.cqoff.p, b.prior.p, b.qcoff.p, b.fin_rec.p,
+                                c->st);
+        }
+        launch_add_u32(b.prior.p, cc, nq, c->st);
+    }
+    // candidate dump for so_query_candidates
+    {
+        std::vector<u32> qcoff((size_t)nq + 1), rec(4 * (size_t)Ntot + 4);
+        HIP_CHECK(hipMemcpyAsync(qcoff.data(), b.qcoff.p, ((size_t)nq + 1) * sizeof(u32), hipMemcpyDeviceToHost, c->st));
+        if (Ntot) HIP_CHECK(hipMemcpyAsync(rec.data(), b.fin_rec.p, 4 * (size_t)Ntot * sizeof(u32), hipMemcpyDeviceToHost, c->st));
+        HIP_CHECK(hipStreamSynchronize(c->st));
+        if (getenv("SOHIT_KEEP_CANDS")) {
+            for (u32 q = 0; q < nq; ++q) {
+                auto& dst = c->last_cands[(size_t)(b.q_lo - c->last_q_lo) + q];
+                dst.assign(rec.begin() + 4 * (size_t)qcoff[q], rec.begin() + 4 * (size_t)qcoff[q + 1]);
+            }
+        }
+    }
+    if (Ntot == 0) {
+        c->cnt.phase2_ms += (wall() - t0) * 1e3;
+        return;
+    }
+    if (c->qry.maxlen >= 4096 || c->ref.maxlen >= 4096) {
+        // kswat_st_long (fsearch.py:1480-1498) tiling is not implemented on the device yet
+        bool any_long = false;
+        for (u32 i = 0; i < nq && !any_long; ++i) any_long = c->qry.len(b.q_lo + i) >= 4096;
+        if (any_long || c->ref.maxlen >= 4096)
+            throw SoError("sequences of >= 4096 residues need the tiled long-alignment path, which this build does not have yet");
+    }
+    const u32 vmax = (u32)std::max<i64>(100, std::max<i64>(c->v + 100, (i64)((double)c->v * 1.1)));  // fsearch.py:3059
+    b.perm.ensure((size_t)Ntot + 4), b.ntask.ensure((size_t)nq + 4), b.toff.ensure((size_t)nq + 4);
+    HIP_CHECK(hipMemsetAsync(b.ntask.p, 0, ((size_t)nq + 4) * sizeof(u32), c->st));
+    launch_csort(b.fin_rec.p, b.qcoff.p, nq, vmax, b.perm.p, b.ntask.p, c->st);
+    const u32* dNT = scan_u32(b.ntask.p, b.toff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
+    const u32 NT = d2h_u32(c, dNT);
+    b.tasks.ensure((size_t)NT + 4), b.ares.ensure((size_t)NT + 4), b.bits.ensure((size_t)NT + 4), b.sel.ensure((size_t)NT + 4);
+    launch_mktasks(b.fin_rec.p, b.qcoff.p, b.perm.p, b.ntask.p, b.toff.p, nq, b.tasks.p, c->st);
+    // banded alignments in slabs bounded by the trace scratch budget
+    const int maxrows = (int)std::min<u32>(std::max(b.maxqlen, c->ref.maxlen), std::min(b.maxqlen, c->ref.maxlen) + 16);
+    const u32 stride = align_trace_stride(maxrows + 1);
+    const size_t budget_words = (size_t)1 << 30;  // 4 GiB of trace scratch
+    const u32 slab = (u32)std::max<size_t>(16, std::min<size_t>(NT, budget_words / std::max<u32>(stride, 1)));
+    b.trace.ensure((size_t)slab * stride + 64);
+    {
+        ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
+        for (u32 t = 0; t < NT; t += slab) {
+            const u32 n = std::min(slab, NT - t);
+            launch_align(b.tasks.p + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p, c->ref.d_off.p,
+                         c->d_b62c.p, b.trace.p, stride, b.ares.p + t, c->st);
+        }
+        pt.stop();
+    }
+    launch_sum_cells(b.ares.p, NT, b.ucount.p + 1, c->st);
+    c->cnt.alignments += NT;
+    b.nout.ensure((size_t)nq + 4), b.ooff.ensure((size_t)nq + 4);
+    HIP_CHECK(hipMemsetAsync(b.nout.p, 0, ((size_t)nq + 4) * sizeof(u32), c->st));
+    launch_stop(b.tasks.p, b.ares.p, b.qcoff.p, b.ntask.p, b.toff.p, nq, b.dev.d_off.p, c->ref.d_off.p, c->d_bittab.p, so_ctx::BITTAB_N,
+                c->ref.N, c->expect, c->max_miss, c->v, b.sel.p, b.nout.p, b.bits.p, c->st);
+    const u32* dNO = scan_u32(b.nout.p, b.ooff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
+    const u32 NO = d2h_u32(c, dNO);
+    if (NO) {
+        b.outrec.ensure(12 * (size_t)NO + 16);
+        launch_emit_hits(b.tasks.p, b.ares.p, b.toff.p, b.sel.p, b.nout.p, b.ooff.p, b.bits.p, nq, b.outrec.p, c->st);
+        std::vector<HostRow> rows(NO);
+        HIP_CHECK(hipMemcpyAsync(rows.data(), b.outrec.p, 12 * (size_t)NO * sizeof(int), hipMemcpyDeviceToHost, c->st));
+        HIP_CHECK(hipStreamSynchronize(c->st));
+        const i64 D = c->ref.N;
+        for (u32 i = 0; i < NO; ++i) {
+            const int* v = rows[i].v;
+            so_hit h;
+            memset(&h, 0, sizeof h);
+            h.qidx = b.q_lo + v[0];
+            h.sidx = v[1];
+            h.aln = v[2], h.mis = v[3], h.gap = v[4], h.qst = v[5], h.qed = v[6], h.sst = v[7], h.sed = v[8], h.bit = v[9];
+            h.ungapped = v[10], h.matches = v[11];
+            h.qlen = (int32_t)c->qry.len(h.qidx);
+            h.slen = (int32_t)c->ref.len(h.sidx);
+            // idy: one += 1. per identical column, then idy *= (100. / AL) (fsearch.py:1458-1459, 1471)
+            h.identity = (double)h.matches * (100. / (double)h.aln);
+            // bit2e (1086): D * len(sqi) * len(sqj) * pow(2, -bit)
+            h.evalue = (double)(D * (i64)h.qlen * (i64)h.slen) * p_pow(2, (double)(-h.bit));
+            if (h.evalue <= c->expect) out.push_back(h);  // entry_point re-check (3234)
+        }
+    }
+    c->cnt.phase2_ms += (wall() - t0) * 1e3;
+}
+
+void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, std::vector<so_hit>& out) {
+    if (!c->ref_loaded) throw SoError("so_search: no reference loaded");
+    if (!c->qry_loaded) throw SoError("so_search: no queries loaded");
+    build_index(c);
+    const double t0 = wall();
+    const i64 N = c->qry.N, D = c->ref.N;
+    i64 st = std::min<i64>(std::max<i64>(0, q_lo), N);       // fsearch.py:2980
+    i64 ed = std::min<i64>(q_hi < 0 ? D : q_hi, N);          // 2981 (uses D when -u < 0)
+    if (ed < st) ed = st;
+    c->last_q_lo = st;
+    c->last_cands.assign((size_t)(ed - st), std::vector<u32>());
+    c->masked.clear();
+    const int nchunks = (int)c->chunks.size();
+    if (const char* e = getenv("SOHIT_BATCH")) c->max_batch = (u32)std::max(1, atoi(e));
+    for (i64 b0 = st; b0 < ed; b0 += c->max_batch) {
+        const i64 b1 = std::min<i64>(ed, b0 + c->max_batch);
+        Batch b;
+        for (i64 i = b0; i < b1; ++i)
+            if (c->qry.len(i) < (u32)c->cfg.mink && c->qry.len(i) > 0 && false) {}
+        prepare_batch(c, b, b0, b1);
+        b.ccnt.ensure((size_t)std::max(1, nchunks) * b.nq + 4);
+        HIP_CHECK(hipMemsetAsync(b.ccnt.p, 0, ((size_t)std::max(1, nchunks) * b.nq + 4) * sizeof(u32), c->st));
+        for (int ci = 0; ci < nchunks; ++ci) seed_stage(c, b, ci);
+        phase2(c, b, out);
+        unsigned long long uc[2] = {0, 0};
+        HIP_CHECK(hipMemcpyAsync(uc, b.ucount.p, sizeof uc, hipMemcpyDeviceToHost, c->st));
+        HIP_CHECK(hipStreamSynchronize(c->st));
+        c->cnt.cells += (i64)uc[1];
+        c->cnt.n_queries += b.nq;
+        c->cnt.query_aa += b.h_off[b.nq];
+        if (getenv("SOHIT_KEEP_MASKED")) {
+            if (c->masked.empty()) c->masked_lo = st;
+            for (u32 i = 0; i < b.nq; ++i)
+                c->masked.emplace_back((const char*)b.h_res.data() + b.h_off[i], (size_t)(b.h_off[i + 1] - b.h_off[i]));
+        }
+    }
+    c->cnt.rows += (i64)out.size();
+    c->cnt.total_ms += (wall() - t0) * 1e3;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row formatting (entry_point, fsearch.py:3234-3243; f2s 43-61)
+// ---------------------------------------------------------------------------------------------
+std::string fmt_f(double x) {
+    char buf[400];
+    snprintf(buf, sizeof buf, "%f", x);
+    return buf;
+}
+
+std::string f2s(double e) {
+    if (e <= 0) return "0";
+    if (e < 1e-3) {
+        double a = p_log10(e);
+        a -= (double)(i64)a;
+        if (a < 0) {
+            double t = 1 + a;
+            a = (t != 0) ? t : a;
+        }
+        double b = p_pow(10, a);
+        std::string s = fmt_f(p_log10(e / b));
+        size_t d = s.find('.');
+        s = s.substr(0, d == std::string::npos ? 0 : d);
+        std::string p = fmt_f(b);
+        d = p.find('.');
+        p = p.substr(0, d == std::string::npos ? 2 : d + 3);
+        return p + "e" + s;
+    }
+    return fmt_f(e);
+}
+
+std::string format_hit(so_ctx* c, const so_hit& h) {
+    if (h.qidx < 0 || h.qidx >= c->qry.N || h.sidx < 0 || h.sidx >= c->ref.N) throw SoError("so_format_hit: hit does not belong to the loaded files");
+    std::string idy = fmt_f(h.identity);
+    size_t d = idy.find('.');
+    idy = idy.substr(0, d == std::string::npos ? 2 : d + 3);
+    char nums[256];
+    snprintf(nums, sizeof nums, "%d\t%d\t%d\t%d\t%d\t%d\t%d", h.aln, h.mis, h.gap, h.qst, h.qed, h.sst, h.sed);
+    char tail[128];
+    snprintf(tail, sizeof tail, "%d\t%d\t%d\t%lld", h.bit, h.qlen, h.slen, (long long)h.qidx);
+    std::string row = c->qry.ident(h.qidx) + "\t" + c->ref.ident(h.sidx) + "\t" + idy + "\t" + nums + "\t" + f2s(h.evalue) + "\t" + tail +
+                      "\t" + c->ref.header(h.sidx) + "\n";
+    return row;
+}
+
+bool read_file(const char* path, std::string& out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize((size_t)std::max<long>(0, n));
+    bool ok = n <= 0 || fread(&out[0], 1, (size_t)n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+
+template <class F>
+int guarded(so_ctx* c, F f) {
+    try {
+        if (!c) return 1;
+        HIP_CHECK(hipSetDevice(c->device));
+        f();
+        c->err.clear();
+        return 0;
+    } catch (const std::exception& e) {
+        if (c) c->err = e.what();
+        return 1;
+    }
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int so_abi_version(void) { return SOHIT_ABI_VERSION; }
+
+so_ctx* so_create(int device, const so_params* params) {
+    so_ctx* c = nullptr;
+    try {
+        if (!params) throw SoError("so_create: params is NULL");
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) throw SoError("so_create: no HIP device available (libsohit has no CPU fallback)");
+        if (device < 0 || device >= n) throw SoError("so_create: device index out of range");
+        HIP_CHECK(hipSetDevice(device));
+        c = new so_ctx();
+        c->device = device;
+        memset(&c->cnt, 0, sizeof c->cnt);
+        set_params(c, params);
+        HIP_CHECK(hipStreamCreate(&c->st));
+        HIP_CHECK(hipEventCreate(&c->ev0));
+        HIP_CHECK(hipEventCreate(&c->ev1));
+        upload_constants(c);
+        g_create_err.clear();
+        return c;
+    } catch (const std::exception& e) {
+        g_create_err = e.what();
+        delete c;
+        return nullptr;
+    }
+}
+
+void so_destroy(so_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->st) (void)hipStreamSynchronize(c->st);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->st) (void)hipStreamDestroy(c->st);
+    delete c;
+}
+
+const char* so_last_error(const so_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int so_load_ref(so_ctx* c, const char* path, int64_t r_lo, int64_t r_hi) {
+    return guarded(c, [&] {
+        if (!read_file(path, c->ref.data)) throw SoError(std::string("cannot read reference FASTA ") + path);
+        load_ref_common(c, r_lo, r_hi);
+    });
+}
+
+int so_load_ref_mem(so_ctx* c, const char* bytes, int64_t n, int64_t r_lo, int64_t r_hi) {
+    return guarded(c, [&] {
+        c->ref.data.assign(bytes, (size_t)n);
+        load_ref_common(c, r_lo, r_hi);
+    });
+}
+
+int so_build_index(so_ctx* c) {
+    return guarded(c, [&] { build_index(c); });
+}
+
+int so_load_queries(so_ctx* c, const char* path) {
+    return guarded(c, [&] {
+        if (!read_file(path, c->qry.data)) throw SoError(std::string("cannot read query FASTA ") + path);
+        c->qry.parse();
+        c->qry_loaded = true;
+    });
+}
+
+int so_load_queries_mem(so_ctx* c, const char* bytes, int64_t n) {
+    return guarded(c, [&] {
+        c->qry.data.assign(bytes, (size_t)n);
+        c->qry.parse();
+        c->qry_loaded = true;
+    });
+}
+
+int64_t so_num_queries(const so_ctx* c) { return c && c->qry_loaded ? c->qry.N : -1; }
+int64_t so_num_refs(const so_ctx* c) { return c && c->ref_loaded ? c->ref.N : -1; }
+int64_t so_query_len(const so_ctx* c, int64_t q) { return (c && c->qry_loaded && q >= 0 && q < c->qry.N) ? (int64_t)c->qry.len(q) : -1; }
+
+int so_search_loaded(so_ctx* c, int64_t q_lo, int64_t q_hi, so_hit** hits, int64_t* n_hits) {
+    return guarded(c, [&] {
+        if (!hits || !n_hits) throw SoError("so_search: output pointers are NULL");
+        *hits = nullptr;
+        *n_hits = 0;
+        std::vector<so_hit> out;
+        search_loaded(c, q_lo, q_hi, out);
+        so_hit* p = (so_hit*)malloc(std::max<size_t>(1, out.size()) * sizeof(so_hit));
+        if (!p) throw SoError("out of host memory");
+        if (!out.empty()) memcpy(p, out.data(), out.size() * sizeof(so_hit));
+        *hits = p;
+        *n_hits = (int64_t)out.size();
+    });
+}
+
+int so_search(so_ctx* c, const char* qry_path, int64_t q_lo, int64_t q_hi, so_hit** hits, int64_t* n_hits) {
+    int rc = so_load_queries(c, qry_path);
+    if (rc) return rc;
+    return so_search_loaded(c, q_lo, q_hi, hits, n_hits);
+}
+
+void so_free_hits(so_hit* hits) { free(hits); }
+
+int64_t so_format_hit(so_ctx* c, const so_hit* hit, char* buf, int64_t cap) {
+    int64_t need = -1;
+    guarded(c, [&] {
+        std::string r = format_hit(c, *hit);
+        need = (int64_t)r.size();
+        if (buf && cap > 0) {
+            size_t k = std::min<size_t>(r.size(), (size_t)cap - 1);
+            memcpy(buf, r.data(), k);
+            buf[k] = 0;
+        }
+    });
+    return need;
+}
+
+int so_write_sc(so_ctx* c, const so_hit* hits, int64_t n, const char* path, const char* mode) {
+    return guarded(c, [&] {
+        FILE* f = fopen(path, (mode && mode[0] == 'a') ? "ab" : "wb");
+        if (!f) throw SoError(std::string("cannot open output ") + path);
+        std::string buf;
+        for (int64_t i = 0; i < n; ++i) {
+            buf += format_hit(c, hits[i]);
+            if (buf.size() > (1u << 22)) {
+                fwrite(buf.data(), 1, buf.size(), f);
+                buf.clear();
+            }
+        }
+        if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
+        fclose(f);
+    });
+}
+
+int so_get_counters(const so_ctx* c, so_counters* out) {
+    if (!c || !out) return 1;
+    *out = c->cnt;
+    return 0;
+}
+
+int so_reset_counters(so_ctx* c) {
+    if (!c) return 1;
+    so_counters keep = c->cnt;
+    memset(&c->cnt, 0, sizeof c->cnt);
+    c->cnt.ref_seqs = keep.ref_seqs, c->cnt.ref_aa = keep.ref_aa, c->cnt.n_chunks = keep.n_chunks;
+    c->cnt.index_entries = keep.index_entries;
+    return 0;
+}
+
+int64_t so_chunk_threshold(const so_ctx* c, int64_t k) { return (c && k >= 0 && k < (int64_t)c->chunks.size()) ? c->chunks[k]->threshold : -1; }
+int64_t so_chunk_entries(const so_ctx* c, int64_t k) { return (c && k >= 0 && k < (int64_t)c->chunks.size()) ? (int64_t)c->chunks[k]->E : -1; }
+
+int so_chunk_download(so_ctx* c, int64_t k, uint32_t* start, uint64_t* entries) {
+    return guarded(c, [&] {
+        if (k < 0 || k >= (int64_t)c->chunks.size()) throw SoError("so_chunk_download: no such chunk");
+        ChunkIndex& ch = *c->chunks[k];
+        if (start) HIP_CHECK(hipMemcpy(start, ch.start.p, ((size_t)c->nc + 1) * sizeof(u32), hipMemcpyDeviceToHost));
+        if (entries && ch.E) HIP_CHECK(hipMemcpy(entries, ch.entries.p, (size_t)ch.E * sizeof(u64), hipMemcpyDeviceToHost));
+    });
+}
+
+int64_t so_masked_query(so_ctx* c, int64_t q, char* buf, int64_t cap) {
+    if (!c) return -1;
+    i64 k = q - c->masked_lo;
+    if (k < 0 || k >= (i64)c->masked.size()) return -1;
+    const std::string& s = c->masked[(size_t)k];
+    if (buf && cap > 0) memcpy(buf, s.data(), std::min<size_t>(s.size(), (size_t)cap));
+    return (int64_t)s.size();
+}
+
+int64_t so_query_candidates(so_ctx* c, int64_t q, uint32_t* out4, int64_t cap) {
+    if (!c) return -1;
+    i64 k = q - c->last_q_lo;
+    if (k < 0 || k >= (i64)c->last_cands.size()) return -1;
+    const auto& v = c->last_cands[(size_t)k];
+    const int64_t n = (int64_t)v.size() / 4;
+    if (out4)
+        for (int64_t i = 0; i < std::min(n, cap) * 4; ++i) out4[i] = v[(size_t)i];
+    return n;
+}
+
+}  // extern "C"

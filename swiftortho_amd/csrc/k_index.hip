@@ -1,0 +1,154 @@
+// k_index.hip -- per-chunk seed index build on the device (Fasta.build_msav, fsearch.py:2208-2280).
+//
+//   start[0..NC]  u32   after the build: start[b] = first slot of bucket b, start[NC] = E
+//   entries[0..E) u64   (subject_local << 32) | (tag << 24) | pos,   tag = alphabet * S + pattern
+//
+// The reference stores bucket members in descending insertion order and later visits them in
+// slot order; here the slot order inside a bucket is arbitrary (atomic fill) because every
+// downstream consumer re-derives the visiting order from the entry value itself (descending
+// (subject, tag, pos) == descending insertion order) -- see DESIGN.md "ordering without sorting
+// the index".  The one order-dependent rule, "the very last locus slot is never read"
+// (fsearch.py:2277, 2539), is kept by k_index_fixlast.
+#include "common.h"
+#include "kernels.h"
+#include "seedhash.h"
+
+template <bool FILL>
+__global__ __launch_bounds__(TILE_POS) void k_index_pass(const u32* __restrict__ words, const u32* __restrict__ pseq,
+                                                         const u32* __restrict__ off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
+                                                         SeedCfg cfg, HashLut lut, u32 step, u32* __restrict__ start,
+                                                         u64* __restrict__ entries) {
+    __shared__ u8 s_cls[TILE_POS + MAX_SEEDLEN];
+    const u32 p0 = p_lo + blockIdx.x * TILE_POS;
+    stage_classes(words, p0, Ppad, s_cls);
+    __syncthreads();
+    const u32 p = p0 + threadIdx.x;
+    if (p >= p_hi) return;
+    if (s_cls[threadIdx.x] >= HCLS_SEP) return;  // separator or x: no window starts here
+    u32 j = 0, pos = 0;
+    if (FILL || step > 1) {
+        j = pseq[p];
+        pos = p - (off[j] + j);
+        if (step > 1 && (pos % step) != 0) return;  // xrange(0, L - k + 1, step), fsearch.py:534
+    }
+    u32 bucket[MAX_PATTERNS];
+    for (int a = 0; a < cfg.A; ++a) {
+        u32 mask = hash_position(s_cls + threadIdx.x, cfg, lut.v[a], bucket);
+        for (int s = 0; s < cfg.S; ++s) {
+            if (!((mask >> s) & 1u)) continue;
+            if (!FILL) {
+                atomicAdd(&start[bucket[s]], 1u);
+            } else {
+                u32 slot = atomicSub(&start[bucket[s]], 1u) - 1u;
+                u32 tag = (u32)(a * cfg.S + s);
+                entries[slot] = ((u64)(j - seq_lo) << 32) | ((u64)tag << 24) | (u64)pos;
+            }
+        }
+    }
+}
+
+// sum c, sum c^2, #non-empty, largest non-empty bucket id over counts[0..NC)
+__global__ __launch_bounds__(256) void k_index_stats(const u32* __restrict__ counts, u32 NC, u64* __restrict__ stats /*[4]*/) {
+    u64 s1 = 0, s2 = 0, nn = 0;
+    u32 mbp1 = 0;  // (largest non-empty bucket id) + 1, 0 = none
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < NC; i += (size_t)gridDim.x * 256 * 4) {
+        u32 c[4] = {0, 0, 0, 0};
+        if (i + 3 < NC) {
+            uint4 v = *reinterpret_cast<const uint4*>(counts + i);
+            c[0] = v.x, c[1] = v.y, c[2] = v.z, c[3] = v.w;
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (i + k < NC) c[k] = counts[i + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c[k]) {
+                s1 += c[k];
+                s2 += (u64)c[k] * c[k];
+                nn += 1;
+                mbp1 = (u32)(i + k) + 1u;
+            }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_down(s1, o);
+        s2 += __shfl_down(s2, o);
+        nn += __shfl_down(nn, o);
+        u32 om = __shfl_down(mbp1, o);
+        mbp1 = om > mbp1 ? om : mbp1;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long*)&stats[0], (unsigned long long)s1);
+        atomicAdd((unsigned long long*)&stats[1], (unsigned long long)s2);
+        atomicAdd((unsigned long long*)&stats[2], (unsigned long long)nn);
+        atomicMax((unsigned long long*)&stats[3], (unsigned long long)mbp1);
+    }
+}
+
+// Keep the reference's "slot len(locus)-1 is never read": that slot belongs to the last non-empty
+// bucket b* and, in the reference's descending order, holds b*'s smallest entry.  Move b*'s
+// smallest entry to slot E-1; the lookup clamps every bucket end to E-1 exactly like get_bin_mem.
+__global__ __launch_bounds__(256) void k_index_fixlast(const u32* __restrict__ start, u64* __restrict__ entries, u32 bstar, u32 E) {
+    __shared__ u64 s_min[256];
+    __shared__ u32 s_idx[256];
+    u32 lo = start[bstar];
+    u64 mn = ~0ull;
+    u32 mi = E - 1;
+    for (u32 i = lo + threadIdx.x; i < E; i += 256) {
+        u64 v = entries[i];
+        if (v < mn) mn = v, mi = i;
+    }
+    s_min[threadIdx.x] = mn, s_idx[threadIdx.x] = mi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o && s_min[threadIdx.x + o] < s_min[threadIdx.x]) {
+            s_min[threadIdx.x] = s_min[threadIdx.x + o];
+            s_idx[threadIdx.x] = s_idx[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        u32 i = s_idx[0];
+        if (i != E - 1) {
+            u64 a = entries[i];
+            entries[i] = entries[E - 1];
+            entries[E - 1] = a;
+        }
+    }
+}
+
+// counts of non-empty buckets in bucket order (exact host replay of get_mu_sd, rare path)
+__global__ __launch_bounds__(256) void k_index_counts_from_start(const u32* __restrict__ start, u32 NC, u32* __restrict__ counts) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < NC) counts[i] = start[i + 1] - start[i];
+}
+
+void launch_index_count(const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
+                        const SeedCfg& cfg, const HashLut& lut, u32 step, u32* start, hipStream_t st) {
+    if (p_hi <= p_lo) return;
+    u32 nb = (p_hi - p_lo + TILE_POS - 1) / TILE_POS;
+    hipLaunchKernelGGL((k_index_pass<false>), dim3(nb), dim3(TILE_POS), 0, st, words, pseq, off, p_lo, p_hi, Ppad, seq_lo, cfg, lut,
+                       step, start, (u64*)nullptr);
+}
+
+void launch_index_fill(const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
+                       const SeedCfg& cfg, const HashLut& lut, u32 step, u32* start, u64* entries, hipStream_t st) {
+    if (p_hi <= p_lo) return;
+    u32 nb = (p_hi - p_lo + TILE_POS - 1) / TILE_POS;
+    hipLaunchKernelGGL((k_index_pass<true>), dim3(nb), dim3(TILE_POS), 0, st, words, pseq, off, p_lo, p_hi, Ppad, seq_lo, cfg, lut,
+                       step, start, entries);
+}
+
+void launch_index_stats(const u32* counts, u32 NC, u64* stats4, hipStream_t st) {
+    HIP_CHECK(hipMemsetAsync(stats4, 0, 4 * sizeof(u64), st));
+    u32 nb = (u32)std::min<size_t>(2048, ((size_t)NC / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_index_stats, dim3(nb), dim3(256), 0, st, counts, NC, stats4);
+}
+
+void launch_index_fixlast(const u32* start, u64* entries, u32 bstar, u32 E, hipStream_t st) {
+    if (E == 0) return;
+    hipLaunchKernelGGL(k_index_fixlast, dim3(1), dim3(256), 0, st, start, entries, bstar, E);
+}
+
+void launch_index_counts_from_start(const u32* start, u32 NC, u32* counts, hipStream_t st) {
+    hipLaunchKernelGGL(k_index_counts_from_start, dim3((NC + 255) / 256), dim3(256), 0, st, start, NC, counts);
+}

@@ -1,0 +1,162 @@
+// k_phase2.hip -- phase 2 of blastp (fsearch.py:3028-3110) around the banded aligner:
+// chunk-major candidate gather, reference quicksort by -ungapped score, top-vmax task list,
+// sequential early-stop replay, reference quicksort by -bit, top-v output records.
+#include "common.h"
+#include "kernels.h"
+#include "refsort.h"
+
+// per-chunk candidate region (sorted by query, then first-touch) -> per-query chunk-major layout
+//   dst = qcoff[q] + prior[q] + (i - cqoff[q])
+__global__ __launch_bounds__(256) void k_gather_cands(const u32* __restrict__ src_q, const u32* __restrict__ src_rec, u32 n,
+                                                      const u32* __restrict__ cqoff /*excl scan of this chunk's per-query counts*/,
+                                                      const u32* __restrict__ prior /*sum of earlier chunks' counts*/,
+                                                      const u32* __restrict__ qcoff, u32* __restrict__ dst_rec) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const u32 q = src_q[i];
+    const u32 d = qcoff[q] + prior[q] + (i - cqoff[q]);
+    *reinterpret_cast<uint4*>(dst_rec + 4 * (size_t)d) = *reinterpret_cast<const uint4*>(src_rec + 4 * (size_t)i);
+}
+
+__global__ __launch_bounds__(256) void k_add_u32(u32* __restrict__ acc, const u32* __restrict__ x, u32 n) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) acc[i] += x[i];
+}
+
+// qsort(hits, key=-score) (3051) per query + number of alignment tasks min(n, vmax) (3059, 3062)
+__global__ __launch_bounds__(64) void k_csort(const u32* __restrict__ rec, const u32* __restrict__ qcoff, u32 nq, u32 vmax,
+                                              u32* __restrict__ perm, u32* __restrict__ ntask) {
+    const u32 q = blockIdx.x * 64u + threadIdx.x;
+    if (q >= nq) return;
+    const u32 c0 = qcoff[q];
+    const int n = (int)(qcoff[q + 1] - c0);
+    u32* x = perm + c0;
+    for (int i = 0; i < n; ++i) x[i] = (u32)i;
+    const u32* r = rec + 4 * (size_t)c0;
+    ref_qsort_dev(x, n, [r](u32 i) { return -(i64)r[4 * (size_t)i + 1]; });
+    ntask[q] = (u32)n < vmax ? (u32)n : vmax;
+}
+
+__global__ __launch_bounds__(64) void k_mktasks(const u32* __restrict__ rec, const u32* __restrict__ qcoff, const u32* __restrict__ perm,
+                                                const u32* __restrict__ ntask, const u32* __restrict__ toff, u32 nq,
+                                                AlnTask* __restrict__ tasks) {
+    const u32 q = blockIdx.x * 64u + threadIdx.x;
+    if (q >= nq) return;
+    const u32 c0 = qcoff[q], t0 = toff[q], nt = ntask[q];
+    for (u32 k = 0; k < nt; ++k) {
+        const u32 c = c0 + perm[c0 + k];
+        AlnTask t;
+        t.q = q, t.subj = rec[4 * (size_t)c], t.score = rec[4 * (size_t)c + 1], t.qi = rec[4 * (size_t)c + 2],
+        t.qj = rec[4 * (size_t)c + 3], t.rank = k;
+        tasks[t0 + k] = t;
+    }
+}
+
+// sequential stop rule (3052-3054, 3062-3104) + qsort_u(m8s, key=-bit) (3108) + first v (3109)
+__global__ __launch_bounds__(64) void k_stop(const AlnTask* __restrict__ tasks, const AlnRes* __restrict__ res,
+                                             const u32* __restrict__ qcoff, const u32* __restrict__ ntask, const u32* __restrict__ toff,
+                                             u32 nq, const u32* __restrict__ qoff, const u32* __restrict__ roff,
+                                             const int* __restrict__ bittab, int bittab_n, i64 D, double expect, double max_miss, i64 v,
+                                             u32* __restrict__ sel, u32* __restrict__ nout, int* __restrict__ bits) {
+    const u32 q = blockIdx.x * 64u + threadIdx.x;
+    if (q >= nq) return;
+    const u32 t0 = toff[q], nt = ntask[q];
+    const u32 n = qcoff[q + 1] - qcoff[q];
+    double mmiss = (double)n * max_miss + 1;
+    const double inv = 100. / mmiss;
+    mmiss = mmiss > inv ? mmiss : inv;
+    mmiss = mmiss > 10. ? mmiss : 10.;
+    mmiss = mmiss < 120. ? mmiss : 120.;
+    const i64 li = (i64)(qoff[q + 1] - qoff[q]);
+    i64 unmch = 0, bv = 0;
+    u32 nsel = 0;
+    for (u32 r = 0; r < nt; ++r) {
+        const AlnTask tk = tasks[t0 + r];
+        const AlnRes a = res[t0 + r];
+        const i64 lj = (i64)(roff[tk.subj + 1] - roff[tk.subj]);
+        const int sc = a.maxscore < bittab_n ? a.maxscore : bittab_n - 1;
+        const int bit = bittab[sc];
+        bits[t0 + r] = bit;
+        const double p2 = bit > 1074 ? 0.0 : ldexp(1.0, -bit);
+        const double e = (double)(D * li * lj) * p2;
+        if (e <= expect) {
+            sel[t0 + nsel++] = r;
+            unmch = 0;
+            bv += 1;
+        } else {
+            unmch += 1;
+        }
+        if ((double)unmch >= mmiss || (double)bv >= (double)v + mmiss) break;
+    }
+    const int* b = bits + t0;
+    ref_qsort_dev(sel + t0, (int)nsel, [b](u32 r) { return -b[r]; });
+    const i64 vv = v > 0 ? v : 0;
+    nout[q] = (i64)nsel < vv ? nsel : (u32)vv;
+}
+
+// final records: 12 x i32 per reported row
+__global__ __launch_bounds__(64) void k_emit_hits(const AlnTask* __restrict__ tasks, const AlnRes* __restrict__ res,
+                                                  const u32* __restrict__ toff, const u32* __restrict__ sel, const u32* __restrict__ nout,
+                                                  const u32* __restrict__ ooff, const int* __restrict__ bits, u32 nq,
+                                                  int* __restrict__ out) {
+    const u32 q = blockIdx.x * 64u + threadIdx.x;
+    if (q >= nq) return;
+    const u32 t0 = toff[q], no = nout[q], o0 = ooff[q];
+    for (u32 k = 0; k < no; ++k) {
+        const u32 r = sel[t0 + k];
+        const AlnTask tk = tasks[t0 + r];
+        const AlnRes a = res[t0 + r];
+        int* o = out + 12 * (size_t)(o0 + k);
+        o[0] = (int)q, o[1] = (int)tk.subj, o[2] = a.aln, o[3] = a.aln - a.matches, o[4] = a.gap, o[5] = a.qst + 1, o[6] = a.qed,
+        o[7] = a.sst + 1, o[8] = a.sed, o[9] = bits[t0 + r], o[10] = (int)tk.score, o[11] = a.matches;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sum_cells(const AlnRes* __restrict__ res, u32 n, unsigned long long* __restrict__ total) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    unsigned long long c = i < n ? (unsigned long long)res[i].cells : 0ull;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, c);
+}
+
+// ---- launch wrappers -------------------------------------------------------------------------------
+void launch_gather_cands(const u32* src_q, const u32* src_rec, u32 n, const u32* cqoff, const u32* prior, const u32* qcoff,
+                         u32* dst_rec, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_gather_cands, dim3((n + 255) / 256), dim3(256), 0, st, src_q, src_rec, n, cqoff, prior, qcoff, dst_rec);
+}
+
+void launch_add_u32(u32* acc, const u32* x, u32 n, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_add_u32, dim3((n + 255) / 256), dim3(256), 0, st, acc, x, n);
+}
+
+void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, u32* perm, u32* ntask, hipStream_t st) {
+    if (!nq) return;
+    hipLaunchKernelGGL(k_csort, dim3((nq + 63) / 64), dim3(64), 0, st, rec, qcoff, nq, vmax, perm, ntask);
+}
+
+void launch_mktasks(const u32* rec, const u32* qcoff, const u32* perm, const u32* ntask, const u32* toff, u32 nq, AlnTask* tasks,
+                    hipStream_t st) {
+    if (!nq) return;
+    hipLaunchKernelGGL(k_mktasks, dim3((nq + 63) / 64), dim3(64), 0, st, rec, qcoff, perm, ntask, toff, nq, tasks);
+}
+
+void launch_stop(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* toff, u32 nq, const u32* qoff,
+                 const u32* roff, const int* bittab, int bittab_n, i64 D, double expect, double max_miss, i64 v, u32* sel, u32* nout,
+                 int* bits, hipStream_t st) {
+    if (!nq) return;
+    hipLaunchKernelGGL(k_stop, dim3((nq + 63) / 64), dim3(64), 0, st, tasks, res, qcoff, ntask, toff, nq, qoff, roff, bittab,
+                       bittab_n, D, expect, max_miss, v, sel, nout, bits);
+}
+
+void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, const u32* sel, const u32* nout, const u32* ooff,
+                      const int* bits, u32 nq, int* out, hipStream_t st) {
+    if (!nq) return;
+    hipLaunchKernelGGL(k_emit_hits, dim3((nq + 63) / 64), dim3(64), 0, st, tasks, res, toff, sel, nout, ooff, bits, nq, out);
+}
+
+void launch_sum_cells(const AlnRes* res, u32 n, unsigned long long* total, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_sum_cells, dim3((n + 255) / 256), dim3(256), 0, st, res, n, total);
+}

@@ -1,0 +1,31 @@
+// k_sort.hip -- device radix sorts used for diagonal binning and candidate ordering.
+// The sort itself is the rocPRIM library primitive (a plain library sort, like a plain
+// library GEMM); everything around it (key construction, grouping, extension) is
+// hand-written in the other k_*.hip files.
+#include "common.h"
+#include "kernels.h"
+#include <hipcub/hipcub.hpp>
+
+size_t sort_keys_u64_temp_bytes(size_t n, int bits) {
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortKeys((void*)nullptr, bytes, (const u64*)nullptr, (u64*)nullptr, (int)n, 0, bits, (hipStream_t)0);
+    return bytes;
+}
+
+void sort_keys_u64(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, int bits, hipStream_t st) {
+    if (n == 0) return;
+    HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, in, out, (int)n, 0, bits, st));
+}
+
+size_t sort_pairs_u64_u32_temp_bytes(size_t n, int bits) {
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs((void*)nullptr, bytes, (const u64*)nullptr, (u64*)nullptr, (const u32*)nullptr, (u32*)nullptr,
+                                       (int)n, 0, bits, (hipStream_t)0);
+    return bytes;
+}
+
+void sort_pairs_u64_u32(void* temp, size_t temp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, int bits,
+                        hipStream_t st) {
+    if (n == 0) return;
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, kin, kout, vin, vout, (int)n, 0, bits, st));
+}

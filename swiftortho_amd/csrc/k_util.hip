@@ -1,0 +1,132 @@
+// k_util.hip -- hand-written device-wide prefix sum (reduce / scan block sums / apply).
+// Wave = 64 lanes on gfx950; 256-thread blocks = 4 waves; 16 B per lane loads.
+#include "common.h"
+#include "kernels.h"
+
+#define SCAN_THREADS 256
+#define SCAN_ITERS 8
+#define SCAN_TILE (SCAN_THREADS * 4 * SCAN_ITERS)  // items per block
+
+__device__ __forceinline__ u32 wave_incl_scan_u32(u32 v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        u32 t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread; returns exclusive prefix, *total = block sum
+__device__ __forceinline__ u32 block_excl_scan_u32(u32 v, u32* lds4, u32* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u32 inc = wave_incl_scan_u32(v, lane);
+    if (lane == 63) lds4[w] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_THREADS / 64; ++k) {
+        u32 s = lds4[k];
+        if (k < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const u32* __restrict__ in, size_t n, u32* __restrict__ blocksums) {
+    __shared__ u32 lds4[4];
+    size_t base = (size_t)blockIdx.x * SCAN_TILE;
+    u32 s = 0;
+#pragma unroll
+    for (int it = 0; it < SCAN_ITERS; ++it) {
+        size_t i = base + (size_t)it * SCAN_THREADS * 4 + (size_t)threadIdx.x * 4;
+        if (i + 3 < n) {
+            uint4 v = *reinterpret_cast<const uint4*>(in + i);
+            s += v.x + v.y + v.z + v.w;
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (i + k < n) s += in[i + k];
+        }
+    }
+    u32 tot;
+    block_excl_scan_u32(s, lds4, &tot);
+    if (threadIdx.x == 0) blocksums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of blocksums[0..nb) in place; blocksums[nb] = grand total
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_blocksums(u32* __restrict__ blocksums, size_t nb) {
+    __shared__ u32 lds4[4];
+    u32 carry = 0;
+    for (size_t b0 = 0; b0 < nb; b0 += SCAN_THREADS) {
+        size_t i = b0 + threadIdx.x;
+        u32 v = i < nb ? blocksums[i] : 0;
+        u32 tot;
+        u32 ex = block_excl_scan_u32(v, lds4, &tot);
+        if (i < nb) blocksums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) blocksums[nb] = carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* __restrict__ in, u32* __restrict__ out, size_t n,
+                                                             const u32* __restrict__ blocksums, int inclusive) {
+    __shared__ u32 lds4[4];
+    size_t base = (size_t)blockIdx.x * SCAN_TILE;
+    u32 carry = blocksums[blockIdx.x];
+#pragma unroll 1
+    for (int it = 0; it < SCAN_ITERS; ++it) {
+        size_t i = base + (size_t)it * SCAN_THREADS * 4 + (size_t)threadIdx.x * 4;
+        u32 a = 0, b = 0, c = 0, d = 0;
+        if (i + 3 < n) {
+            uint4 v = *reinterpret_cast<const uint4*>(in + i);
+            a = v.x, b = v.y, c = v.z, d = v.w;
+        } else {
+            if (i < n) a = in[i];
+            if (i + 1 < n) b = in[i + 1];
+            if (i + 2 < n) c = in[i + 2];
+            if (i + 3 < n) d = in[i + 3];
+        }
+        u32 s = a + b + c + d, tot;
+        u32 ex = carry + block_excl_scan_u32(s, lds4, &tot);
+        u32 o0, o1, o2, o3;
+        if (inclusive) o0 = ex + a, o1 = o0 + b, o2 = o1 + c, o3 = o2 + d;
+        else o0 = ex, o1 = ex + a, o2 = o1 + b, o3 = o2 + c;
+        if (i + 3 < n) {
+            *reinterpret_cast<uint4*>(out + i) = make_uint4(o0, o1, o2, o3);
+        } else {
+            if (i < n) out[i] = o0;
+            if (i + 1 < n) out[i + 1] = o1;
+            if (i + 2 < n) out[i + 2] = o2;
+            if (i + 3 < n) out[i + 3] = o3;
+        }
+        carry += tot;
+    }
+}
+
+size_t scan_u32_temp_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 2; }
+
+// out[i] = sum(in[0..i)) (exclusive) or sum(in[0..i]) (inclusive); in may alias out (16-byte aligned).
+// temp needs scan_u32_temp_elems(n) u32; temp[nblocks] receives the grand total (device side).
+const u32* scan_u32(const u32* in, u32* out, size_t n, bool inclusive, u32* temp, hipStream_t st) {
+    size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb == 0) {
+        HIP_CHECK(hipMemsetAsync(temp, 0, sizeof(u32), st));
+        return temp;
+    }
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, temp);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_THREADS), 0, st, temp, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, out, n, temp, inclusive ? 1 : 0);
+    return temp + nb;
+}
+
+// ---- tiny helpers ------------------------------------------------------------------------------
+__global__ void k_fill_u32(u32* p, size_t n, u32 v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+void fill_u32(u32* p, size_t n, u32 v, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+}

@@ -1,0 +1,80 @@
+// kernels.h -- launch wrappers implemented in the k_*.hip translation units.
+#pragma once
+#include "common.h"
+
+struct HashLut;
+
+// k_util.hip
+size_t scan_u32_temp_elems(size_t n);
+const u32* scan_u32(const u32* in, u32* out, size_t n, bool inclusive, u32* temp, hipStream_t st);  // returns device ptr to total
+void fill_u32(u32* p, size_t n, u32 v, hipStream_t st);
+
+// k_sort.hip
+size_t sort_keys_u64_temp_bytes(size_t n, int bits);
+void sort_keys_u64(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, int bits, hipStream_t st);
+size_t sort_pairs_u64_u32_temp_bytes(size_t n, int bits);
+void sort_pairs_u64_u32(void* temp, size_t temp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, int bits,
+                        hipStream_t st);
+
+// k_prep.hip
+void launch_layout(const u8* res, const u32* off, u32 nseq, u32 P, u32 Ppad, const u8* hmap, u32* pseq, u8* pcls, u32* words,
+                   hipStream_t st);
+void launch_scls(const u8* res, size_t n, const u8* smap, u8* scls, hipStream_t st);
+
+// k_index.hip
+void launch_index_count(const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
+                        const SeedCfg& cfg, const HashLut& lut, u32 step, u32* start, hipStream_t st);
+void launch_index_fill(const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
+                       const SeedCfg& cfg, const HashLut& lut, u32 step, u32* start, u64* entries, hipStream_t st);
+void launch_index_stats(const u32* counts, u32 NC, u64* stats4, hipStream_t st);
+void launch_index_fixlast(const u32* start, u64* entries, u32 bstar, u32 E, hipStream_t st);
+void launch_index_counts_from_start(const u32* start, u32 NC, u32* counts, hipStream_t st);
+
+// k_seed.hip
+void launch_qhash(const u32* words, u32 Ppad, const SeedCfg& cfg, const HashLut& lut, u32* qbucket, hipStream_t st);
+void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* start, u32 NC, u32 E, u32* sbeg, u32* scnt, u32* pcnt,
+                   hipStream_t st);
+void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, int mink, const signed char* b62c, int* ksc, u32* korder,
+                      hipStream_t st);
+void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark, hipStream_t st);
+void launch_effcnt(const u8* mark, const u32* scnt, u32 Ppad, int AS, u32* eff, u32* nz, hipStream_t st);
+void launch_compact_seeds(const u32* eff, const u32* hoff, const u32* cidx, const u32* sbeg, const u32* q_pseq, const u32* qoff,
+                          u32 Ppad, int AS, u32* cs_hoff, u32* cs_beg, u32* cs_q, u32* cs_qa, hipStream_t st);
+u32 lookup_num_blocks(u32 H);
+void launch_lookup_blockfirst(const u32* cs_hoff, u32 K, u32 H, u32* blk_first, hipStream_t st);
+void launch_lookup(const u32* cs_hoff, const u32* cs_beg, const u32* cs_q, const u32* cs_qa, const u32* blk_first, u32 K, u32 H,
+                   const u64* entries, const u32* roff, const KeyLayout& kl, u64* keys, hipStream_t st);
+
+// k_group.hip
+void launch_group_flags(const u64* keys, u32 H, const KeyLayout& kl, u32* flags, u32* hvalid, hipStream_t st);
+void launch_group_list(const u32* flags, const u32* gidx, u32 H, u32* ghead, hipStream_t st);
+void launch_ungap(const u64* keys, const u32* ghead, u32 G, u32 Hvalid, const KeyLayout& kl, int ft_bits_entry, int bsp,
+                  const u8* q_scls, const u32* qoff, const u8* r_scls, const u32* roff, const signed char* b62g, u32* pass_count,
+                  u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* step_count, hipStream_t st);
+void launch_seg_flags(const u64* sorted_qs, u32 n, u32* flags, hipStream_t st);
+void launch_best(const u64* sorted_qs, const u32* idx, const u32* shead, u32 nseg, u32 n, const u64* p_sd, const u64* p_ft,
+                 u32 seq_lo, u64* c_ft, u32* c_q, u32* c_rec, hipStream_t st);
+void launch_gather_u32_as_u64(const u32* src, const u32* idx, u32 n, u64* dst, hipStream_t st);
+void launch_iota(u32* p, u32 n, hipStream_t st);
+void launch_emit_cands(const u32* order, u32 n, const u32* c_q, const u32* c_rec, u32* out_q, u32* out_rec, u32* qcnt,
+                       hipStream_t st);
+
+// k_align.hip
+u32 align_trace_stride(int max_rows);
+void launch_align(const AlnTask* tasks, u32 ntasks, const u8* q_res, const u8* q_scls, const u32* qoff, const u8* r_res,
+                  const u8* r_scls, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, AlnRes* out,
+                  hipStream_t st);
+
+// k_phase2.hip
+void launch_gather_cands(const u32* src_q, const u32* src_rec, u32 n, const u32* cqoff, const u32* prior, const u32* qcoff,
+                         u32* dst_rec, hipStream_t st);
+void launch_add_u32(u32* acc, const u32* x, u32 n, hipStream_t st);
+void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, u32* perm, u32* ntask, hipStream_t st);
+void launch_mktasks(const u32* rec, const u32* qcoff, const u32* perm, const u32* ntask, const u32* toff, u32 nq, AlnTask* tasks,
+                    hipStream_t st);
+void launch_stop(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* toff, u32 nq, const u32* qoff,
+                 const u32* roff, const int* bittab, int bittab_n, i64 D, double expect, double max_miss, i64 v, u32* sel, u32* nout,
+                 int* bits, hipStream_t st);
+void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, const u32* sel, const u32* nout, const u32* ooff,
+                      const int* bits, u32 nq, int* out, hipStream_t st);
+void launch_sum_cells(const AlnRes* res, u32 n, unsigned long long* total, hipStream_t st);

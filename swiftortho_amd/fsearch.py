@@ -1,0 +1,258 @@
+"""Host-side mirror of the reference's native search core interface (lib/fsearch.py), backed
+by libsohit.so on an MI355X.
+
+Same names, argument meaning and error behaviour as the reference for this path:
+
+* ``blastp(qry, ref, expect, v, max_miss, st, ed, rst, red, thr, flt, ..., ssd, nr, step, ht, chk)``
+  -- fsearch.py:2968 -- generator of hit tuples in the reference's order;
+* ``entry_point(argv)`` -- fsearch.py:3152-3264 -- the ``fsearch-c`` flag grammar (``-k v`` or
+  ``-kv``, unknown tokens skipped, always returns 0, manual text on bad input) and the
+  16-column output row.
+
+The compute is entirely in the HIP library; this module never falls back to a CPU path.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+from . import _lib
+
+AA9 = "AST,CFILMVY,DN,EQ,G,H,KR,P,W"
+AA20 = "A,S,T,C,F,I,L,M,V,Y,D,N,E,Q,G,H,K,R,P,W"
+
+
+class SohitError(RuntimeError):
+    pass
+
+
+class Searcher:
+    """One libsohit context == one GPU (include/sohit.h).  Not thread-safe."""
+
+    def __init__(self, ssd="111111", nr=AA9, ht=120000000, chk=50000, step=1, v=500, thr=-1, expect=1e-3, max_miss=1e-3,
+                 flt="T", device=0, profile=False):
+        self.L = _lib.load()
+        self._keep = (ssd.encode(), nr.encode())
+        p = _lib.SoParams(self._keep[0], self._keep[1], int(ht), int(chk), int(step), int(v), int(thr), float(expect),
+                          float(max_miss), 1 if flt == "T" else 0, 1 if profile else 0)
+        self.h = self.L.so_create(int(device), C.byref(p))
+        if not self.h:
+            raise SohitError(self.L.so_last_error(None).decode())
+        self.nc = int(ht)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.so_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc:
+            raise SohitError(self.L.so_last_error(self.h).decode())
+
+    # reference side ---------------------------------------------------------------------------
+    def load_ref(self, path, rst=-1, red=-1):
+        self._chk(self.L.so_load_ref(self.h, os.fsencode(path), rst, red))
+
+    def load_ref_bytes(self, data, rst=-1, red=-1):
+        self._chk(self.L.so_load_ref_mem(self.h, data, len(data), rst, red))
+
+    def build_index(self):
+        self._chk(self.L.so_build_index(self.h))
+
+    # query side -------------------------------------------------------------------------------
+    def load_queries(self, path):
+        self._chk(self.L.so_load_queries(self.h, os.fsencode(path)))
+
+    def load_queries_bytes(self, data):
+        self._chk(self.L.so_load_queries_mem(self.h, data, len(data)))
+
+    @property
+    def num_queries(self):
+        return int(self.L.so_num_queries(self.h))
+
+    @property
+    def num_refs(self):
+        return int(self.L.so_num_refs(self.h))
+
+    def query_lengths(self):
+        n = self.num_queries
+        return np.array([self.L.so_query_len(self.h, i) for i in range(n)], dtype=np.int64)
+
+    # search -----------------------------------------------------------------------------------
+    def search(self, st=-1, ed=-1):
+        """Queries [st, ed) of the loaded query file -> Hits (owning wrapper)."""
+        hits = C.POINTER(_lib.SoHit)()
+        n = C.c_int64(0)
+        self._chk(self.L.so_search_loaded(self.h, st, ed, C.byref(hits), C.byref(n)))
+        return Hits(self, hits, n.value)
+
+    def counters(self):
+        c = _lib.SoCounters()
+        self.L.so_get_counters(self.h, C.byref(c))
+        return c.as_dict()
+
+    def reset_counters(self):
+        self.L.so_reset_counters(self.h)
+
+    # introspection (tests) ----------------------------------------------------------------------
+    def chunk_threshold(self, k):
+        return int(self.L.so_chunk_threshold(self.h, k))
+
+    def chunk_index(self, k):
+        n = int(self.L.so_chunk_entries(self.h, k))
+        start = np.zeros(self.nc + 1, dtype=np.uint32)
+        ent = np.zeros(max(n, 1), dtype=np.uint64)
+        self._chk(self.L.so_chunk_download(self.h, k, start.ctypes.data, ent.ctypes.data))
+        return start, ent[:n]
+
+    def masked_query(self, q):
+        n = self.L.so_masked_query(self.h, q, None, 0)
+        if n < 0:
+            return None
+        buf = C.create_string_buffer(max(1, n))
+        self.L.so_masked_query(self.h, q, buf, n)
+        return buf.raw[:n]
+
+    def query_candidates(self, q):
+        n = self.L.so_query_candidates(self.h, q, None, 0)
+        if n < 0:
+            return None
+        out = np.zeros((max(n, 1), 4), dtype=np.uint32)
+        self.L.so_query_candidates(self.h, q, out.ctypes.data, n)
+        return out[:n]
+
+
+class Hits:
+    """Result rows of one search; frees the library buffer on close."""
+
+    def __init__(self, s, ptr, n):
+        self.s, self.ptr, self.n = s, ptr, n
+
+    def __len__(self):
+        return self.n
+
+    def array(self):
+        """numpy structured view (copy) of the so_hit records."""
+        dt = np.dtype([(n, t) for n, t in (("qidx", "<i8"), ("sidx", "<i8"), ("identity", "<f8"), ("evalue", "<f8"), ("aln", "<i4"),
+                                          ("mis", "<i4"), ("gap", "<i4"), ("qst", "<i4"), ("qed", "<i4"), ("sst", "<i4"),
+                                          ("sed", "<i4"), ("bit", "<i4"), ("qlen", "<i4"), ("slen", "<i4"), ("matches", "<i4"),
+                                          ("ungapped", "<i4"))])
+        if self.n == 0:
+            return np.zeros(0, dtype=dt)
+        raw = C.string_at(self.ptr, self.n * C.sizeof(_lib.SoHit))
+        return np.frombuffer(raw, dtype=dt).copy()
+
+    def write(self, path, mode="w"):
+        self.s._chk(self.s.L.so_write_sc(self.s.h, self.ptr, self.n, os.fsencode(path), mode.encode()))
+
+    def rows(self):
+        buf = C.create_string_buffer(1 << 16)
+        out = []
+        for i in range(self.n):
+            k = self.s.L.so_format_hit(self.s.h, C.byref(self.ptr[i]), buf, len(buf))
+            out.append(buf.raw[:k])
+        return out
+
+    def raw_bytes(self):
+        return C.string_at(self.ptr, self.n * C.sizeof(_lib.SoHit)) if self.n else b""
+
+    def close(self):
+        if self.ptr:
+            self.s.L.so_free_hits(self.ptr)
+            self.ptr = None
+
+    __del__ = close
+
+
+def blastp(qry, ref, expect=1e-5, v=500, max_miss=1e-3, st=-1, ed=-1, rst=-1, red=-1, thr=-1, flt="T", ref_idx="", memory=True,
+           ssd="", nr="", step=4, ht=-1, chk=100000, tmpdir="./tmpdir", device=0):
+    """fsearch.py:2968 -- yields (i, j, li, lj, idy, aln, mis, gap, qst, qed, sst, sed, e, bit, seed) per reported row
+    (query ordinal, subject ordinal, lengths, identity, ..., 1-based starts as printed, e-value, bit, ungapped score)."""
+    s = Searcher(ssd=ssd, nr=nr, ht=ht, chk=chk, step=step, v=v, thr=thr, expect=expect, max_miss=max_miss, flt=flt, device=device)
+    try:
+        s.load_ref(ref, rst, red)
+        s.load_queries(qry)
+        hits = s.search(st, ed)
+        for r in hits.array():
+            yield (int(r["qidx"]), int(r["sidx"]), int(r["qlen"]), int(r["slen"]), float(r["identity"]), int(r["aln"]), int(r["mis"]),
+                   int(r["gap"]), int(r["qst"]), int(r["qed"]), int(r["sst"]), int(r["sed"]), float(r["evalue"]), int(r["bit"]),
+                   int(r["ungapped"]))
+        hits.close()
+    finally:
+        s.close()
+
+
+def manual_print(out=sys.stdout):
+    w = out.write
+    w("Usage:\n  fsearch -p blastp -i qry.fsa -d db.fsa\nParameters:\n")
+    for line in ("-p: program", "-i: query sequences in fasta format", "-l: start index of query sequences",
+                 "-u: end index of query sequences", "-L: start index of reference", "-U: end index of reference",
+                 "-d: ref database", "-o: output file", "-O: write mode of output file. w: overwrite, a: append",
+                 "-s: spaced seed in format: 1111,1110,1001.. etc",
+                 "-r: reduced amino acid alphabet in format: AST,CFILMVY,DN,EQ,G,H,KR,P,W", "-v: number of hits to show",
+                 "-e: expect value", "-m: max ratio of pseudo hits that will trigger stop",
+                 "-j: distance between start sites of two neighbor seeds, greater will reduce the size of database",
+                 "-t: filter high frequency kmers whose counts > t", "-F: Filter query sequence",
+                 "-M: bucket size of hash table", "-c: chunck size of reference. default is 50K",
+                 "-T: tmpdir (accepted, unused: nothing is spilled to disk)"):
+        w("  %s\n" % line)
+
+
+DEFAULTS = {'-p': '', '-v': '500', '-s': '111111', '-i': '', '-d': '', '-e': '1e-3', '-l': '-1', '-u': '-1', '-m': '1e-3',
+            '-t': '-1', '-r': AA9, '-j': '4', '-F': 'T', '-o': '', '-D': '', '-O': 'wb', '-L': '-1', '-U': '-1', '-M': '-1',
+            '-c': '50000', '-T': './tmpdir'}
+
+
+def parse_flags(argv, defaults):
+    """fsearch.py:3189-3199: `-k v` or `-kv`; unknown tokens are skipped."""
+    args = dict(defaults)
+    n = len(argv)
+    for i in range(1, n):
+        k = argv[i]
+        if k in args:
+            if i + 1 < n:
+                args[k] = argv[i + 1]
+        elif k[:2] in args and len(k) > 2:
+            args[k[:2]] = k[2:]
+    return args
+
+
+def entry_point(argv, device=0, searcher=None):
+    """fsearch.py:3152 -- same flags as lib/fsearch-c; writes the 16-column rows; always returns 0."""
+    args = parse_flags(argv, DEFAULTS)
+    if args['-p'] != 'blastp' or args['-i'] == '' or args['-d'] == '':
+        manual_print()
+        return 0
+    try:
+        exp, bv, start, end = float(args['-e']), int(args['-v']), int(args['-l']), int(args['-u'])
+        rstart, rend, miss, thr = int(args['-L']), int(args['-U']), float(args['-m']), int(args['-t'])
+        step, ht, chk = int(args['-j']), int(args['-M']), int(args['-c'])
+    except ValueError:
+        print('blastp')
+        manual_print()
+        return 0
+    wrt = args['-O']
+    wrt = wrt if (wrt and wrt in 'wa') else 'w'
+    s = searcher or Searcher(ssd=args['-s'], nr=args['-r'], ht=ht, chk=chk, step=step, v=bv, thr=thr, expect=exp, max_miss=miss,
+                             flt=args['-F'], device=device)
+    try:
+        s.load_ref(args['-d'], rstart, rend)
+        s.load_queries(args['-i'])
+        hits = s.search(start, end)
+        if args['-o']:
+            hits.write(args['-o'], wrt)
+        else:
+            for r in hits.rows():
+                sys.stdout.write(r.decode('latin-1'))
+        hits.close()
+    finally:
+        if searcher is None:
+            s.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(entry_point(sys.argv))

@@ -1,0 +1,114 @@
+"""The oracle (oracle/sohit_cpu.cpp) against fixtures produced by the REAL reference source
+(tools/refharness/make_goldens.py, run in the build container).  CPU only."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, golden_names
+
+
+@pytest.fixture(scope="module")
+def kat():
+    return json.load(open(os.path.join(GOLD, "kat.json")))
+
+
+def test_b62_table(oracle, kat):
+    L = kat["b62_letters"]
+    for a, row in zip(L, kat["b62_23x23"]):
+        for b, v in zip(L, row):
+            assert oracle.b62(a, b) == v
+            assert oracle.b62(a.lower(), b) == v and oracle.b62(a, b.lower()) == v
+    assert oracle.b62("U", "U") == kat["b62_default"]
+    for a, b, v in kat["b62_probe"]:
+        assert oracle.b62(a, b) == v
+    assert int(oracle.b62_matrix().sum()) == kat["b62_sum"]
+
+
+def test_nr_tables(oracle, kat):
+    for g, tbl in kat["nr_tbl"].items():
+        assert oracle.nr_tbl(g) == tbl
+
+
+def test_spseeds(oracle, kat):
+    for c in kat["spseeds"]:
+        got = oracle.spseeds(c["seq"], c["ssd"], c["nr"], c["mod"], c["step"])
+        assert got == [tuple(x) for x in c["out"]], c
+
+
+def test_seg(oracle, kat):
+    for c in kat["seg"]:
+        assert oracle.seg(c["in"]).decode() == c["out"], c["in"]
+
+
+def test_qsort(oracle, kat):
+    for c in kat["qsort"]:
+        assert oracle.qsort_perm(c["keys"]) == c["perm"]
+
+
+def test_ungap(oracle, kat):
+    for c in kat["ungap"]:
+        assert list(oracle.ungap(c["q"], c["s"], c["Qst"], c["Sst"], c["qlo"], c["slo"])) == c["out"], c
+    for c in kat["ungap_chain"]:
+        assert list(oracle.ungap_chain(c["q"], c["s"], c["locs"])) == c["out"], c
+
+
+def test_kswat_st(oracle, kat):
+    for c in kat["kswat_st"]:
+        got = oracle.kswat_st(c["q"], c["s"], c["qst"], c["sst"])
+        assert got[0] == c["out"][0] and list(got[1:]) == c["out"][1:], (c, got)
+
+
+def test_scalar_formulas(oracle, kat):
+    for s, b in kat["score2bit"]:
+        assert oracle.score2bit(s) == b
+    for D, a, b, bit, e in kat["bit2e"]:
+        assert oracle.bit2e(D, a, b, bit) == e
+    for e, s in kat["f2s"]:
+        assert oracle.f2s(float(e)) == s
+    for x, s in kat["fmt_idy"]:
+        assert oracle.fmt_idy(float(x)) == s
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_end_to_end_golden(oracle, name, tmp_path):
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    ref = os.path.join(GOLD, name + ".ref.fsa")
+    qry = os.path.join(GOLD, name + ".qry.fsa") if meta["separate_query"] else ref
+    out = str(tmp_path / "o.sc")
+    subprocess.run([oracle.EXE, "-p", "blastp", "-i", qry, "-d", ref, "-o", out, "-T", str(tmp_path)] + meta["flags"], check=True,
+                   stderr=subprocess.DEVNULL)
+    assert open(out, "rb").read() == open(os.path.join(GOLD, name + ".sc"), "rb").read()
+
+
+@pytest.mark.parametrize("name", ["stage_default", "stage_multi"])
+def test_stage_dump(oracle, name):
+    d = json.load(open(os.path.join(GOLD, name + ".stage.json")))
+    fa = open(os.path.join(GOLD, name + ".ref.fsa"), "rb").read()
+    ix = oracle.Index(fa, d["ssd"], d["nr"], d["step"], d["NC"])
+    assert ix.threshold == d["threshold"]
+    start, locus, soas = ix.start(), ix.locus(), ix.soas()
+    assert len(locus) == d["n_locus"] and soas.tolist() == d["soas"]
+    assert int(locus.astype(np.int64).sum()) == d["locus_sum"] and int(start.astype(np.int64).sum()) == d["start_sum"]
+    assert locus[:4000].tolist() == d["locus_head"]
+    nz = np.array(d["nonempty_buckets"])
+    assert start[nz].tolist() == d["start_at_nonempty"]
+    for q in d["queries"]:
+        assert oracle.seg(q["masked"]) is not None
+        assert ix.find_msav_m(q["masked"]) == q["cands"], q["i"]
+
+
+def test_query_partition_invariance(oracle, tmp_path):
+    """-l/-u splits concatenate to the full run (find_hit.py's block scheme relies on it)."""
+    name = "toy_default"
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    ref = os.path.join(GOLD, name + ".ref.fsa")
+    parts = b""
+    for lo, hi in ((0, 40), (40, 99)):
+        out = str(tmp_path / ("p%d.sc" % lo))
+        subprocess.run([oracle.EXE, "-p", "blastp", "-i", ref, "-d", ref, "-o", out, "-l", str(lo), "-u", str(hi)] + meta["flags"],
+                       check=True, stderr=subprocess.DEVNULL)
+        parts += open(out, "rb").read()
+    assert parts == open(os.path.join(GOLD, name + ".sc"), "rb").read()

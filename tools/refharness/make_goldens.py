@@ -1,0 +1,225 @@
+"""Generate tests/golden/ fixtures by running the REAL reference source (container only).
+
+    python tools/refharness/make_goldens.py
+
+Writes only data: inputs (FASTA), expected outputs (.sc rows, stage values) and the
+flags used.  No reference source text is stored.  Re-running must reproduce the
+committed files byte for byte (the reference path is deterministic).
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import refload  # noqa: E402
+from swiftortho_amd import synthprot  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+AA9 = "AST,CFILMVY,DN,EQ,G,H,KR,P,W"
+AA20 = "A,S,T,C,F,I,L,M,V,Y,D,N,E,Q,G,H,K,R,P,W"
+AA10B = "A,KR,EDNQ,C,G,H,ILVM,FYW,P,ST"
+
+
+def messy_fasta(rng):
+    """Hand-shaped inputs: low-complexity runs, X/B/Z/U letters, lower case, multi-line
+    records, descriptions with spaces, a short record, an offset-0 seed situation."""
+    base = synthprot.synthprot(24, 90, 99).decode().split("\n")
+    recs = [(base[i][1:], base[i + 1]) for i in range(0, len(base) - 1, 2)]
+    out = []
+    for k, (hd, sq) in enumerate(recs):
+        if k % 4 == 0:
+            sq = sq[:30] + "SSSSSSSSSSSSSSGAAAAAAPAPAPAPAPAPQQQQQQQQQQQ" + sq[30:]
+        if k % 5 == 1:
+            sq = sq[:20] + "XXBZU" + sq[25:]
+        if k % 7 == 2:
+            sq = sq[:40] + sq[40:60].lower() + sq[60:]
+        if k % 6 == 3:
+            sq = "\n".join(sq[i:i + 25] for i in range(0, len(sq), 25))
+        out.append(">%s some description %d\n%s\n" % (hd, k, sq))
+    # (a record shorter than the shortest seed crashes the reference: fsearch.py:2649-2651 indexes past the string)
+    out.append(">dup|p2\n%s\n" % recs[0][1])
+    return "".join(out).encode()
+
+
+FORCE = "--force" in sys.argv
+
+
+def run_e2e(m, name, fasta, flags, qry=None):
+    if os.path.isfile(os.path.join(GOLD, name + ".sc")) and not FORCE:
+        print(name, "exists, skipped")
+        return
+    tmp = tempfile.mkdtemp(prefix="gold_")
+    fa = os.path.join(tmp, "ref.fsa")
+    open(fa, "wb").write(fasta)
+    qa = fa
+    if qry is not None:
+        qa = os.path.join(tmp, "qry.fsa")
+        open(qa, "wb").write(qry)
+    out = os.path.join(tmp, "out.sc")
+    m.entry_point(["fsearch", "-p", "blastp", "-i", qa, "-d", fa, "-o", out, "-T", tmp] + flags)
+    open(os.path.join(GOLD, name + ".ref.fsa"), "wb").write(fasta)
+    if qry is not None:
+        open(os.path.join(GOLD, name + ".qry.fsa"), "wb").write(qry)
+    open(os.path.join(GOLD, name + ".sc"), "wb").write(open(out, "rb").read())
+    json.dump({"flags": flags, "separate_query": qry is not None}, open(os.path.join(GOLD, name + ".json"), "w"), indent=1)
+    print(name, "rows:", open(out, "rb").read().count(b"\n"))
+
+
+def stage_dump(m, name, fasta, ssd, nr, NC, step=1, nq=12):
+    """find_msav_m internals for a few queries: threshold, index digest, candidates."""
+    tmp = tempfile.mkdtemp(prefix="gold_")
+    fa = os.path.join(tmp, "ref.fsa")
+    open(fa, "wb").write(fasta)
+    DB = m.Fasta(open(fa, "rb"))
+    DB.build_msav(space=ssd, nr=nr, step=step, start=0, end=len(DB), ht=NC)
+    start = np.array(DB.start, dtype=np.uint32)
+    locus = np.array(DB.locus, dtype=np.uint32)
+    soas = np.array(DB.soas, dtype=np.uint32)
+    nz = np.nonzero(np.diff(np.concatenate([start, [len(locus)]])))[0]
+    d = {"ssd": ssd, "nr": nr, "NC": NC, "step": step, "threshold": int(DB.threshold), "n_locus": int(len(locus)),
+         "soas": soas.tolist(), "nonempty_buckets": nz[:2000].tolist(), "start_at_nonempty": start[nz[:2000]].tolist(),
+         "locus_head": locus[:4000].tolist(), "locus_sum": int(locus.astype(np.int64).sum()),
+         "start_sum": int(start.astype(np.int64).sum()), "queries": []}
+    for i in range(min(nq, len(DB))):
+        hd, sq = DB[i]
+        sqi = m.seg(sq)[0]
+        cands = DB.find_msav_m(sqi, sort=False)
+        d["queries"].append({"i": i, "masked": sqi, "cands": [[int(x) for x in c] for c in cands]})
+    open(os.path.join(GOLD, name + ".ref.fsa"), "wb").write(fasta)
+    json.dump(d, open(os.path.join(GOLD, name + ".stage.json"), "w"))
+    print(name, "threshold", d["threshold"], "locus", d["n_locus"])
+
+
+def kats(m):
+    rng = np.random.default_rng(5)
+    k = {}
+    # BLOSUM62 over raw bytes: full 256x256 as a nested list of the 46 interesting rows/cols + default
+    letters = "ABCDEFGHIKLMNPQRSTVWXYZ"
+    k["b62_letters"] = letters
+    k["b62_23x23"] = [[m.b62[ord(a)][ord(b)] for b in letters] for a in letters]
+    k["b62_default"] = m.b62[ord("U")][ord("U")]
+    k["b62_probe"] = [[a, b, m.b62[a][b]] for a, b in
+                      [(ord("a"), ord("A")), (ord("x"), ord("x")), (ord("x"), ord("A")), (ord("J"), ord("L")), (42, 42),
+                       (ord("w"), ord("W")), (ord("b"), ord("n")), (13, 65), (ord("-"), ord("-"))]]
+    k["b62_sum"] = int(sum(sum(r) for r in m.b62))
+    k["nr_tbl"] = {g: list(m.generate_nr_tbl(g)) for g in (AA9, AA20, AA10B, "KREDQN,C,G,H,ILV,M,F,Y,W,P,STA")}
+    seqs = ["MENIHDLWERAL", "MENIHDLWERALAE", "MENIHDLWE", "MKVxxxxxxxxxxxxLLLAAAGGGHHWWPPKKRR", "AXAAAAAAAAAAAAAAAAAAB",
+            "".join("ACDEFGHIKLMNPQRSTVWY"[i] for i in rng.integers(0, 20, 200))]
+    sp = []
+    for s in seqs:
+        for ssd, nr, mod, step in [("111111", AA9, 120000000, 1), ("11111011111", AA9, 120000000, 1), ("1111111", AA20, 120000000, 1),
+                                   ("111111,1101011", AA9, 1000003, 1), ("1111,1011", AA9 + "/" + AA10B, 97, 1),
+                                   ("111111", AA9, 120000000, 3), ("11,11", AA9, 5, 1)]:
+            codes = [m.generate_nr_tbl(e) for e in nr.split("/")]
+            sp.append({"seq": s, "ssd": ssd, "nr": nr, "mod": mod, "step": step,
+                       "out": [[int(a), int(b)] for a, b in m.spseeds(s, step=step, codes=codes, ssps=ssd, mod=mod)]})
+    k["spseeds"] = sp
+    segs = ["MSSSSSSSSSSSSGAAAAAAPAPAPAPAPAPQQQQQQQQQQQKLMNDERTWYHGFCVIKLMNPQRSTDE", "MKV", "AAAAAAAAAAAA", "ACDEFGHIKLMN",
+            "ACDEFGHIKLMNACDEFGHIKLMNAAAAAAAAAAAAAAAAAAAAAAAACDEFGHIKLMNPQRSTVWY", "mkvllaAAAaaaAAAaaaAAAKLMNDERTWYHGFCVIK",
+            "A", "AC", "QQQQQQQQQQQQQWERTYIPASDFGHKLCVNM", "WERTYIPASDFGHKLCVNMQQQQQQQQQQQQQ"]
+    for _ in range(30):
+        n = int(rng.integers(5, 150))
+        alpha = "ACDEFGHIKLMNPQRSTVWY"[:int(rng.integers(2, 20))]
+        segs.append("".join(alpha[i] for i in rng.integers(0, len(alpha), n)))
+    k["seg"] = [{"in": s, "out": m.seg(s)[0]} for s in segs]
+    qs = []
+    for _ in range(40):
+        n = int(rng.integers(0, 400))
+        v = [int(x) for x in rng.integers(-5, 6 if n % 2 else 60, n)]
+        idx = list(range(n))
+        m.qsort(idx, key=lambda i: v[i])
+        qs.append({"keys": v, "perm": idx})
+    k["qsort"] = qs
+    S0 = "MENIHDLWERALAEMEKKVSKPSYETWLKSTKANDIQNDVITITAPNEFARDWLEEHYAG"
+    S1 = "MENLHDLWDRALAEMEKVSKPSYETWLRSTKANDIANDQVITITAPNEFARDWLEEHWAG"
+    f = m.Fasta.__new__(m.Fasta)
+    ug = []
+    for q, s, a, b, qlo, slo in [(S0, S1, 10, 10, -1, -1), (S0, S1, 0, 0, -1, -1), (S0, S1, 1, 1, -1, -1), (S0, S1, 30, 30, 20, 20),
+                                 (S0, S1, 5, 8, -1, -1), (S0, S1, 59, 59, -1, -1), (S0, S1, 20, 60, -1, -1), (S0, S1, 25, 25, 40, 40),
+                                 (S0, S1, 10, -61, -1, -1)]:
+        ug.append({"q": q, "s": s, "Qst": a, "Sst": b, "qlo": qlo, "slo": slo, "out": list(f.ungap(q, s, a, b, qlo=qlo, slo=slo))})
+    k["ungap"] = ug
+    ch = []
+    for locs in [[[10, 10], [30, 30], [50, 50]], [[10, 10]], [[1, 1], [2, 2], [3, 3], [40, 40]], [[5, 8], [20, 23]]]:
+        ch.append({"q": S0, "s": S1, "locs": locs, "out": list(f.get_ungap_scores(S0, S1, locs))})
+    k["ungap_chain"] = ch
+    ks = []
+    pairs = [(S0, S1, 0, 0), (S0, S1[3:], 3, 0), (S0[10:], S1, 0, 10), (S0[5:40], S1, 0, 2), (S0, S0, 0, 0), (S1, S0, 7, 0),
+             (S0, "WWWWWWWWWW", 0, 0), (S0[:20], S1, 0, 0), (S0, S1[:20], 0, 0), (S0, S1, 0, 30), (S0, S1, 30, 0),
+             (S0.replace("ETWLK", "xxxxx"), S1, 0, 0)]
+    for _ in range(40):
+        n = int(rng.integers(20, 260))
+        a = "".join("ACDEFGHIKLMNPQRSTVWY"[i] for i in rng.integers(0, 20, n))
+        b = list(a)
+        for _i in range(int(rng.integers(0, n // 3 + 1))):
+            p = int(rng.integers(0, len(b)))
+            r = rng.random()
+            if r < 0.6:
+                b[p] = "ACDEFGHIKLMNPQRSTVWY"[int(rng.integers(0, 20))]
+            elif r < 0.8 and len(b) > 5:
+                del b[p:p + int(rng.integers(1, 4))]
+            else:
+                b[p:p] = list("ACDEFGHIKLMNPQRSTVWY"[int(rng.integers(0, 20))] * int(rng.integers(1, 4)))
+        b = "".join(b)
+        qi, qj = (0, int(rng.integers(0, 6))) if rng.random() < 0.5 else (int(rng.integers(0, 6)), 0)
+        pairs.append((a, b, qi, qj))
+    sm = [[0] * 4100 for _ in range(4100)]
+    tm = [["*"] * 4100 for _ in range(4100)]
+    for q, s, a, b in pairs:
+        r = m.kswat_st(q, s, qst=a, sst=b, score=sm, trace=tm, al0=[], al1=[])
+        ks.append({"q": q, "s": s, "qst": a, "sst": b, "out": [r[0]] + [int(x) for x in r[1:]]})
+    k["kswat_st"] = ks
+    k["score2bit"] = [[s, int(m.score2bit(s))] for s in (0, 1, 24, 25, 50, 100, 111, 500, 2000, 30000)]
+    k["bit2e"] = [[D, a, b, bit, m.bit2e(D, "x" * a, "x" * b, bit)] for D, a, b, bit in
+                  [(99, 147, 143, 104), (10000, 300, 300, 30), (1000000, 300, 310, 1000), (5, 3, 3, 1075), (7, 450, 450, 897)]]
+    k["f2s"] = [[repr(e), m.f2s(e)] for e in (2.88e-261, 9.9999e-4, 1e-5, 0.5, 0.0, 1.0260511648602738e-25, 1e-3, 9.995e-10,
+                                             1e-300, 123.456, 1e-10, 9.99e-7)]
+    k["fmt_idy"] = [[repr(x), ("%f" % x)[:("%f" % x).find(".") + 3]] for x in (88.52459016393443, 100.0, 99.99999999, 7.0 * (100. / 9), 0.0)]
+    json.dump(k, open(os.path.join(GOLD, "kat.json"), "w"))
+    print("kat.json written")
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    m = refload.load()
+    if FORCE or not os.path.isfile(os.path.join(GOLD, "kat.json")):
+        kats(m)
+    rng = np.random.default_rng(1)
+    base = ["-e", "1e-5", "-v", "500", "-j", "1", "-F", "T"]
+    run_e2e(m, "toy_default", synthprot.synthprot(99, 150, 21), base + ["-s", "111111", "-r", AA9, "-M", "1000003", "-c", "50000"])
+    run_e2e(m, "toy_chunks", synthprot.synthprot(90, 120, 6), base + ["-s", "111111", "-r", AA9, "-M", "1000003", "-c", "40"])
+    run_e2e(m, "toy_multiseed", synthprot.synthprot(80, 100, 3), base + ["-s", "111111,1101011", "-r", AA9, "-M", "1000003", "-c", "50000"])
+    run_e2e(m, "toy_twoalpha", synthprot.synthprot(80, 100, 5),
+            base + ["-s", "11111", "-r", AA9 + "/" + AA10B, "-M", "300007", "-c", "25000"])
+    run_e2e(m, "toy_uniform", synthprot.uniform_proteins(60, 150, 8), base + ["-s", "111111", "-r", AA9, "-M", "5003", "-c", "50000"])
+    run_e2e(m, "toy_messy", messy_fasta(rng), ["-e", "1e-3", "-v", "5", "-j", "1", "-F", "T", "-s", "111111", "-r", AA9, "-M", "1000003", "-c", "10"])
+    run_e2e(m, "toy_w10", synthprot.synthprot(70, 200, 12), base + ["-s", "11111011111", "-r", AA9, "-M", "120000000", "-c", "50000"])
+    run_e2e(m, "toy_aa20", synthprot.synthprot(80, 100, 4), base + ["-s", "1111111", "-r", AA20, "-M", "50021", "-c", "50000"])
+    qry = open(os.path.join(refload.REFERENCE, "example", "qry.fsa"), "rb").read()
+    # config 1 (example/run.sh plumbing): the shipped ref.fsa is absent -> stand-in reference with the
+    # query and three mutated copies planted among synthetic proteins
+    ref = synthprot.synthprot(40, 300, 31)
+    q = qry.split(b"\n")[1].decode()
+    rr = np.random.default_rng(3)
+    planted = []
+    for t, d in enumerate((0.0, 0.1, 0.3, 0.5)):
+        s = list(q)
+        for p in range(len(s)):
+            if rr.random() < d:
+                s[p] = "ACDEFGHIKLMNPQRSTVWY"[int(rr.integers(0, 20))]
+        planted.append(">t%04d|planted%d copy d=%.1f\n%s\n" % (t, t, d, "".join(s)))
+    ref = ref + "".join(planted).encode()
+    run_e2e(m, "example_cfg1", ref, ["-e", "1e-5", "-s", "111111", "-r", AA9, "-M", "120000000", "-c", "50000", "-j", "1"], qry=qry)
+    stage_dump(m, "stage_default", synthprot.synthprot(99, 150, 21), "111111", AA9, 1000003)
+    stage_dump(m, "stage_multi", synthprot.synthprot(60, 100, 3), "111111,1101011", AA9 + "/" + AA10B, 200003)
+
+
+if __name__ == "__main__":
+    main()
