@@ -1,0 +1,224 @@
+"""GPU parity tests: libsohit.so (HIP, through the C ABI) against the oracle and the golden
+fixtures.  Bit-exact for every integer/byte/index column; e-value and identity are compared as
+exact doubles too (both sides evaluate the same IEEE expressions), which is tighter than the
+1e-6 relative tolerance BASELINE.json allows.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, golden_names
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6  # tolerance BASELINE.json states for e-value / bit-score columns
+
+
+def flags_to_kwargs(flags):
+    d = dict(zip(flags[0::2], flags[1::2]))
+    nr = d.get("-r", "AST,CFILMVY,DN,EQ,G,H,KR,P,W")
+    return dict(ssd=d.get("-s", "111111"), nr=nr, ht=int(d.get("-M", -1)), chk=int(d.get("-c", 50000)), step=int(d.get("-j", 4)),
+                v=int(d.get("-v", 500)), thr=int(d.get("-t", -1)), expect=float(d.get("-e", 1e-3)), max_miss=float(d.get("-m", 1e-3)),
+                flt=d.get("-F", "T"))
+
+
+@pytest.fixture(scope="module")
+def fs():
+    from swiftortho_amd import fsearch
+    return fsearch
+
+
+def gpu_rows(fs, ref_bytes, qry_bytes, kw, st=-1, ed=-1, keep=False):
+    if keep:
+        os.environ["SOHIT_KEEP_CANDS"] = "1"
+        os.environ["SOHIT_KEEP_MASKED"] = "1"
+    s = fs.Searcher(**kw)
+    s.load_ref_bytes(ref_bytes)
+    s.load_queries_bytes(qry_bytes)
+    hits = s.search(st, ed)
+    rows = b"".join(hits.rows())
+    return s, hits, rows
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_end_to_end_golden(fs, name):
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    ref = open(os.path.join(GOLD, name + ".ref.fsa"), "rb").read()
+    qry = open(os.path.join(GOLD, name + ".qry.fsa"), "rb").read() if meta["separate_query"] else ref
+    s, hits, rows = gpu_rows(fs, ref, qry, flags_to_kwargs(meta["flags"]))
+    want = open(os.path.join(GOLD, name + ".sc"), "rb").read()
+    if rows != want:
+        a, b = rows.split(b"\n"), want.split(b"\n")
+        for i in range(max(len(a), len(b))):
+            x = a[i] if i < len(a) else b"<none>"
+            y = b[i] if i < len(b) else b"<none>"
+            assert x == y, "row %d differs\n gpu: %s\n ref: %s" % (i, x.decode("latin-1"), y.decode("latin-1"))
+    hits.close()
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["stage_default", "stage_multi"])
+def test_index_and_candidates_vs_golden(fs, oracle, name):
+    d = json.load(open(os.path.join(GOLD, name + ".stage.json")))
+    fa = open(os.path.join(GOLD, name + ".ref.fsa"), "rb").read()
+    kw = dict(ssd=d["ssd"], nr=d["nr"], ht=d["NC"], chk=50000, step=d["step"], v=500, expect=1e-5, flt="T")
+    s, hits, _ = gpu_rows(fs, fa, fa, kw, keep=True)
+    assert s.chunk_threshold(0) == d["threshold"]
+    ix = oracle.Index(fa, d["ssd"], d["nr"], d["step"], d["NC"])
+    check_index(s, ix, d["NC"], A=d["nr"].count("/") + 1, S=d["ssd"].count(",") + 1)
+    for q in d["queries"]:
+        assert s.masked_query(q["i"]).decode("latin-1") == q["masked"]
+        got = s.query_candidates(q["i"]).astype(np.int64).tolist()
+        assert got == q["cands"], "query %d" % q["i"]
+    hits.close()
+    s.close()
+
+
+def check_index(s, ix, NC, A, S):
+    """GPU chunk index == oracle CSR: same bucket boundaries; each bucket holds the same members
+    (the GPU keeps them unordered except that slot E-1 is the last bucket's smallest member)."""
+    o_start, o_locus, soas = ix.start(), ix.locus(), ix.soas()
+    g_start, ent = s.chunk_index(0)
+    E = len(o_locus)
+    assert int(g_start[NC]) == E and len(ent) == E
+    assert np.array_equal(g_start[:NC], o_start)
+    if E == 0:
+        return
+    subj = (ent >> np.uint64(32)).astype(np.int64)
+    pos = (ent & np.uint64(0xFFFFFF)).astype(np.int64)
+    x = soas[subj].astype(np.int64) + pos
+    counts = np.diff(g_start.astype(np.int64))
+    bucket = np.repeat(np.arange(NC), counts)
+    # reference order inside a bucket = descending entry value (subject, tag, pos)
+    order = np.lexsort(((~ent), bucket))
+    assert np.array_equal(x[order], o_locus.astype(np.int64))
+    # the slot the reference never reads
+    last_b = bucket[-1]
+    lo = int(g_start[last_b])
+    assert ent[E - 1] == ent[lo:E].min()
+
+
+def oracle_vs_gpu(fs, oracle, fasta, kw, tmp_path, sub=None):
+    fa = str(tmp_path / "x.fsa")
+    open(fa, "wb").write(fasta)
+    out = str(tmp_path / "o.sc")
+    st, ed = sub if sub else (-1, -1)
+    r = oracle.blastp(fa, fa, out, ssd=kw["ssd"], nr=kw["nr"], expect=kw["expect"], v=kw["v"], step=kw["step"], flt=kw["flt"],
+                      ht=kw["ht"], chk=kw["chk"], st=st, ed=ed)
+    s, hits, rows = gpu_rows(fs, fasta, fasta, kw, st, ed, keep=True)
+    want = open(out, "rb").read()
+    # stage: candidates of every query, in the reference's spill order
+    lo = 0 if st < 0 else st
+    for qrel in range(r.nqueries):
+        got = s.query_candidates(lo + qrel)
+        exp = r.cands(qrel)
+        assert np.array_equal(got, exp), "candidates of query %d differ:\n gpu %s\n ora %s" % (lo + qrel, got[:8], exp[:8])
+    a, b = rows.split(b"\n"), want.split(b"\n")
+    for i in range(max(len(a), len(b))):
+        x = a[i] if i < len(a) else b"<none>"
+        y = b[i] if i < len(b) else b"<none>"
+        assert x == y, "row %d differs\n gpu: %s\n ora: %s" % (i, x.decode("latin-1"), y.decode("latin-1"))
+    # fixed-width records: integer columns exact, fp columns within the stated tolerance
+    g = hits.array()
+    assert len(g) == len(r.ints)
+    if len(g):
+        for k, col in enumerate(["qidx", "sidx", "aln", "mis", "gap", "qst", "qed", "sst", "sed", "bit", "qlen", "slen", "ungapped"]):
+            assert np.array_equal(g[col].astype(np.int64), r.ints[:, k]), col
+        assert np.allclose(g["identity"], r.dbl[:, 0], rtol=REL_TOL, atol=0)
+        assert np.allclose(g["evalue"], r.dbl[:, 1], rtol=REL_TOL, atol=0)
+        assert np.array_equal(g["identity"], r.dbl[:, 0]) and np.array_equal(g["evalue"], r.dbl[:, 1])
+    c = s.counters()
+    assert c["seed_hits"] == r.stats["seed_hits"]
+    # the oracle also counts the never-scoring "subject -1" groups (offset 0 of a chunk's first sequence)
+    assert 0 <= r.stats["groups"] - c["groups"] <= 64 * c["n_chunks"] * max(1, r.nqueries // 50)
+    hits.close()
+    s.close()
+    return c, r.stats
+
+
+def test_synth_2000_vs_oracle(fs, oracle, tmp_path):
+    from swiftortho_amd import synthprot
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=120000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, synthprot.synthprot(2000, 300, 77), kw, tmp_path)
+
+
+def test_synth_multichunk_vs_oracle(fs, oracle, tmp_path):
+    from swiftortho_amd import synthprot
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=5000011, chk=700, step=1, v=500, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, synthprot.synthprot(1500, 200, 78), kw, tmp_path)
+
+
+def test_uniform_adversarial_vs_oracle(fs, oracle, tmp_path):
+    """iid residues, no homologs: the seed cap binds and the early-stop rule fires."""
+    from swiftortho_amd import synthprot
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=15000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, synthprot.uniform_proteins(1200, 300, 79), kw, tmp_path)
+
+
+def test_weight10_seed_vs_oracle(fs, oracle, tmp_path):
+    from swiftortho_amd import synthprot
+    kw = dict(ssd="11111011111", nr=oracle.AA9, ht=120000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, synthprot.synthprot(3000, 300, 80), kw, tmp_path)
+
+
+def test_multiseed_two_alphabets_vs_oracle(fs, oracle, tmp_path):
+    from swiftortho_amd import synthprot
+    kw = dict(ssd="111111,1101011", nr=oracle.AA9 + "/A,KR,EDNQ,C,G,H,ILVM,FYW,P,ST", ht=3000017, chk=400, step=2, v=50,
+              expect=1e-3, flt="T")
+    oracle_vs_gpu(fs, oracle, synthprot.synthprot(900, 150, 81), kw, tmp_path)
+
+
+def test_query_subrange_and_small_batches(fs, oracle, tmp_path, monkeypatch):
+    """-l/-u sub-range, processed in several device batches: rows must not depend on batching."""
+    from swiftortho_amd import synthprot
+    monkeypatch.setenv("SOHIT_BATCH", "64")
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, synthprot.synthprot(500, 120, 82), kw, tmp_path, sub=(100, 333))
+
+
+def test_exact_threshold_replay(fs, oracle, monkeypatch):
+    """the rare exact get_mu_sd replay path gives the same threshold as the integer-sum path"""
+    from swiftortho_amd import synthprot
+    fa = synthprot.synthprot(300, 150, 83)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    ix = oracle.Index(fa, kw["ssd"], kw["nr"], 1, kw["ht"])
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("SOHIT_EXACT_THRESHOLD", "1")
+        s = fs.Searcher(**kw)
+        s.load_ref_bytes(fa)
+        s.build_index()
+        assert s.chunk_threshold(0) == ix.threshold
+        s.close()
+
+
+def test_full_size_properties(fs):
+    """BASELINE config 2 (10k x 300 aa self-search, seed 111111): size-independent properties."""
+    from swiftortho_amd import synthprot
+    fa = synthprot.synthprot(10000, 300)
+    kw = dict(ssd="111111", nr="AST,CFILMVY,DN,EQ,G,H,KR,P,W", ht=120000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    s, hits, _ = gpu_rows(fs, fa, fa, kw)
+    g = hits.array()
+    assert len(g) > 10000
+    q = g["qidx"]
+    assert np.all(np.diff(q) >= 0)                       # queries contiguous and ascending
+    same = q[1:] == q[:-1]
+    assert np.all(g["bit"][1:][same] <= g["bit"][:-1][same])   # descending bit inside a query
+    assert np.all(np.bincount(q) <= 500)                 # at most v rows per query
+    assert np.all(g["evalue"] <= 1e-5)
+    assert np.all((g["qst"] >= 1) & (g["qed"] <= g["qlen"]) & (g["sst"] >= 1) & (g["sed"] <= g["slen"]))
+    assert np.all(g["mis"] + g["matches"] == g["aln"])
+    self_hit = g[g["qidx"] == g["sidx"]]
+    lens = s.query_lengths()
+    assert len(np.unique(self_hit["qidx"])) >= 0.99 * len(lens)   # (masked low-complexity queries may miss themselves)
+    # idempotence: a second run over a sub-range reproduces the same records
+    h2 = s.search(1234, 1300)
+    g2 = h2.array()
+    assert g2.tobytes() == g[(g["qidx"] >= 1234) & (g["qidx"] < 1300)].tobytes()
+    h2.close()
+    hits.close()
+    s.close()
