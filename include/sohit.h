@@ -100,6 +100,7 @@ int so_abi_version(void);
 int so_load_ref(so_ctx *ctx, const char *fasta_path, int64_t r_lo, int64_t r_hi);
 int so_load_ref_mem(so_ctx *ctx, const char *fasta_bytes, int64_t nbytes, int64_t r_lo, int64_t r_hi);
 int so_build_index(so_ctx *ctx);
+int so_drop_index(so_ctx *ctx); /* forget the built chunk indexes (residues stay resident) */
 
 /* Query side.  Replaces: Fasta(open(qry)) (fsearch.py:2971-2973).  Parses the FASTA and
  * makes the query residues resident in HBM. */
@@ -126,6 +127,8 @@ int64_t so_format_hit(so_ctx *ctx, const so_hit *hit, char *buf, int64_t cap);
 /* Introspection (tests, bench). */
 int so_get_counters(const so_ctx *ctx, so_counters *out);
 int so_reset_counters(so_ctx *ctx);
+/* "stage=ms;stage=ms;..." wall-clock laps of the pipeline stages (only with params.profile) */
+int64_t so_timing_report(const so_ctx *ctx, char *buf, int64_t cap);
 int64_t so_chunk_threshold(const so_ctx *ctx, int64_t chunk);
 int64_t so_chunk_entries(const so_ctx *ctx, int64_t chunk);
 /* copies start[0..NC] (uint32, NC+1 values) / entries (uint64) of one chunk's index to host */

@@ -34,12 +34,36 @@ class SoCounters(C.Structure):
 
 
 # every symbol include/sohit.h declares
-EXPORTS = ["so_abi_version", "so_create", "so_destroy", "so_last_error", "so_load_ref", "so_load_ref_mem", "so_build_index",
+EXPORTS = ["so_abi_version", "so_create", "so_destroy", "so_last_error", "so_load_ref", "so_load_ref_mem", "so_build_index", "so_drop_index",
            "so_load_queries", "so_load_queries_mem", "so_num_queries", "so_num_refs", "so_query_len", "so_search_loaded",
-           "so_search", "so_free_hits", "so_write_sc", "so_format_hit", "so_get_counters", "so_reset_counters",
+           "so_search", "so_free_hits", "so_write_sc", "so_format_hit", "so_get_counters", "so_reset_counters", "so_timing_report",
            "so_chunk_threshold", "so_chunk_entries", "so_chunk_download", "so_masked_query", "so_query_candidates"]
 
 _lib = None
+
+
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP
+    runtimes in one process cannot both open the GPU, so whichever of torch / libsohit loads
+    second would fail.  Loading torch's copy first (by path, without importing torch) makes the
+    dynamic linker bind libsohit's DT_NEEDED libamdhip64.so.7 to it, and a later `import torch`
+    reuses the same mapping.  Without torch installed this is a no-op (system ROCm is used)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.isfile(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load():
@@ -47,6 +71,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    _preload_torch_hip_runtime()
     if not os.path.isfile(LIBPATH):
         raise ImportError("libsohit.so is missing (%s): run `python -m swiftortho_amd.build` -- there is no CPU fallback" % LIBPATH)
     L = C.CDLL(LIBPATH)
@@ -60,6 +85,7 @@ def load():
     L.so_load_ref.argtypes = [vp, cp, i64, i64]
     L.so_load_ref_mem.argtypes = [vp, cp, i64, i64, i64]
     L.so_build_index.argtypes = [vp]
+    L.so_drop_index.argtypes = [vp]
     L.so_load_queries.argtypes = [vp, cp]
     L.so_load_queries_mem.argtypes = [vp, cp, i64]
     for f in ("so_num_queries", "so_num_refs"):
@@ -75,6 +101,8 @@ def load():
     L.so_format_hit.argtypes = [vp, C.POINTER(SoHit), cp, i64]
     L.so_get_counters.argtypes = [vp, C.POINTER(SoCounters)]
     L.so_reset_counters.argtypes = [vp]
+    L.so_timing_report.restype = i64
+    L.so_timing_report.argtypes = [vp, cp, i64]
     for f in ("so_chunk_threshold", "so_chunk_entries"):
         getattr(L, f).restype = i64
         getattr(L, f).argtypes = [vp, i64]

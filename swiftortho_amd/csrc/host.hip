@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <thread>
 #include <unordered_map>
@@ -230,6 +231,8 @@ struct so_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t max_hits_per_pass = (size_t)1 << 30;
     u32 max_batch = 16384;
+    std::map<std::string, double> tm;  // per-stage wall ms (only with params.profile)
+    std::shared_ptr<void> batch;       // persistent per-batch scratch (struct Batch)
 };
 
 namespace {
@@ -613,6 +616,25 @@ u32 d2h_u32(so_ctx* c, const u32* p) {
 
 void ensure_sort_tmp(so_ctx* c, size_t bytes) { c->d_sort_tmp.ensure(bytes + 256); }
 
+// wall-clock stage laps (stream-synchronising, so only when profiling)
+struct StageClock {
+    so_ctx* c;
+    double t = 0;
+    explicit StageClock(so_ctx* c_) : c(c_) {
+        if (c->profile) {
+            (void)hipStreamSynchronize(c->st);
+            t = wall();
+        }
+    }
+    void lap(const char* name) {
+        if (!c->profile) return;
+        (void)hipStreamSynchronize(c->st);
+        double n = wall();
+        c->tm[name] += (n - t) * 1e3;
+        t = n;
+    }
+};
+
 struct ProfTimer {
     so_ctx* c;
     double* ms;
@@ -644,6 +666,7 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     b.chunk_base.push_back(b.chunk_base.empty() ? 0u : b.chunk_base.back());
     if (nseq_chunk == 0 || ch.E == 0 || b.nq == 0) return;
     const double t0 = wall();
+    StageClock sc(c);
     {
         ProfTimer pt(c, &c->cnt.bounds_ms, &c->cnt.bounds_launches);
         launch_bounds(b.qbucket.p, Ppad, AS, ch.start.p, NC, ch.E, b.sbeg.p, b.scnt.p, b.pcnt.p, c->st);
@@ -662,6 +685,7 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     (void)Hcheck;
     const u32* dK = scan_u32(b.nz.p, b.cidx.p, T, false, c->d_scan_tmp.p, c->st);
     const u32 K = d2h_u32(c, dK);
+    sc.lap("seed.bounds_cap_scan");
     c->cnt.seed_hits += H;
     if (H == 0 || K == 0) {
         c->cnt.seed_ms += (wall() - t0) * 1e3;
@@ -695,9 +719,11 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
         if (c->profile) c->cnt.lookup_bytes += (i64)8 * (i64)H;
     }
     const double t1 = wall();
+    sc.lap("seed.compact_lookup");
     // diagonal binning: sort keys, find group heads
     ensure_sort_tmp(c, sort_keys_u64_temp_bytes(H, kl.total));
     sort_keys_u64(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.keys.p, b.keys2.p, H, kl.total, c->st);
+    sc.lap("group.sort_keys");
     b.flags.ensure((size_t)H + 4), b.gidx.ensure((size_t)H + 4);
     launch_group_flags(b.keys2.p, H, kl, b.flags.p, b.counters.p + 1, c->st);
     c->d_scan_tmp.ensure(scan_u32_temp_elems(H) + 8);
@@ -712,11 +738,13 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     }
     b.ghead.ensure((size_t)G + 2);
     launch_group_list(b.flags.p, b.gidx.p, H, b.ghead.p, c->st);
+    sc.lap("group.heads");
     b.p_qs.ensure((size_t)G + 2), b.p_sd.ensure((size_t)G + 2), b.p_ft.ensure((size_t)G + 2);
     HIP_CHECK(hipMemsetAsync(b.counters.p, 0, sizeof(u32), c->st));
     launch_ungap(b.keys2.p, b.ghead.p, G, Hvalid, kl, ft_bits_entry, bsp, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls.p,
                  c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.counters.p, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.ucount.p, c->st);
     const u32 NP = d2h_u32(c, b.counters.p);
+    sc.lap("group.ungap");
     if (NP == 0) {
         c->cnt.seed_ms += (t1 - t0) * 1e3;
         c->cnt.group_ms += (wall() - t1) * 1e3;
@@ -749,6 +777,7 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     b.chunk_base.back() = base + NS;
     c->cnt.candidates += NS;
     HIP_CHECK(hipStreamSynchronize(c->st));
+    sc.lap("group.best_order");
     c->cnt.seed_ms += (t1 - t0) * 1e3;
     c->cnt.group_ms += (wall() - t1) * 1e3;
 }
@@ -759,6 +788,7 @@ struct HostRow {
 
 void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
     const double t0 = wall();
+    StageClock sc(c);
     const int nchunks = (int)c->chunks.size();
     const u32 nq = b.nq;
     if (nq == 0) return;
@@ -780,17 +810,16 @@ void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
         }
         launch_add_u32(b.prior.p, cc, nq, c->st);
     }
-    // candidate dump for so_query_candidates
-    {
+    sc.lap("phase2.gather");
+    // candidate dump for so_query_candidates (tests only)
+    if (getenv("SOHIT_KEEP_CANDS")) {
         std::vector<u32> qcoff((size_t)nq + 1), rec(4 * (size_t)Ntot + 4);
         HIP_CHECK(hipMemcpyAsync(qcoff.data(), b.qcoff.p, ((size_t)nq + 1) * sizeof(u32), hipMemcpyDeviceToHost, c->st));
         if (Ntot) HIP_CHECK(hipMemcpyAsync(rec.data(), b.fin_rec.p, 4 * (size_t)Ntot * sizeof(u32), hipMemcpyDeviceToHost, c->st));
         HIP_CHECK(hipStreamSynchronize(c->st));
-        if (getenv("SOHIT_KEEP_CANDS")) {
-            for (u32 q = 0; q < nq; ++q) {
-                auto& dst = c->last_cands[(size_t)(b.q_lo - c->last_q_lo) + q];
-                dst.assign(rec.begin() + 4 * (size_t)qcoff[q], rec.begin() + 4 * (size_t)qcoff[q + 1]);
-            }
+        for (u32 q = 0; q < nq; ++q) {
+            auto& dst = c->last_cands[(size_t)(b.q_lo - c->last_q_lo) + q];
+            dst.assign(rec.begin() + 4 * (size_t)qcoff[q], rec.begin() + 4 * (size_t)qcoff[q + 1]);
         }
     }
     if (Ntot == 0) {
@@ -810,6 +839,7 @@ void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
     launch_csort(b.fin_rec.p, b.qcoff.p, nq, vmax, b.perm.p, b.ntask.p, c->st);
     const u32* dNT = scan_u32(b.ntask.p, b.toff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
     const u32 NT = d2h_u32(c, dNT);
+    sc.lap("phase2.csort");
     b.tasks.ensure((size_t)NT + 4), b.ares.ensure((size_t)NT + 4), b.bits.ensure((size_t)NT + 4), b.sel.ensure((size_t)NT + 4);
     launch_mktasks(b.fin_rec.p, b.qcoff.p, b.perm.p, b.ntask.p, b.toff.p, nq, b.tasks.p, c->st);
     // banded alignments in slabs bounded by the trace scratch budget
@@ -818,6 +848,7 @@ void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
     const size_t budget_words = (size_t)1 << 30;  // 4 GiB of trace scratch
     const u32 slab = (u32)std::max<size_t>(16, std::min<size_t>(NT, budget_words / std::max<u32>(stride, 1)));
     b.trace.ensure((size_t)slab * stride + 64);
+    sc.lap("phase2.mktasks");
     {
         ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
         for (u32 t = 0; t < NT; t += slab) {
@@ -828,6 +859,7 @@ void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
         pt.stop();
     }
     launch_sum_cells(b.ares.p, NT, b.ucount.p + 1, c->st);
+    sc.lap("phase2.align");
     c->cnt.alignments += NT;
     b.nout.ensure((size_t)nq + 4), b.ooff.ensure((size_t)nq + 4);
     HIP_CHECK(hipMemsetAsync(b.nout.p, 0, ((size_t)nq + 4) * sizeof(u32), c->st));
@@ -835,6 +867,7 @@ void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
                 c->ref.N, c->expect, c->max_miss, c->v, b.sel.p, b.nout.p, b.bits.p, c->st);
     const u32* dNO = scan_u32(b.nout.p, b.ooff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
     const u32 NO = d2h_u32(c, dNO);
+    sc.lap("phase2.stop");
     if (NO) {
         b.outrec.ensure(12 * (size_t)NO + 16);
         launch_emit_hits(b.tasks.p, b.ares.p, b.toff.p, b.sel.p, b.nout.p, b.ooff.p, b.bits.p, nq, b.outrec.p, c->st);
@@ -859,6 +892,7 @@ void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
             if (h.evalue <= c->expect) out.push_back(h);  // entry_point re-check (3234)
         }
     }
+    sc.lap("phase2.emit_d2h");
     c->cnt.phase2_ms += (wall() - t0) * 1e3;
 }
 
@@ -878,10 +912,12 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, std::vector<so_hit>& out) {
     if (const char* e = getenv("SOHIT_BATCH")) c->max_batch = (u32)std::max(1, atoi(e));
     for (i64 b0 = st; b0 < ed; b0 += c->max_batch) {
         const i64 b1 = std::min<i64>(ed, b0 + c->max_batch);
-        Batch b;
-        for (i64 i = b0; i < b1; ++i)
-            if (c->qry.len(i) < (u32)c->cfg.mink && c->qry.len(i) > 0 && false) {}
+        if (!c->batch) c->batch = std::make_shared<Batch>();
+        Batch& b = *static_cast<Batch*>(c->batch.get());
+        b.chunk_base.clear();
+        StageClock scp(c);
         prepare_batch(c, b, b0, b1);
+        scp.lap("prepare_batch");
         b.ccnt.ensure((size_t)std::max(1, nchunks) * b.nq + 4);
         HIP_CHECK(hipMemsetAsync(b.ccnt.p, 0, ((size_t)std::max(1, nchunks) * b.nq + 4) * sizeof(u32), c->st));
         for (int ci = 0; ci < nchunks; ++ci) seed_stage(c, b, ci);
@@ -1037,6 +1073,13 @@ int so_build_index(so_ctx* c) {
     return guarded(c, [&] { build_index(c); });
 }
 
+int so_drop_index(so_ctx* c) {
+    return guarded(c, [&] {
+        c->chunks.clear();
+        c->index_built = false;
+    });
+}
+
 int so_load_queries(so_ctx* c, const char* path) {
     return guarded(c, [&] {
         if (!read_file(path, c->qry.data)) throw SoError(std::string("cannot read query FASTA ") + path);
@@ -1117,8 +1160,25 @@ int so_get_counters(const so_ctx* c, so_counters* out) {
     return 0;
 }
 
+int64_t so_timing_report(const so_ctx* c, char* buf, int64_t cap) {
+    if (!c) return -1;
+    std::string s;
+    for (auto& kv : c->tm) {
+        char tmp[128];
+        snprintf(tmp, sizeof tmp, "%s=%.3f;", kv.first.c_str(), kv.second);
+        s += tmp;
+    }
+    if (buf && cap > 0) {
+        size_t k = std::min<size_t>(s.size(), (size_t)cap - 1);
+        memcpy(buf, s.data(), k);
+        buf[k] = 0;
+    }
+    return (int64_t)s.size();
+}
+
 int so_reset_counters(so_ctx* c) {
     if (!c) return 1;
+    c->tm.clear();
     so_counters keep = c->cnt;
     memset(&c->cnt, 0, sizeof c->cnt);
     c->cnt.ref_seqs = keep.ref_seqs, c->cnt.ref_aa = keep.ref_aa, c->cnt.n_chunks = keep.n_chunks;

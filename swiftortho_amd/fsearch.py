@@ -62,6 +62,9 @@ class Searcher:
     def build_index(self):
         self._chk(self.L.so_build_index(self.h))
 
+    def drop_index(self):
+        self._chk(self.L.so_drop_index(self.h))
+
     # query side -------------------------------------------------------------------------------
     def load_queries(self, path):
         self._chk(self.L.so_load_queries(self.h, os.fsencode(path)))
@@ -96,6 +99,12 @@ class Searcher:
 
     def reset_counters(self):
         self.L.so_reset_counters(self.h)
+
+    def timing(self):
+        n = self.L.so_timing_report(self.h, None, 0)
+        buf = C.create_string_buffer(n + 2)
+        self.L.so_timing_report(self.h, buf, n + 1)
+        return {kv.split("=")[0]: float(kv.split("=")[1]) for kv in buf.value.decode().split(";") if kv}
 
     # introspection (tests) ----------------------------------------------------------------------
     def chunk_threshold(self, k):
