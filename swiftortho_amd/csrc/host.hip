@@ -560,6 +560,7 @@ struct Batch {
     DevBuf<u32> cand_q, cand_rec;             // all chunks' regions concatenated
     std::vector<u32> chunk_base;              // region start per chunk (+ total)
     DevBuf<u32> ccnt;                         // [nchunks][nq] per-query counts
+    DevBuf<u32> segfirst, st_state, rcnt, roff, ridx;
     DevBuf<u32> cqoff, prior, qtot, qcoff, fin_rec, perm, ntask, toff, sel, nout, ooff;
     DevBuf<AlnTask> tasks;
     DevBuf<AlnRes> ares;
@@ -773,7 +774,8 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     const u32 base = b.chunk_base.back();
     b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
     b.cand_rec.ensure(4 * ((size_t)base + NS) + 16, true, c->st);
-    launch_emit_cands(b.order.p, NS, b.c_q.p, b.c_rec.p, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, c->st);
+    b.segfirst.ensure((size_t)b.nq + 4);
+    launch_emit_cands(b.order.p, NS, b.c_q.p, b.c_rec.p, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, b.segfirst.p, c->st);
     b.chunk_base.back() = base + NS;
     c->cnt.candidates += NS;
     HIP_CHECK(hipStreamSynchronize(c->st));
@@ -841,30 +843,43 @@ void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
     const u32 NT = d2h_u32(c, dNT);
     sc.lap("phase2.csort");
     b.tasks.ensure((size_t)NT + 4), b.ares.ensure((size_t)NT + 4), b.bits.ensure((size_t)NT + 4), b.sel.ensure((size_t)NT + 4);
+    HIP_CHECK(hipMemsetAsync(b.ares.p, 0, ((size_t)NT + 4) * sizeof(AlnRes), c->st));  // unaligned slots count 0 cells
     launch_mktasks(b.fin_rec.p, b.qcoff.p, b.perm.p, b.ntask.p, b.toff.p, nq, b.tasks.p, c->st);
-    // banded alignments in slabs bounded by the trace scratch budget
+    // banded alignments in rounds (see k_stop_round): round sizes 64, 128, 256, ... ranks per query
     const int maxrows = (int)std::min<u32>(std::max(b.maxqlen, c->ref.maxlen), std::min(b.maxqlen, c->ref.maxlen) + 16);
     const u32 stride = align_trace_stride(maxrows + 1);
     const size_t budget_words = (size_t)1 << 30;  // 4 GiB of trace scratch
     const u32 slab = (u32)std::max<size_t>(16, std::min<size_t>(NT, budget_words / std::max<u32>(stride, 1)));
-    b.trace.ensure((size_t)slab * stride + 64);
+    b.st_state.ensure(5 * (size_t)nq + 8), b.rcnt.ensure((size_t)nq + 4), b.roff.ensure((size_t)nq + 4), b.ridx.ensure((size_t)NT + 4);
+    HIP_CHECK(hipMemsetAsync(b.st_state.p, 0, (5 * (size_t)nq + 8) * sizeof(u32), c->st));
     sc.lap("phase2.mktasks");
-    {
-        ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
-        for (u32 t = 0; t < NT; t += slab) {
-            const u32 n = std::min(slab, NT - t);
-            launch_align(b.tasks.p + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p, c->ref.d_off.p,
-                         c->d_b62c.p, b.trace.p, stride, b.ares.p + t, c->st);
+    u32 aligned_total = 0;
+    for (u32 B = 64;; B *= 2) {
+        launch_round_counts(b.ntask.p, b.st_state.p, nq, B, b.rcnt.p, c->st);
+        const u32* dNR = scan_u32(b.rcnt.p, b.roff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
+        const u32 NR = d2h_u32(c, dNR);
+        if (NR == 0) break;
+        launch_round_idx(b.rcnt.p, b.roff.p, b.toff.p, b.st_state.p, nq, b.ridx.p, c->st);
+        b.trace.ensure((size_t)std::min(slab, NR) * stride + 64);
+        {
+            ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
+            for (u32 t = 0; t < NR; t += slab) {
+                const u32 n = std::min(slab, NR - t);
+                launch_align(b.tasks.p, b.ridx.p + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
+                             c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, b.ares.p, c->st);
+            }
+            pt.stop();
         }
-        pt.stop();
+        launch_stop_round(b.tasks.p, b.ares.p, b.qcoff.p, b.ntask.p, b.toff.p, b.rcnt.p, nq, b.dev.d_off.p, c->ref.d_off.p, c->d_bittab.p,
+                          so_ctx::BITTAB_N, c->ref.N, c->expect, c->max_miss, c->v, b.sel.p, b.st_state.p, b.bits.p, c->st);
+        aligned_total += NR;
     }
     launch_sum_cells(b.ares.p, NT, b.ucount.p + 1, c->st);
-    sc.lap("phase2.align");
-    c->cnt.alignments += NT;
+    sc.lap("phase2.align_rounds");
+    c->cnt.alignments += aligned_total;
     b.nout.ensure((size_t)nq + 4), b.ooff.ensure((size_t)nq + 4);
     HIP_CHECK(hipMemsetAsync(b.nout.p, 0, ((size_t)nq + 4) * sizeof(u32), c->st));
-    launch_stop(b.tasks.p, b.ares.p, b.qcoff.p, b.ntask.p, b.toff.p, nq, b.dev.d_off.p, c->ref.d_off.p, c->d_bittab.p, so_ctx::BITTAB_N,
-                c->ref.N, c->expect, c->max_miss, c->v, b.sel.p, b.nout.p, b.bits.p, c->st);
+    launch_final_select(b.toff.p, nq, c->v, b.sel.p, b.st_state.p, b.bits.p, b.nout.p, c->st);
     const u32* dNO = scan_u32(b.nout.p, b.ooff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
     const u32 NO = d2h_u32(c, dNO);
     sc.lap("phase2.stop");

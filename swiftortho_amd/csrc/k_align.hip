@@ -22,7 +22,8 @@ __device__ __forceinline__ int dpp_row_shr1(int v) { return __builtin_amdgcn_upd
 __device__ __forceinline__ int dpp_row_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true); }
 
 // trace codes: 0 '*' (stop), 1 '\\' (diag), 2 '-' (left), 3 '|' (up)
-__global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks, u32 ntasks, const u8* __restrict__ q_res,
+__global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 ntasks,
+                                               const u8* __restrict__ q_res,
                                                const u8* __restrict__ q_scls, const u32* __restrict__ qoff,
                                                const u8* __restrict__ r_res, const u8* __restrict__ r_scls,
                                                const u32* __restrict__ roff, const signed char* __restrict__ b62g,
@@ -33,7 +34,8 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     const u32 tid = blockIdx.x * 16u + (threadIdx.x >> 4);
     const int l = threadIdx.x & 15;
     if (tid >= ntasks) return;
-    const AlnTask tk = tasks[tid];
+    const u32 slot = ridx ? ridx[tid] : tid;  // task / result slot; the trace slab is per launch position
+    const AlnTask tk = tasks[slot];
     const u32 qb = qoff[tk.q], sb = roff[tk.subj];
     const int lq = (int)(qoff[tk.q + 1] - qb), ls = (int)(roff[tk.subj + 1] - sb);
     const int qi = min((int)tk.qi, lq), qj = min((int)tk.qj, ls);
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     } else {
         r.qst = j + qi, r.qed = bj + qi, r.sst = i + qj, r.sed = bi + qj;
     }
-    out[tid] = r;
+    out[slot] = r;
 }
 
 u32 align_trace_stride(int max_cols_plus) {
@@ -138,10 +140,10 @@ u32 align_trace_stride(int max_cols_plus) {
     return (w + 31u) & ~31u;
 }
 
-void launch_align(const AlnTask* tasks, u32 ntasks, const u8* q_res, const u8* q_scls, const u32* qoff, const u8* r_res,
+void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u32* qoff, const u8* r_res,
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, AlnRes* out,
                   hipStream_t st) {
     if (!ntasks) return;
-    hipLaunchKernelGGL(k_align, dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ntasks, q_res, q_scls, qoff, r_res, r_scls, roff,
+    hipLaunchKernelGGL(k_align, dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_res, q_scls, qoff, r_res, r_scls, roff,
                        b62g, trace, trace_stride, out);
 }

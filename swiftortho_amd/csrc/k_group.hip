@@ -206,10 +206,11 @@ __global__ __launch_bounds__(256) void k_iota(u32* __restrict__ p, u32 n) {
     if (i < n) p[i] = i;
 }
 
-// final order -> chunk candidate region + per-query counts
+// final order -> chunk candidate region; the region is sorted by query, so per-query counts are
+// segment lengths: the thread at a segment's last element knows them without atomics.
 __global__ __launch_bounds__(256) void k_emit_cands(const u32* __restrict__ order, u32 n, const u32* __restrict__ c_q,
                                                     const u32* __restrict__ c_rec, u32* __restrict__ out_q, u32* __restrict__ out_rec,
-                                                    u32* __restrict__ qcnt) {
+                                                    u32* __restrict__ seg_first) {
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const u32 r = order[i];
@@ -217,7 +218,15 @@ __global__ __launch_bounds__(256) void k_emit_cands(const u32* __restrict__ orde
     out_q[i] = q;
     const uint4 v = *reinterpret_cast<const uint4*>(c_rec + 4 * (size_t)r);
     *reinterpret_cast<uint4*>(out_rec + 4 * (size_t)i) = v;
-    atomicAdd(&qcnt[q], 1u);
+    if (i == 0 || c_q[order[i - 1]] != q) seg_first[q] = i;
+}
+
+__global__ __launch_bounds__(256) void k_seg_counts(const u32* __restrict__ out_q, u32 n, const u32* __restrict__ seg_first,
+                                                    u32* __restrict__ qcnt) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const u32 q = out_q[i];
+    if (i + 1 == n || out_q[i + 1] != q) qcnt[q] = i + 1 - seg_first[q];
 }
 
 // ---- launch wrappers -------------------------------------------------------------------------------
@@ -263,7 +272,8 @@ void launch_iota(u32* p, u32 n, hipStream_t st) {
 }
 
 void launch_emit_cands(const u32* order, u32 n, const u32* c_q, const u32* c_rec, u32* out_q, u32* out_rec, u32* qcnt,
-                       hipStream_t st) {
+                       u32* seg_first, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_emit_cands, dim3((n + 255) / 256), dim3(256), 0, st, order, n, c_q, c_rec, out_q, out_rec, qcnt);
+    hipLaunchKernelGGL(k_emit_cands, dim3((n + 255) / 256), dim3(256), 0, st, order, n, c_q, c_rec, out_q, out_rec, seg_first);
+    hipLaunchKernelGGL(k_seg_counts, dim3((n + 255) / 256), dim3(256), 0, st, out_q, n, seg_first, qcnt);
 }

@@ -23,17 +23,46 @@ __global__ __launch_bounds__(256) void k_add_u32(u32* __restrict__ acc, const u3
     if (i < n) acc[i] += x[i];
 }
 
-// qsort(hits, key=-score) (3051) per query + number of alignment tasks min(n, vmax) (3059, 3062)
+// qsort(hits, key=-score) (3051) per query + number of alignment tasks min(n, vmax) (3059, 3062).
+// One wave per query: the candidates' (inverted score << 12 | index) words are staged in LDS and
+// lane 0 replays the reference quicksort there (LDS latency instead of HBM latency per compare);
+// only ranges that reach into the first vmax positions are sorted.  Queries with more than
+// LDS_SORT_MAX candidates take the global-memory kernel below.
+#define LDS_SORT_MAX 4096
+#define SCORE_CAP ((1u << 20) - 1u)
+
+__global__ __launch_bounds__(64) void k_csort_lds(const u32* __restrict__ rec, const u32* __restrict__ qcoff, u32 nq, u32 vmax,
+                                                  u32* __restrict__ perm, u32* __restrict__ ntask) {
+    __shared__ u32 s_x[LDS_SORT_MAX];
+    const u32 q = blockIdx.x;
+    const u32 c0 = qcoff[q];
+    const int n = (int)(qcoff[q + 1] - c0);
+    if (n > LDS_SORT_MAX) return;  // k_csort handles it
+    const u32* r = rec + 4 * (size_t)c0;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        u32 sc = r[4 * (size_t)i + 1];
+        sc = sc > SCORE_CAP ? SCORE_CAP : sc;
+        s_x[i] = ((SCORE_CAP - sc) << 12) | (u32)i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ref_qsort_dev(s_x, n, [](u32 v) { return (int)(v >> 12); }, (int)vmax);
+    __syncthreads();
+    const int m = n < (int)vmax ? n : (int)vmax;
+    for (int i = threadIdx.x; i < m; i += 64) perm[c0 + i] = s_x[i] & 0xFFFu;
+    if (threadIdx.x == 0) ntask[q] = (u32)m;
+}
+
 __global__ __launch_bounds__(64) void k_csort(const u32* __restrict__ rec, const u32* __restrict__ qcoff, u32 nq, u32 vmax,
                                               u32* __restrict__ perm, u32* __restrict__ ntask) {
     const u32 q = blockIdx.x * 64u + threadIdx.x;
     if (q >= nq) return;
     const u32 c0 = qcoff[q];
     const int n = (int)(qcoff[q + 1] - c0);
+    if (n <= LDS_SORT_MAX) return;  // done by k_csort_lds
     u32* x = perm + c0;
     for (int i = 0; i < n; ++i) x[i] = (u32)i;
     const u32* r = rec + 4 * (size_t)c0;
-    ref_qsort_dev(x, n, [r](u32 i) { return -(i64)r[4 * (size_t)i + 1]; });
+    ref_qsort_dev(x, n, [r](u32 i) { return -(i64)r[4 * (size_t)i + 1]; }, (int)vmax);
     ntask[q] = (u32)n < vmax ? (u32)n : vmax;
 }
 
@@ -52,15 +81,45 @@ __global__ __launch_bounds__(64) void k_mktasks(const u32* __restrict__ rec, con
     }
 }
 
-// sequential stop rule (3052-3054, 3062-3104) + qsort_u(m8s, key=-bit) (3108) + first v (3109)
-__global__ __launch_bounds__(64) void k_stop(const AlnTask* __restrict__ tasks, const AlnRes* __restrict__ res,
-                                             const u32* __restrict__ qcoff, const u32* __restrict__ ntask, const u32* __restrict__ toff,
-                                             u32 nq, const u32* __restrict__ qoff, const u32* __restrict__ roff,
-                                             const int* __restrict__ bittab, int bittab_n, i64 D, double expect, double max_miss, i64 v,
-                                             u32* __restrict__ sel, u32* __restrict__ nout, int* __restrict__ bits) {
+// ---- sequential stop rule in rounds -----------------------------------------------------------------
+// The reference aligns a query's sorted candidates one by one and stops after `mmiss` consecutive
+// misses (3052-3054, 3062-3104), so only a prefix of the top-vmax list is ever aligned.  The
+// device aligns that list in growing rounds: each round aligns the next B ranks of every query
+// that has not stopped, then k_stop_round replays the sequential rule over them.  Per-query state
+// st_state[5*q + {0 next rank, 1 unmch, 2 bv, 3 nsel, 4 done}].
+__global__ __launch_bounds__(256) void k_round_counts(const u32* __restrict__ ntask, const u32* __restrict__ st_state, u32 nq, u32 B,
+                                                      u32* __restrict__ rcnt) {
+    const u32 q = blockIdx.x * 256u + threadIdx.x;
+    if (q > nq) return;
+    u32 c = 0;
+    if (q < nq && !st_state[5 * (size_t)q + 4]) {
+        const u32 left = ntask[q] - st_state[5 * (size_t)q];
+        c = left < B ? left : B;
+    }
+    rcnt[q] = c;
+}
+
+__global__ __launch_bounds__(64) void k_round_idx(const u32* __restrict__ rcnt, const u32* __restrict__ roff, const u32* __restrict__ toff,
+                                                  const u32* __restrict__ st_state, u32 nq, u32* __restrict__ ridx) {
+    const u32 q = blockIdx.x;
+    const u32 n = rcnt[q];
+    if (!n) return;
+    const u32 base = toff[q] + st_state[5 * (size_t)q], o = roff[q];
+    for (u32 k = threadIdx.x; k < n; k += 64) ridx[o + k] = base + k;
+}
+
+__global__ __launch_bounds__(64) void k_stop_round(const AlnTask* __restrict__ tasks, const AlnRes* __restrict__ res,
+                                                   const u32* __restrict__ qcoff, const u32* __restrict__ ntask,
+                                                   const u32* __restrict__ toff, const u32* __restrict__ rcnt, u32 nq,
+                                                   const u32* __restrict__ qoff, const u32* __restrict__ roff,
+                                                   const int* __restrict__ bittab, int bittab_n, i64 D, double expect, double max_miss,
+                                                   i64 v, u32* __restrict__ sel, u32* __restrict__ st_state, int* __restrict__ bits) {
     const u32 q = blockIdx.x * 64u + threadIdx.x;
     if (q >= nq) return;
-    const u32 t0 = toff[q], nt = ntask[q];
+    const u32 nr = rcnt[q];
+    if (!nr) return;
+    u32* S = st_state + 5 * (size_t)q;
+    const u32 t0 = toff[q];
     const u32 n = qcoff[q + 1] - qcoff[q];
     double mmiss = (double)n * max_miss + 1;
     const double inv = 100. / mmiss;
@@ -68,9 +127,12 @@ __global__ __launch_bounds__(64) void k_stop(const AlnTask* __restrict__ tasks, 
     mmiss = mmiss > 10. ? mmiss : 10.;
     mmiss = mmiss < 120. ? mmiss : 120.;
     const i64 li = (i64)(qoff[q + 1] - qoff[q]);
-    i64 unmch = 0, bv = 0;
-    u32 nsel = 0;
-    for (u32 r = 0; r < nt; ++r) {
+    u32 r = S[0];
+    i64 unmch = S[1], bv = S[2];
+    u32 nsel = S[3];
+    bool done = false;
+    const u32 rend = r + nr;
+    for (; r < rend; ++r) {
         const AlnTask tk = tasks[t0 + r];
         const AlnRes a = res[t0 + r];
         const i64 lj = (i64)(roff[tk.subj + 1] - roff[tk.subj]);
@@ -78,7 +140,7 @@ __global__ __launch_bounds__(64) void k_stop(const AlnTask* __restrict__ tasks, 
         const int bit = bittab[sc];
         bits[t0 + r] = bit;
         const double p2 = bit > 1074 ? 0.0 : ldexp(1.0, -bit);
-        const double e = (double)(D * li * lj) * p2;
+        const double e = (double)(D * li * lj) * p2;  // bit2e (1086)
         if (e <= expect) {
             sel[t0 + nsel++] = r;
             unmch = 0;
@@ -86,8 +148,24 @@ __global__ __launch_bounds__(64) void k_stop(const AlnTask* __restrict__ tasks, 
         } else {
             unmch += 1;
         }
-        if ((double)unmch >= mmiss || (double)bv >= (double)v + mmiss) break;
+        if ((double)unmch >= mmiss || (double)bv >= (double)v + mmiss) {
+            done = true;
+            ++r;
+            break;
+        }
     }
+    if (r >= ntask[q]) done = true;
+    S[0] = r, S[1] = (u32)unmch, S[2] = (u32)bv, S[3] = nsel, S[4] = done ? 1u : 0u;
+}
+
+// qsort_u(m8s, key=-bit) (3108) + first v (3109)
+__global__ __launch_bounds__(64) void k_final_select(const u32* __restrict__ toff, u32 nq, i64 v, u32* __restrict__ sel,
+                                                     const u32* __restrict__ st_state, const int* __restrict__ bits,
+                                                     u32* __restrict__ nout) {
+    const u32 q = blockIdx.x * 64u + threadIdx.x;
+    if (q >= nq) return;
+    const u32 t0 = toff[q];
+    const u32 nsel = st_state[5 * (size_t)q + 3];
     const int* b = bits + t0;
     ref_qsort_dev(sel + t0, (int)nsel, [b](u32 r) { return -b[r]; });
     const i64 vv = v > 0 ? v : 0;
@@ -113,10 +191,16 @@ __global__ __launch_bounds__(64) void k_emit_hits(const AlnTask* __restrict__ ta
 }
 
 __global__ __launch_bounds__(256) void k_sum_cells(const AlnRes* __restrict__ res, u32 n, unsigned long long* __restrict__ total) {
-    const u32 i = blockIdx.x * 256u + threadIdx.x;
-    unsigned long long c = i < n ? (unsigned long long)res[i].cells : 0ull;
+    __shared__ unsigned long long s_w[4];
+    unsigned long long c = 0;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) c += (unsigned long long)res[i].cells;
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, c);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (c) atomicAdd(total, c);
+    }
 }
 
 // ---- launch wrappers -------------------------------------------------------------------------------
@@ -133,6 +217,7 @@ void launch_add_u32(u32* acc, const u32* x, u32 n, hipStream_t st) {
 
 void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, u32* perm, u32* ntask, hipStream_t st) {
     if (!nq) return;
+    hipLaunchKernelGGL(k_csort_lds, dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, perm, ntask);
     hipLaunchKernelGGL(k_csort, dim3((nq + 63) / 64), dim3(64), 0, st, rec, qcoff, nq, vmax, perm, ntask);
 }
 
@@ -142,12 +227,26 @@ void launch_mktasks(const u32* rec, const u32* qcoff, const u32* perm, const u32
     hipLaunchKernelGGL(k_mktasks, dim3((nq + 63) / 64), dim3(64), 0, st, rec, qcoff, perm, ntask, toff, nq, tasks);
 }
 
-void launch_stop(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* toff, u32 nq, const u32* qoff,
-                 const u32* roff, const int* bittab, int bittab_n, i64 D, double expect, double max_miss, i64 v, u32* sel, u32* nout,
-                 int* bits, hipStream_t st) {
+void launch_round_counts(const u32* ntask, const u32* st_state, u32 nq, u32 B, u32* rcnt, hipStream_t st) {
+    hipLaunchKernelGGL(k_round_counts, dim3((nq + 1 + 255) / 256), dim3(256), 0, st, ntask, st_state, nq, B, rcnt);
+}
+
+void launch_round_idx(const u32* rcnt, const u32* roff, const u32* toff, const u32* st_state, u32 nq, u32* ridx, hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_stop, dim3((nq + 63) / 64), dim3(64), 0, st, tasks, res, qcoff, ntask, toff, nq, qoff, roff, bittab,
-                       bittab_n, D, expect, max_miss, v, sel, nout, bits);
+    hipLaunchKernelGGL(k_round_idx, dim3(nq), dim3(64), 0, st, rcnt, roff, toff, st_state, nq, ridx);
+}
+
+void launch_stop_round(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* toff, const u32* rcnt,
+                       u32 nq, const u32* qoff, const u32* roff, const int* bittab, int bittab_n, i64 D, double expect,
+                       double max_miss, i64 v, u32* sel, u32* st_state, int* bits, hipStream_t st) {
+    if (!nq) return;
+    hipLaunchKernelGGL(k_stop_round, dim3((nq + 63) / 64), dim3(64), 0, st, tasks, res, qcoff, ntask, toff, rcnt, nq, qoff, roff, bittab,
+                       bittab_n, D, expect, max_miss, v, sel, st_state, bits);
+}
+
+void launch_final_select(const u32* toff, u32 nq, i64 v, u32* sel, const u32* st_state, const int* bits, u32* nout, hipStream_t st) {
+    if (!nq) return;
+    hipLaunchKernelGGL(k_final_select, dim3((nq + 63) / 64), dim3(64), 0, st, toff, nq, v, sel, st_state, bits, nout);
 }
 
 void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, const u32* sel, const u32* nout, const u32* ooff,
@@ -158,5 +257,5 @@ void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, 
 
 void launch_sum_cells(const AlnRes* res, u32 n, unsigned long long* total, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_sum_cells, dim3((n + 255) / 256), dim3(256), 0, st, res, n, total);
+    hipLaunchKernelGGL(k_sum_cells, dim3(std::min<u32>(1024u, (n + 255) / 256)), dim3(256), 0, st, res, n, total);
 }

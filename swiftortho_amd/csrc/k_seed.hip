@@ -53,8 +53,36 @@ __global__ __launch_bounds__(256) void k_bounds(const u32* __restrict__ qbucket,
 }
 
 // ---- k-mer self-score order (fsearch.py:2647-2656, 2660, 2668) -----------------------------------
-// One thread per query: kscs over the shortest seed span on the MASKED query, then the
-// reference quicksort of positions by -ksc.  korder[qoff[q] + r] = r-th position.
+// kscs over the shortest seed span on the MASKED query, then the reference quicksort of positions
+// by -ksc.  korder[qoff[q] + r] = r-th position.  One wave per query with the
+// ((KSC_BIAS - ksc) << 12 | position) words in LDS and lane 0 replaying the reference quicksort;
+// queries longer than LDS_SORT_MAX windows take the one-thread-per-query global-memory kernel.
+#define LDS_SORT_MAX 4096
+#define KSC_BIAS (1 << 18)
+
+__global__ __launch_bounds__(64) void k_ksc_order_lds(const u8* __restrict__ q_scls, const u32* __restrict__ qoff, u32 nq, int mink,
+                                                      const signed char* __restrict__ b62c, u32* __restrict__ korder) {
+    __shared__ signed char s_self[SCLS_N];
+    __shared__ u32 s_x[LDS_SORT_MAX];
+    if (threadIdx.x < SCLS_N) s_self[threadIdx.x] = b62c[threadIdx.x * SCLS_N + threadIdx.x];
+    __syncthreads();
+    const u32 q = blockIdx.x;
+    const u32 base = qoff[q];
+    const int ql = (int)(qoff[q + 1] - base);
+    const int nk = ql - mink + 1;
+    if (nk <= 0 || nk > LDS_SORT_MAX) return;
+    const u8* c = q_scls + base;
+    for (int i = threadIdx.x; i < nk; i += 64) {
+        int sc = 0;
+        for (int j = 0; j < mink; ++j) sc += s_self[c[i + j]];
+        s_x[i] = ((u32)(KSC_BIAS - sc) << 12) | (u32)i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ref_qsort_dev(s_x, nk, [](u32 v) { return (int)(v >> 12); });
+    __syncthreads();
+    for (int i = threadIdx.x; i < nk; i += 64) korder[base + i] = s_x[i] & 0xFFFu;
+}
+
 __global__ __launch_bounds__(64) void k_ksc_order(const u8* __restrict__ q_scls, const u32* __restrict__ qoff, u32 nq, int mink,
                                                   const signed char* __restrict__ b62c /*24x24*/, int* __restrict__ ksc,
                                                   u32* __restrict__ korder) {
@@ -66,7 +94,7 @@ __global__ __launch_bounds__(64) void k_ksc_order(const u8* __restrict__ q_scls,
     const u32 base = qoff[q];
     const int ql = (int)(qoff[q + 1] - base);
     const int nk = ql - mink + 1;
-    if (nk <= 0) return;
+    if (nk <= LDS_SORT_MAX) return;  // done by k_ksc_order_lds (or nothing to do)
     const u8* c = q_scls + base;
     int* k = ksc + base;
     u32* x = korder + base;
@@ -234,6 +262,7 @@ void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* start, u32 N
 void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, int mink, const signed char* b62c, int* ksc, u32* korder,
                       hipStream_t st) {
     if (!nq) return;
+    hipLaunchKernelGGL(k_ksc_order_lds, dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
     hipLaunchKernelGGL(k_ksc_order, dim3((nq + 63) / 64), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, ksc, korder);
 }
 

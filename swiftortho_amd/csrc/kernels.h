@@ -57,11 +57,11 @@ void launch_best(const u64* sorted_qs, const u32* idx, const u32* shead, u32 nse
 void launch_gather_u32_as_u64(const u32* src, const u32* idx, u32 n, u64* dst, hipStream_t st);
 void launch_iota(u32* p, u32 n, hipStream_t st);
 void launch_emit_cands(const u32* order, u32 n, const u32* c_q, const u32* c_rec, u32* out_q, u32* out_rec, u32* qcnt,
-                       hipStream_t st);
+                       u32* seg_first, hipStream_t st);
 
 // k_align.hip
 u32 align_trace_stride(int max_rows);
-void launch_align(const AlnTask* tasks, u32 ntasks, const u8* q_res, const u8* q_scls, const u32* qoff, const u8* r_res,
+void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u32* qoff, const u8* r_res,
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, AlnRes* out,
                   hipStream_t st);
 
@@ -72,9 +72,12 @@ void launch_add_u32(u32* acc, const u32* x, u32 n, hipStream_t st);
 void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, u32* perm, u32* ntask, hipStream_t st);
 void launch_mktasks(const u32* rec, const u32* qcoff, const u32* perm, const u32* ntask, const u32* toff, u32 nq, AlnTask* tasks,
                     hipStream_t st);
-void launch_stop(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* toff, u32 nq, const u32* qoff,
-                 const u32* roff, const int* bittab, int bittab_n, i64 D, double expect, double max_miss, i64 v, u32* sel, u32* nout,
-                 int* bits, hipStream_t st);
+void launch_round_counts(const u32* ntask, const u32* st_state, u32 nq, u32 B, u32* rcnt, hipStream_t st);
+void launch_round_idx(const u32* rcnt, const u32* roff, const u32* toff, const u32* st_state, u32 nq, u32* ridx, hipStream_t st);
+void launch_stop_round(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* toff, const u32* rcnt,
+                       u32 nq, const u32* qoff, const u32* roff, const int* bittab, int bittab_n, i64 D, double expect,
+                       double max_miss, i64 v, u32* sel, u32* st_state, int* bits, hipStream_t st);
+void launch_final_select(const u32* toff, u32 nq, i64 v, u32* sel, const u32* st_state, const int* bits, u32* nout, hipStream_t st);
 void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, const u32* sel, const u32* nout, const u32* ooff,
                       const int* bits, u32 nq, int* out, hipStream_t st);
 void launch_sum_cells(const AlnRes* res, u32 n, unsigned long long* total, hipStream_t st);

@@ -7,15 +7,17 @@
 #pragma once
 #include "common.h"
 
+// `limit`: only positions [0, limit) of the result are needed -- sub-ranges that start at or beyond
+// it are left unsorted (they cannot influence earlier positions: sub-ranges are independent).
 template <class KeyFn>
-__device__ inline void ref_qsort_dev(u32* x, int n, KeyFn key) {
+__device__ inline void ref_qsort_dev(u32* x, int n, KeyFn key, int limit = 0x7fffffff) {
     int stk[2 * 48];
     int sp = 0;
     stk[sp++] = 0;
     stk[sp++] = n - 1;
     while (sp > 0) {
         int r = stk[--sp], l = stk[--sp];
-        if (r <= l) continue;
+        if (r <= l || l >= limit) continue;
         int gap = r - l + 1;
         if (gap < 7) {
             for (int i = l; i < r + 1; ++i) {  // insort(x, l, r + 1)
