@@ -69,6 +69,7 @@ struct DevBuf {
 #define MAX_SEEDLEN 32   // longest spaced-seed pattern
 #define MIN_UNGAP 25     // self.min, fsearch.py:2224
 #define DROPX 30
+#define UG_SHARDS 64   // pass-list shards of k_ungap (power of two)
 
 struct SeedCfg {
     int S, A;                       // #patterns, #alphabets

@@ -550,7 +550,9 @@ struct Batch {
     DevBuf<u32> cs_hoff, cs_beg, cs_q, cs_qa, blk_first;
     DevBuf<u64> keys, keys2;
     DevBuf<u32> flags, gidx, ghead;
-    DevBuf<u64> p_qs, p_sd, p_ft, p_qs2, tmp64;
+    DevBuf<u64> p_qs, p_sd, p_ft, p_qs2, tmp64, q_qs, q_sd, q_ft;
+    DevBuf<u32> shard;
+    DevBuf<unsigned long long> stepshard;
     DevBuf<u32> pidx, pidx2, shead;
     DevBuf<u64> c_ft, c_ft2;
     DevBuf<u32> c_q, c_rec, order, order2;
@@ -740,12 +742,24 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     b.ghead.ensure((size_t)G + 2);
     launch_group_list(b.flags.p, b.gidx.p, H, b.ghead.p, c->st);
     sc.lap("group.heads");
-    b.p_qs.ensure((size_t)G + 2), b.p_sd.ensure((size_t)G + 2), b.p_ft.ensure((size_t)G + 2);
-    HIP_CHECK(hipMemsetAsync(b.counters.p, 0, sizeof(u32), c->st));
+    const u32 shard_cap = ungap_shard_cap(G);
+    const size_t pcap = (size_t)shard_cap * UG_SHARDS + 2;
+    b.p_qs.ensure(pcap), b.p_sd.ensure(pcap), b.p_ft.ensure(pcap);
+    b.shard.ensure(2 * UG_SHARDS + 8);
+    b.stepshard.ensure(UG_SHARDS);
+    HIP_CHECK(hipMemsetAsync(b.shard.p, 0, (2 * UG_SHARDS + 8) * sizeof(u32), c->st));
+    HIP_CHECK(hipMemsetAsync(b.stepshard.p, 0, UG_SHARDS * sizeof(unsigned long long), c->st));
     launch_ungap(b.keys2.p, b.ghead.p, G, Hvalid, kl, ft_bits_entry, bsp, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls.p,
-                 c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.counters.p, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.ucount.p, c->st);
-    const u32 NP = d2h_u32(c, b.counters.p);
+                 c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
+    // contiguous pass list
+    u32* shard_off = b.shard.p + UG_SHARDS;
+    launch_shard_scan(b.shard.p, shard_off, c->st);
+    const u32 NP = d2h_u32(c, shard_off + UG_SHARDS);
     sc.lap("group.ungap");
+    if (NP) {
+        b.q_qs.ensure((size_t)NP + 2), b.q_sd.ensure((size_t)NP + 2), b.q_ft.ensure((size_t)NP + 2);
+        launch_compact_shards(b.shard.p, shard_off, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.q_qs.p, b.q_sd.p, b.q_ft.p, c->st);
+    }
     if (NP == 0) {
         c->cnt.seed_ms += (t1 - t0) * 1e3;
         c->cnt.group_ms += (wall() - t1) * 1e3;
@@ -755,7 +769,7 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     b.pidx.ensure((size_t)NP + 2), b.pidx2.ensure((size_t)NP + 2), b.p_qs2.ensure((size_t)NP + 2);
     launch_iota(b.pidx.p, NP, c->st);
     ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(NP, 64));
-    sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.p_qs.p, b.p_qs2.p, b.pidx.p, b.pidx2.p, NP, 32 + kl.bq, c->st);
+    sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.q_qs.p, b.p_qs2.p, b.pidx.p, b.pidx2.p, NP, 32 + kl.bq, c->st);
     b.flags.ensure((size_t)NP + 4), b.gidx.ensure((size_t)NP + 4);
     launch_seg_flags(b.p_qs2.p, NP, b.flags.p, c->st);
     const u32* dS = scan_u32(b.flags.p, b.gidx.p, NP, false, c->d_scan_tmp.p, c->st);
@@ -763,7 +777,7 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     b.shead.ensure((size_t)NS + 2);
     launch_group_list(b.flags.p, b.gidx.p, NP, b.shead.p, c->st);
     b.c_ft.ensure((size_t)NS + 2), b.c_ft2.ensure((size_t)NS + 2), b.c_q.ensure((size_t)NS + 2), b.c_rec.ensure(4 * (size_t)NS + 8);
-    launch_best(b.p_qs2.p, b.pidx2.p, b.shead.p, NS, NP, b.p_sd.p, b.p_ft.p, (u32)ch.seq_lo, b.c_ft.p, b.c_q.p, b.c_rec.p, c->st);
+    launch_best(b.p_qs2.p, b.pidx2.p, b.shead.p, NS, NP, b.q_sd.p, b.q_ft.p, (u32)ch.seq_lo, b.c_ft.p, b.c_q.p, b.c_rec.p, c->st);
     // order candidates by (query, first-touch): sort by first-touch, then stable sort by query
     b.order.ensure((size_t)NS + 2), b.order2.ensure((size_t)NS + 2), b.tmp64.ensure((size_t)NS + 2);
     launch_iota(b.order.p, NS, c->st);

@@ -36,35 +36,80 @@ __global__ __launch_bounds__(256) void k_group_list(const u32* __restrict__ flag
 
 // ---- chained ungapped extension -----------------------------------------------------------------
 struct UG {
-    int max_score, max_qst, max_qed, max_sst, max_sed, steps;
+    int max_score, max_qst, max_qed, max_sst, max_sed;
 };
 
-// Fasta.ungap (fsearch.py:2454-2494); qlo/slo already resolved to >= 0
-__device__ __forceinline__ UG ungap_dev(const u8* __restrict__ q, int ql, const u8* __restrict__ s, int sl, int Qst, int Sst, int qlo,
-                                        int slo, const signed char* b62c) {
-    int off = max(max(qlo - Qst, slo - Sst), 0);
+#define B62_LD 32  // LDS score table is 32 x 32 so that any 5-bit class pair indexes inside it
+
+__device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global load
+    u64 w;
+    __builtin_memcpy(&w, p, 8);
+    return w;
+}
+
+// Fasta.ungap (fsearch.py:2454-2494); qlo/slo already resolved to >= 0.
+// The reference's per-residue loops are evaluated in chunks of 8 residues: two unaligned 8-byte
+// loads, eight LDS score lookups issued back to back, and predicated (branch-free) max / X-drop
+// updates.  Scores, maxima and end points are exactly those of the sequential loops: an element
+// is applied only while `k < remaining && !stopped`.  qabs/sabs = absolute offsets of the two
+// sequences inside their (padded) class arrays, used to keep the left-pass loads in bounds.
+__device__ __forceinline__ UG ungap_dev(const u8* __restrict__ q, int ql, i64 qabs, const u8* __restrict__ s, int sl, i64 sabs, int Qst,
+                                        int Sst, int qlo, int slo, const signed char* b62c) {
+    const int off = max(max(qlo - Qst, slo - Sst), 0);
     Qst += off;
     Sst += off;
-    int qst = Qst, sst = Sst;
-    int score = 0, max_score = 0, max_qed = qst, max_sed = sst, steps = 0;
-    while (qlo < qst && qst < ql && slo < sst && sst < sl) {
-        ++steps;
-        score += b62c[q[qst] * SCLS_N + s[sst]];
-        if (score > max_score) max_score = score, max_qed = qst, max_sed = sst;
-        else if (score + DROPX < max_score) break;
-        ++qst, ++sst;
+    int max_score = 0, score = 0, best = -1;
+    bool stop = false;
+    // right pass: t-th step scores (Qst + t, Sst + t) while qlo < qst < ql and slo < sst < sl
+    int n = (qlo < Qst && slo < Sst) ? min(ql - Qst, sl - Sst) : 0;
+    for (int i = 0; i < n && !stop; i += 8) {
+        const u64 qw = load8u(q + Qst + i), sw = load8u(s + Sst + i);
+        const int m = n - i;
+        int sc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sc[k] = b62c[(((u32)(qw >> (8 * k)) & 31u) * B62_LD) + ((u32)(sw >> (8 * k)) & 31u)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool act = (k < m) && !stop;
+            const int ns = score + sc[k];
+            const bool better = act && (ns > max_score);
+            stop = stop || (act && !better && (ns + DROPX < max_score));
+            score = act ? ns : score;
+            max_score = better ? ns : max_score;
+            best = better ? i + k : best;
+        }
     }
-    qst = Qst - 1, sst = Sst - 1;
+    const int max_qed = best >= 0 ? Qst + best : Qst, max_sed = best >= 0 ? Sst + best : Sst;
+    // left pass from (Qst - 1, Sst - 1), score continues from the maximum
     score = max_score;
-    int max_qst = qst, max_sst = sst;
-    while (ql > qst && qst > qlo && sl > sst && sst > slo) {
-        ++steps;
-        score += b62c[q[qst] * SCLS_N + s[sst]];
-        if (score > max_score) max_score = score, max_qst = qst, max_sst = sst;
-        else if (score + DROPX < max_score) break;
-        --qst, --sst;
+    stop = false;
+    best = -1;
+    n = (Qst - 1 < ql && Sst - 1 < sl) ? min(Qst - 1 - qlo, Sst - 1 - slo) : 0;
+    for (int i = 0; i < n && !stop; i += 8) {
+        // bytes [p - 7, p] with p = Qst - 1 - i; element k lives in byte 7 - k
+        i64 qa = (i64)Qst - 8 - i, sa = (i64)Sst - 8 - i;
+        u64 qw, sw;
+        if (qabs + qa >= 0) qw = load8u(q + qa);
+        else qw = load8u(q - qabs) << (8 * (int)(-(qabs + qa)));  // array start: missing low bytes are never active
+        if (sabs + sa >= 0) sw = load8u(s + sa);
+        else sw = load8u(s - sabs) << (8 * (int)(-(sabs + sa)));
+        const int m = n - i;
+        int sc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sc[k] = b62c[(((u32)(qw >> (8 * (7 - k))) & 31u) * B62_LD) + ((u32)(sw >> (8 * (7 - k))) & 31u)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool act = (k < m) && !stop;
+            const int ns = score + sc[k];
+            const bool better = act && (ns > max_score);
+            stop = stop || (act && !better && (ns + DROPX < max_score));
+            score = act ? ns : score;
+            max_score = better ? ns : max_score;
+            best = better ? i + k : best;
+        }
     }
-    return {max_score, max_qst, max_qed, max_sst, max_sed, steps};
+    const int max_qst = best >= 0 ? Qst - 1 - best : Qst - 1, max_sst = best >= 0 ? Sst - 1 - best : Sst - 1;
+    return {max_score, max_qst, max_qed, max_sst, max_sed};
 }
 
 // One thread per (query, subject, diagonal) group.  Passing groups (score >= 25) are appended to
@@ -74,16 +119,20 @@ __global__ __launch_bounds__(256) void k_ungap(const u64* __restrict__ keys, con
                                                KeyLayout kl, int ft_bits_entry, int bsp, const u8* __restrict__ q_scls,
                                                const u32* __restrict__ qoff, const u8* __restrict__ r_scls,
                                                const u32* __restrict__ roff /*chunk-local offsets (absolute values)*/,
-                                               const signed char* __restrict__ b62g, u32* __restrict__ pass_count,
-                                               u64* __restrict__ p_qs, u64* __restrict__ p_sd, u64* __restrict__ p_ft,
-                                               unsigned long long* __restrict__ step_count) {
-    __shared__ signed char s_b62[SCLS_N * SCLS_N];
-    for (int i = threadIdx.x; i < SCLS_N * SCLS_N; i += 256) s_b62[i] = b62g[i];
+                                               const signed char* __restrict__ b62g, u32* __restrict__ shard_cnt /*[UG_SHARDS]*/,
+                                               u32 shard_cap, u64* __restrict__ p_qs, u64* __restrict__ p_sd, u64* __restrict__ p_ft,
+                                               unsigned long long* __restrict__ step_shards /*[UG_SHARDS]*/) {
+    __shared__ signed char s_b62[B62_LD * B62_LD];
+    __shared__ u32 s_wcnt[4];
+    __shared__ u32 s_base;
+    for (int i = threadIdx.x; i < B62_LD * B62_LD; i += 256) {
+        const int a = i / B62_LD, b = i % B62_LD;
+        s_b62[i] = (a < SCLS_N && b < SCLS_N) ? b62g[a * SCLS_N + b] : (signed char)-4;
+    }
     __syncthreads();
     const u32 g = blockIdx.x * 256u + threadIdx.x;
     bool pass = false;
     u64 o_qs = 0, o_sd = 0, o_ft = 0;
-    int steps_total = 0;
     if (g < G) {
         const u32 h0 = ghead[g], h1 = (g + 1 < G) ? ghead[g + 1] : Hvalid;
         const u64 k0 = keys[h0];
@@ -119,14 +168,12 @@ __global__ __launch_bounds__(256) void k_ungap(const u64* __restrict__ keys, con
             if (qpos == prev_qpos) continue;  // duplicate (qst, sst) pair: dropped by lis()
             prev_qpos = qpos;
             if (first) {
-                UG u = ungap_dev(qs, ql, ss, sl, qpos, sst, 0, 0, s_b62);
+                UG u = ungap_dev(qs, ql, (i64)qb, ss, sl, (i64)sb, qpos, sst, 0, 0, s_b62);
                 scores = u.max_score, x0 = u.max_qst, y0 = u.max_sst, x = u.max_qed, y = u.max_sed;
-                steps_total += u.steps;
                 first = false;
             } else {
-                UG u = ungap_dev(qs, ql, ss, sl, qpos, sst, x, y, s_b62);
+                UG u = ungap_dev(qs, ql, (i64)qb, ss, sl, (i64)sb, qpos, sst, x, y, s_b62);
                 scores += u.max_score, x = u.max_qed, y = u.max_sed;
-                steps_total += u.steps;
             }
         }
         if (scores >= MIN_UNGAP) {
@@ -139,21 +186,49 @@ __global__ __launch_bounds__(256) void k_ungap(const u64* __restrict__ keys, con
             o_ft = ft;
         }
     }
-    // wave-ballot compaction
+    // Wave-ballot compaction, aggregated per block, into one of UG_SHARDS regions: a single global
+    // counter would serialise ~3 M same-address atomics (one per wave) and dominated this kernel;
+    // with one atomic per block spread over 64 addresses the tail is free.  Shard s owns slots
+    // [s * shard_cap, (s + 1) * shard_cap); k_compact_shards makes the list contiguous afterwards.
     const unsigned long long bal = __ballot(pass);
-    const int lane = threadIdx.x & 63;
-    u32 base = 0;
-    if (bal) {
-        if (lane == (int)__ffsll((unsigned long long)bal) - 1) base = atomicAdd(pass_count, (u32)__popcll(bal));
-        base = __shfl(base, __ffsll((unsigned long long)bal) - 1);
-        if (pass) {
-            u32 i = base + (u32)__popcll(bal & ((1ull << lane) - 1ull));
-            p_qs[i] = o_qs, p_sd[i] = o_sd, p_ft[i] = o_ft;
-        }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_wcnt[w] = (u32)__popcll(bal);
+    __syncthreads();
+    const u32 shard = blockIdx.x & (UG_SHARDS - 1);
+    if (threadIdx.x == 0) {
+        const u32 tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        s_base = tot ? atomicAdd(&shard_cnt[shard], tot) : 0u;
     }
-    // work counter (b62 lookups == the reference's `flag`)
-    for (int o = 32; o > 0; o >>= 1) steps_total += __shfl_down(steps_total, o);
-    if (lane == 0 && steps_total) atomicAdd(step_count, (unsigned long long)steps_total);
+    __syncthreads();
+    if (pass) {
+        u32 i = s_base + (u32)__popcll(bal & ((1ull << lane) - 1ull));
+        for (int k = 0; k < w; ++k) i += s_wcnt[k];
+        const size_t o = (size_t)shard * shard_cap + i;
+        p_qs[o] = o_qs, p_sd[o] = o_sd, p_ft[o] = o_ft;
+    }
+}
+
+// shard offsets (exclusive scan over UG_SHARDS counters) + total
+__global__ void k_shard_scan(const u32* __restrict__ shard_cnt, u32* __restrict__ shard_off /*[UG_SHARDS + 1]*/) {
+    if (threadIdx.x == 0) {
+        u32 s = 0;
+        for (int k = 0; k < UG_SHARDS; ++k) {
+            shard_off[k] = s;
+            s += shard_cnt[k];
+        }
+        shard_off[UG_SHARDS] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_compact_shards(const u32* __restrict__ shard_cnt, const u32* __restrict__ shard_off, u32 shard_cap,
+                                                        const u64* __restrict__ a0, const u64* __restrict__ a1, const u64* __restrict__ a2,
+                                                        u64* __restrict__ b0, u64* __restrict__ b1, u64* __restrict__ b2) {
+    const u32 shard = blockIdx.y;
+    const u32 n = shard_cnt[shard], o = shard_off[shard];
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const size_t s = (size_t)shard * shard_cap + i;
+        b0[o + i] = a0[s], b1[o + i] = a1[s], b2[o + i] = a2[s];
+    }
 }
 
 // ---- best diagonal per (query, subject) -----------------------------------------------------------
@@ -241,12 +316,26 @@ void launch_group_list(const u32* flags, const u32* gidx, u32 H, u32* ghead, hip
     hipLaunchKernelGGL(k_group_list, dim3((H + 255) / 256), dim3(256), 0, st, flags, gidx, H, ghead);
 }
 
+u32 ungap_shard_cap(u32 G) {
+    const u32 nblk = (G + 255) / 256;
+    return ((nblk + UG_SHARDS - 1) / UG_SHARDS) * 256u;
+}
+
 void launch_ungap(const u64* keys, const u32* ghead, u32 G, u32 Hvalid, const KeyLayout& kl, int ft_bits_entry, int bsp,
-                  const u8* q_scls, const u32* qoff, const u8* r_scls, const u32* roff, const signed char* b62g, u32* pass_count,
-                  u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* step_count, hipStream_t st) {
+                  const u8* q_scls, const u32* qoff, const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt,
+                  u32 shard_cap, u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* step_shards, hipStream_t st) {
     if (!G) return;
     hipLaunchKernelGGL(k_ungap, dim3((G + 255) / 256), dim3(256), 0, st, keys, ghead, G, Hvalid, kl, ft_bits_entry, bsp, q_scls, qoff,
-                       r_scls, roff, b62g, pass_count, p_qs, p_sd, p_ft, step_count);
+                       r_scls, roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, step_shards);
+}
+
+void launch_shard_scan(const u32* shard_cnt, u32* shard_off, hipStream_t st) {
+    hipLaunchKernelGGL(k_shard_scan, dim3(1), dim3(64), 0, st, shard_cnt, shard_off);
+}
+
+void launch_compact_shards(const u32* shard_cnt, u32* shard_off, u32 shard_cap, const u64* a0, const u64* a1, const u64* a2, u64* b0,
+                           u64* b1, u64* b2, hipStream_t st) {
+    hipLaunchKernelGGL(k_compact_shards, dim3(64, UG_SHARDS), dim3(256), 0, st, shard_cnt, shard_off, shard_cap, a0, a1, a2, b0, b1, b2);
 }
 
 void launch_seg_flags(const u64* sorted_qs, u32 n, u32* flags, hipStream_t st) {
