@@ -101,10 +101,12 @@ struct KeyLayout {
 struct AlnTask {
     u32 q;        // query index local to the batch
     u32 subj;     // global subject id
-    u32 qi, qj;   // start offsets (fsearch.py:3063, 3069-3070)
+    u32 qi, qj;   // start offsets (fsearch.py:3063, 3069-3070); tile starts for the long path
     u32 score;    // ungapped candidate score
     u32 rank;     // position in the query's sorted candidate list
+    u32 qe, se;   // exclusive ends of the aligned windows: sequence lengths, or tile ends (kswat_st_long, 1487-1490)
 };
+#define LONG_SEQ 4096  // fsearch.py:3068 / kswat_st_long chk
 
 struct AlnRes {
     int maxscore, aln, matches, gap;

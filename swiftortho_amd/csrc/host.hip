@@ -562,7 +562,7 @@ struct Batch {
     DevBuf<u32> cand_q, cand_rec;             // all chunks' regions concatenated
     std::vector<u32> chunk_base;              // region start per chunk (+ total)
     DevBuf<u32> ccnt;                         // [nchunks][nq] per-query counts
-    DevBuf<u32> segfirst, st_state, rcnt, roff, ridx;
+    DevBuf<u32> segfirst, st_state, rcnt, tcnt, roff, ridx, ntile, roffc, rk_slot, order_tmp;
     DevBuf<u32> cqoff, prior, qtot, qcoff, fin_rec, perm, ntask, toff, sel, nout, ooff;
     DevBuf<AlnTask> tasks;
     DevBuf<AlnRes> ares;
@@ -842,40 +842,47 @@ void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
         c->cnt.phase2_ms += (wall() - t0) * 1e3;
         return;
     }
-    if (c->qry.maxlen >= 4096 || c->ref.maxlen >= 4096) {
-        // kswat_st_long (fsearch.py:1480-1498) tiling is not implemented on the device yet
-        bool any_long = false;
-        for (u32 i = 0; i < nq && !any_long; ++i) any_long = c->qry.len(b.q_lo + i) >= 4096;
-        if (any_long || c->ref.maxlen >= 4096)
-            throw SoError("sequences of >= 4096 residues need the tiled long-alignment path, which this build does not have yet");
-    }
     const u32 vmax = (u32)std::max<i64>(100, std::max<i64>(c->v + 100, (i64)((double)c->v * 1.1)));  // fsearch.py:3059
-    b.perm.ensure((size_t)Ntot + 4), b.ntask.ensure((size_t)nq + 4), b.toff.ensure((size_t)nq + 4);
+    // ranks = candidates considered (top vmax); tasks = alignments (1 per rank, or one per 4096-tile
+    // of a long candidate, kswat_st_long)
+    b.perm.ensure((size_t)Ntot + 4), b.ntask.ensure((size_t)nq + 4), b.ntile.ensure((size_t)nq + 4);
+    b.toff.ensure((size_t)nq + 4), b.roffc.ensure((size_t)nq + 4);
     HIP_CHECK(hipMemsetAsync(b.ntask.p, 0, ((size_t)nq + 4) * sizeof(u32), c->st));
-    launch_csort(b.fin_rec.p, b.qcoff.p, nq, vmax, b.perm.p, b.ntask.p, c->st);
-    const u32* dNT = scan_u32(b.ntask.p, b.toff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
+    HIP_CHECK(hipMemsetAsync(b.ntile.p, 0, ((size_t)nq + 4) * sizeof(u32), c->st));
+    launch_csort(b.fin_rec.p, b.qcoff.p, nq, vmax, b.dev.d_off.p, c->ref.d_off.p, b.perm.p, b.ntask.p, b.ntile.p, c->st);
+    const u32* dNRk = scan_u32(b.ntask.p, b.roffc.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
+    const u32 NRK = d2h_u32(c, dNRk);
+    const u32* dNT = scan_u32(b.ntile.p, b.toff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
     const u32 NT = d2h_u32(c, dNT);
     sc.lap("phase2.csort");
     b.tasks.ensure((size_t)NT + 4), b.ares.ensure((size_t)NT + 4), b.bits.ensure((size_t)NT + 4), b.sel.ensure((size_t)NT + 4);
+    b.rk_slot.ensure((size_t)NRK + 4);
     HIP_CHECK(hipMemsetAsync(b.ares.p, 0, ((size_t)NT + 4) * sizeof(AlnRes), c->st));  // unaligned slots count 0 cells
-    launch_mktasks(b.fin_rec.p, b.qcoff.p, b.perm.p, b.ntask.p, b.toff.p, nq, b.tasks.p, c->st);
-    // banded alignments in rounds (see k_stop_round): round sizes 64, 128, 256, ... ranks per query
-    const int maxrows = (int)std::min<u32>(std::max(b.maxqlen, c->ref.maxlen), std::min(b.maxqlen, c->ref.maxlen) + 16);
+    launch_mktasks(b.fin_rec.p, b.qcoff.p, b.perm.p, b.ntask.p, b.roffc.p, b.toff.p, nq, b.dev.d_off.p, c->ref.d_off.p, b.tasks.p,
+                   b.rk_slot.p, c->st);
+    // banded alignments in rounds (see k_stop_round): 64, 128, 256, ... ranks per query and round
+    const u32 maxwin_q = std::min<u32>(b.maxqlen, LONG_SEQ), maxwin_s = std::min<u32>(c->ref.maxlen, LONG_SEQ);
+    const int maxrows = (int)std::min<u32>(std::max(maxwin_q, maxwin_s), std::min(maxwin_q, maxwin_s) + 16);
     const u32 stride = align_trace_stride(maxrows + 1);
     const size_t budget_words = (size_t)1 << 30;  // 4 GiB of trace scratch
-    const u32 slab = (u32)std::max<size_t>(16, std::min<size_t>(NT, budget_words / std::max<u32>(stride, 1)));
-    b.st_state.ensure(5 * (size_t)nq + 8), b.rcnt.ensure((size_t)nq + 4), b.roff.ensure((size_t)nq + 4), b.ridx.ensure((size_t)NT + 4);
+    const u32 slab = (u32)std::max<size_t>(16, std::min<size_t>(std::max<u32>(NT, 1), budget_words / std::max<u32>(stride, 1)));
+    b.st_state.ensure(5 * (size_t)nq + 8), b.rcnt.ensure((size_t)nq + 4), b.tcnt.ensure((size_t)nq + 4), b.roff.ensure((size_t)nq + 4);
+    b.order_tmp.ensure((size_t)nq + 4);
+    b.ridx.ensure((size_t)NT + 4);
     HIP_CHECK(hipMemsetAsync(b.st_state.p, 0, (5 * (size_t)nq + 8) * sizeof(u32), c->st));
     sc.lap("phase2.mktasks");
     u32 aligned_total = 0;
-    for (u32 B = 64;; B *= 2) {
-        launch_round_counts(b.ntask.p, b.st_state.p, nq, B, b.rcnt.p, c->st);
-        const u32* dNR = scan_u32(b.rcnt.p, b.roff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
+    for (u32 B = 64;; B = B < (1u << 20) ? B * 2 : B) {
+        launch_round_counts(b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.st_state.p, nq, B, b.rcnt.p, b.tcnt.p, c->st);
+        const u32* dNR = scan_u32(b.tcnt.p, b.roff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
         const u32 NR = d2h_u32(c, dNR);
-        if (NR == 0) break;
-        launch_round_idx(b.rcnt.p, b.roff.p, b.toff.p, b.st_state.p, nq, b.ridx.p, c->st);
-        b.trace.ensure((size_t)std::min(slab, NR) * stride + 64);
-        {
+        // ranks left this round (a round may hold ranks with zero tiles only)
+        const u32* dRR = scan_u32(b.rcnt.p, b.order_tmp.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
+        const u32 RR = d2h_u32(c, dRR);
+        if (RR == 0) break;
+        if (NR) {
+            launch_round_idx(b.tcnt.p, b.roff.p, b.toff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.st_state.p, nq, b.ridx.p, c->st);
+            b.trace.ensure((size_t)std::min(slab, NR) * stride + 64);
             ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
             for (u32 t = 0; t < NR; t += slab) {
                 const u32 n = std::min(slab, NR - t);
@@ -884,8 +891,9 @@ void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
             }
             pt.stop();
         }
-        launch_stop_round(b.tasks.p, b.ares.p, b.qcoff.p, b.ntask.p, b.toff.p, b.rcnt.p, nq, b.dev.d_off.p, c->ref.d_off.p, c->d_bittab.p,
-                          so_ctx::BITTAB_N, c->ref.N, c->expect, c->max_miss, c->v, b.sel.p, b.st_state.p, b.bits.p, c->st);
+        launch_stop_round(b.tasks.p, b.ares.p, b.qcoff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.toff.p, b.rcnt.p, nq,
+                          b.dev.d_off.p, c->ref.d_off.p, c->d_bittab.p, so_ctx::BITTAB_N, c->ref.N, c->expect, c->max_miss, c->v, b.sel.p,
+                          b.st_state.p, b.bits.p, c->st);
         aligned_total += NR;
     }
     launch_sum_cells(b.ares.p, NT, b.ucount.p + 1, c->st);

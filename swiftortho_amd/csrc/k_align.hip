@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     const u32 slot = ridx ? ridx[tid] : tid;  // task / result slot; the trace slab is per launch position
     const AlnTask tk = tasks[slot];
     const u32 qb = qoff[tk.q], sb = roff[tk.subj];
-    const int lq = (int)(qoff[tk.q + 1] - qb), ls = (int)(roff[tk.subj + 1] - sb);
+    const int lq = min((int)(qoff[tk.q + 1] - qb), (int)tk.qe), ls = min((int)(roff[tk.subj + 1] - sb), (int)tk.se);
     const int qi = min((int)tk.qi, lq), qj = min((int)tk.qj, ls);
     const int la = lq - qi, lb = ls - qj;
     const bool swp = !(la < lb);  // abs(qed - qst) < abs(sed - sst) -> no swap (1364-1369)

@@ -31,8 +31,16 @@ __global__ __launch_bounds__(256) void k_add_u32(u32* __restrict__ acc, const u3
 #define LDS_SORT_MAX 4096
 #define SCORE_CAP ((1u << 20) - 1u)
 
+// tiles of one candidate: 1 on the normal path; on the long path (either sequence >= 4096,
+// fsearch.py:3068, 3085) one per 4096-residue step of the query from qi (range(qi, li, chk), 1487)
+__device__ __forceinline__ u32 cand_tiles(u32 lq, u32 ls, u32 qi) {
+    if (lq < LONG_SEQ && ls < LONG_SEQ) return 1u;
+    return qi < lq ? (lq - qi + LONG_SEQ - 1) / LONG_SEQ : 0u;
+}
+
 __global__ __launch_bounds__(64) void k_csort_lds(const u32* __restrict__ rec, const u32* __restrict__ qcoff, u32 nq, u32 vmax,
-                                                  u32* __restrict__ perm, u32* __restrict__ ntask) {
+                                                  const u32* __restrict__ qoff, const u32* __restrict__ roff, u32* __restrict__ perm,
+                                                  u32* __restrict__ ntask, u32* __restrict__ ntile) {
     __shared__ u32 s_x[LDS_SORT_MAX];
     const u32 q = blockIdx.x;
     const u32 c0 = qcoff[q];
@@ -48,12 +56,21 @@ __global__ __launch_bounds__(64) void k_csort_lds(const u32* __restrict__ rec, c
     if (threadIdx.x == 0) ref_qsort_dev(s_x, n, [](u32 v) { return (int)(v >> 12); }, (int)vmax);
     __syncthreads();
     const int m = n < (int)vmax ? n : (int)vmax;
-    for (int i = threadIdx.x; i < m; i += 64) perm[c0 + i] = s_x[i] & 0xFFFu;
-    if (threadIdx.x == 0) ntask[q] = (u32)m;
+    const u32 lq = qoff[q + 1] - qoff[q];
+    u32 tiles = 0;
+    for (int i = threadIdx.x; i < m; i += 64) {
+        const u32 c = s_x[i] & 0xFFFu;
+        perm[c0 + i] = c;
+        const u32 subj = r[4 * (size_t)c], qi = r[4 * (size_t)c + 2];
+        tiles += cand_tiles(lq, roff[subj + 1] - roff[subj], qi);
+    }
+    for (int o = 32; o > 0; o >>= 1) tiles += __shfl_down(tiles, o);
+    if (threadIdx.x == 0) ntask[q] = (u32)m, ntile[q] = tiles;
 }
 
 __global__ __launch_bounds__(64) void k_csort(const u32* __restrict__ rec, const u32* __restrict__ qcoff, u32 nq, u32 vmax,
-                                              u32* __restrict__ perm, u32* __restrict__ ntask) {
+                                              const u32* __restrict__ qoff, const u32* __restrict__ roff, u32* __restrict__ perm,
+                                              u32* __restrict__ ntask, u32* __restrict__ ntile) {
     const u32 q = blockIdx.x * 64u + threadIdx.x;
     if (q >= nq) return;
     const u32 c0 = qcoff[q];
@@ -63,21 +80,46 @@ __global__ __launch_bounds__(64) void k_csort(const u32* __restrict__ rec, const
     for (int i = 0; i < n; ++i) x[i] = (u32)i;
     const u32* r = rec + 4 * (size_t)c0;
     ref_qsort_dev(x, n, [r](u32 i) { return -(i64)r[4 * (size_t)i + 1]; }, (int)vmax);
-    ntask[q] = (u32)n < vmax ? (u32)n : vmax;
+    const u32 m = (u32)n < vmax ? (u32)n : vmax;
+    const u32 lq = qoff[q + 1] - qoff[q];
+    u32 tiles = 0;
+    for (u32 i = 0; i < m; ++i) {
+        const u32 subj = r[4 * (size_t)x[i]], qi = r[4 * (size_t)x[i] + 2];
+        tiles += cand_tiles(lq, roff[subj + 1] - roff[subj], qi);
+    }
+    ntask[q] = m, ntile[q] = tiles;
 }
 
+// tasks of a query in rank order; rk_slot[roffc[q] + r] = first task slot (relative to toff[q]) of rank r
 __global__ __launch_bounds__(64) void k_mktasks(const u32* __restrict__ rec, const u32* __restrict__ qcoff, const u32* __restrict__ perm,
-                                                const u32* __restrict__ ntask, const u32* __restrict__ toff, u32 nq,
-                                                AlnTask* __restrict__ tasks) {
+                                                const u32* __restrict__ ntask, const u32* __restrict__ roffc, const u32* __restrict__ toff,
+                                                u32 nq, const u32* __restrict__ qoff, const u32* __restrict__ roff,
+                                                AlnTask* __restrict__ tasks, u32* __restrict__ rk_slot) {
     const u32 q = blockIdx.x * 64u + threadIdx.x;
     if (q >= nq) return;
-    const u32 c0 = qcoff[q], t0 = toff[q], nt = ntask[q];
+    const u32 c0 = qcoff[q], t0 = toff[q], nt = ntask[q], r0 = roffc[q];
+    const u32 lq = qoff[q + 1] - qoff[q];
+    u32 slot = 0;
     for (u32 k = 0; k < nt; ++k) {
         const u32 c = c0 + perm[c0 + k];
         AlnTask t;
         t.q = q, t.subj = rec[4 * (size_t)c], t.score = rec[4 * (size_t)c + 1], t.qi = rec[4 * (size_t)c + 2],
         t.qj = rec[4 * (size_t)c + 3], t.rank = k;
-        tasks[t0 + k] = t;
+        const u32 ls = roff[t.subj + 1] - roff[t.subj];
+        rk_slot[r0 + k] = slot;
+        if (lq < LONG_SEQ && ls < LONG_SEQ) {
+            t.qe = lq, t.se = ls;
+            tasks[t0 + slot++] = t;
+        } else {
+            // kswat_st_long (1480-1498): tile i over [qi + 4096 i, +4096) x [qj + 4096 i, +4096), each aligned from its corner
+            const u32 qi0 = t.qi, qj0 = t.qj;
+            for (u32 i = qi0, j = qj0; i < lq; i += LONG_SEQ, j += LONG_SEQ) {
+                t.qi = i, t.qe = min(lq, i + LONG_SEQ);
+                t.qj = min(j, ls), t.se = min(ls, j + LONG_SEQ);
+                if (j >= ls) t.qj = ls, t.se = ls;  // sqj[j:jed] is empty
+                tasks[t0 + slot++] = t;
+            }
+        }
     }
 }
 
@@ -87,39 +129,53 @@ __global__ __launch_bounds__(64) void k_mktasks(const u32* __restrict__ rec, con
 // device aligns that list in growing rounds: each round aligns the next B ranks of every query
 // that has not stopped, then k_stop_round replays the sequential rule over them.  Per-query state
 // st_state[5*q + {0 next rank, 1 unmch, 2 bv, 3 nsel, 4 done}].
-__global__ __launch_bounds__(256) void k_round_counts(const u32* __restrict__ ntask, const u32* __restrict__ st_state, u32 nq, u32 B,
-                                                      u32* __restrict__ rcnt) {
-    const u32 q = blockIdx.x * 256u + threadIdx.x;
-    if (q > nq) return;
-    u32 c = 0;
-    if (q < nq && !st_state[5 * (size_t)q + 4]) {
-        const u32 left = ntask[q] - st_state[5 * (size_t)q];
-        c = left < B ? left : B;
-    }
-    rcnt[q] = c;
+__device__ __forceinline__ u32 rank_slot(const u32* rk_slot, u32 r0, u32 r, u32 nt, u32 ntile_q) {
+    return r < nt ? rk_slot[r0 + r] : ntile_q;
 }
 
-__global__ __launch_bounds__(64) void k_round_idx(const u32* __restrict__ rcnt, const u32* __restrict__ roff, const u32* __restrict__ toff,
+// rcnt[q] = ranks aligned this round, tcnt[q] = their tasks
+__global__ __launch_bounds__(256) void k_round_counts(const u32* __restrict__ ntask, const u32* __restrict__ ntile,
+                                                      const u32* __restrict__ roffc, const u32* __restrict__ rk_slot,
+                                                      const u32* __restrict__ st_state, u32 nq, u32 B, u32* __restrict__ rcnt,
+                                                      u32* __restrict__ tcnt) {
+    const u32 q = blockIdx.x * 256u + threadIdx.x;
+    if (q > nq) return;
+    u32 c = 0, tc = 0;
+    if (q < nq && !st_state[5 * (size_t)q + 4]) {
+        const u32 nt = ntask[q], next = st_state[5 * (size_t)q];
+        const u32 left = nt - next;
+        c = left < B ? left : B;
+        tc = rank_slot(rk_slot, roffc[q], next + c, nt, ntile[q]) - rank_slot(rk_slot, roffc[q], next, nt, ntile[q]);
+    }
+    rcnt[q] = c;
+    tcnt[q] = tc;
+}
+
+__global__ __launch_bounds__(64) void k_round_idx(const u32* __restrict__ tcnt, const u32* __restrict__ troff, const u32* __restrict__ toff,
+                                                  const u32* __restrict__ ntask, const u32* __restrict__ ntile,
+                                                  const u32* __restrict__ roffc, const u32* __restrict__ rk_slot,
                                                   const u32* __restrict__ st_state, u32 nq, u32* __restrict__ ridx) {
     const u32 q = blockIdx.x;
-    const u32 n = rcnt[q];
+    const u32 n = tcnt[q];
     if (!n) return;
-    const u32 base = toff[q] + st_state[5 * (size_t)q], o = roff[q];
+    const u32 base = toff[q] + rank_slot(rk_slot, roffc[q], st_state[5 * (size_t)q], ntask[q], ntile[q]), o = troff[q];
     for (u32 k = threadIdx.x; k < n; k += 64) ridx[o + k] = base + k;
 }
 
 __global__ __launch_bounds__(64) void k_stop_round(const AlnTask* __restrict__ tasks, const AlnRes* __restrict__ res,
                                                    const u32* __restrict__ qcoff, const u32* __restrict__ ntask,
-                                                   const u32* __restrict__ toff, const u32* __restrict__ rcnt, u32 nq,
-                                                   const u32* __restrict__ qoff, const u32* __restrict__ roff,
-                                                   const int* __restrict__ bittab, int bittab_n, i64 D, double expect, double max_miss,
-                                                   i64 v, u32* __restrict__ sel, u32* __restrict__ st_state, int* __restrict__ bits) {
+                                                   const u32* __restrict__ ntile, const u32* __restrict__ roffc,
+                                                   const u32* __restrict__ rk_slot, const u32* __restrict__ toff,
+                                                   const u32* __restrict__ rcnt, u32 nq, const u32* __restrict__ qoff,
+                                                   const u32* __restrict__ roff, const int* __restrict__ bittab, int bittab_n, i64 D,
+                                                   double expect, double max_miss, i64 v, u32* __restrict__ sel,
+                                                   u32* __restrict__ st_state, int* __restrict__ bits) {
     const u32 q = blockIdx.x * 64u + threadIdx.x;
     if (q >= nq) return;
     const u32 nr = rcnt[q];
     if (!nr) return;
     u32* S = st_state + 5 * (size_t)q;
-    const u32 t0 = toff[q];
+    const u32 t0 = toff[q], r0 = roffc[q], nt = ntask[q], ntl = ntile[q];
     const u32 n = qcoff[q + 1] - qcoff[q];
     double mmiss = (double)n * max_miss + 1;
     const double inv = 100. / mmiss;
@@ -133,28 +189,32 @@ __global__ __launch_bounds__(64) void k_stop_round(const AlnTask* __restrict__ t
     bool done = false;
     const u32 rend = r + nr;
     for (; r < rend; ++r) {
-        const AlnTask tk = tasks[t0 + r];
-        const AlnRes a = res[t0 + r];
-        const i64 lj = (i64)(roff[tk.subj + 1] - roff[tk.subj]);
-        const int sc = a.maxscore < bittab_n ? a.maxscore : bittab_n - 1;
-        const int bit = bittab[sc];
-        bits[t0 + r] = bit;
-        const double p2 = bit > 1074 ? 0.0 : ldexp(1.0, -bit);
-        const double e = (double)(D * li * lj) * p2;  // bit2e (1086)
-        if (e <= expect) {
-            sel[t0 + nsel++] = r;
-            unmch = 0;
-            bv += 1;
-        } else {
-            unmch += 1;
+        const u32 s0 = rank_slot(rk_slot, r0, r, nt, ntl), s1 = rank_slot(rk_slot, r0, r + 1, nt, ntl);
+        bool hit = false;
+        for (u32 s = s0; s < s1; ++s) {  // one task, or the tiles of a long candidate (3085-3096)
+            const AlnTask tk = tasks[t0 + s];
+            const AlnRes a = res[t0 + s];
+            const i64 lj = (i64)(roff[tk.subj + 1] - roff[tk.subj]);
+            const int sc = a.maxscore < bittab_n ? a.maxscore : bittab_n - 1;
+            const int bit = bittab[sc];
+            bits[t0 + s] = bit;
+            const double p2 = bit > 1074 ? 0.0 : ldexp(1.0, -bit);
+            const double e = (double)(D * li * lj) * p2;  // bit2e (1086), full sequence lengths
+            if (e <= expect) {
+                sel[t0 + nsel++] = s;
+                hit = true;
+                bv += 1;
+            }
         }
+        if (hit) unmch = 0;
+        else unmch += 1;
         if ((double)unmch >= mmiss || (double)bv >= (double)v + mmiss) {
             done = true;
             ++r;
             break;
         }
     }
-    if (r >= ntask[q]) done = true;
+    if (r >= nt) done = true;
     S[0] = r, S[1] = (u32)unmch, S[2] = (u32)bv, S[3] = nsel, S[4] = done ? 1u : 0u;
 }
 
@@ -215,33 +275,39 @@ void launch_add_u32(u32* acc, const u32* x, u32 n, hipStream_t st) {
     hipLaunchKernelGGL(k_add_u32, dim3((n + 255) / 256), dim3(256), 0, st, acc, x, n);
 }
 
-void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, u32* perm, u32* ntask, hipStream_t st) {
+void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, const u32* qoff, const u32* roff, u32* perm, u32* ntask,
+                  u32* ntile, hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_csort_lds, dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, perm, ntask);
-    hipLaunchKernelGGL(k_csort, dim3((nq + 63) / 64), dim3(64), 0, st, rec, qcoff, nq, vmax, perm, ntask);
+    hipLaunchKernelGGL(k_csort_lds, dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile);
+    hipLaunchKernelGGL(k_csort, dim3((nq + 63) / 64), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile);
 }
 
-void launch_mktasks(const u32* rec, const u32* qcoff, const u32* perm, const u32* ntask, const u32* toff, u32 nq, AlnTask* tasks,
-                    hipStream_t st) {
+void launch_mktasks(const u32* rec, const u32* qcoff, const u32* perm, const u32* ntask, const u32* roffc, const u32* toff, u32 nq,
+                    const u32* qoff, const u32* roff, AlnTask* tasks, u32* rk_slot, hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_mktasks, dim3((nq + 63) / 64), dim3(64), 0, st, rec, qcoff, perm, ntask, toff, nq, tasks);
+    hipLaunchKernelGGL(k_mktasks, dim3((nq + 63) / 64), dim3(64), 0, st, rec, qcoff, perm, ntask, roffc, toff, nq, qoff, roff, tasks,
+                       rk_slot);
 }
 
-void launch_round_counts(const u32* ntask, const u32* st_state, u32 nq, u32 B, u32* rcnt, hipStream_t st) {
-    hipLaunchKernelGGL(k_round_counts, dim3((nq + 1 + 255) / 256), dim3(256), 0, st, ntask, st_state, nq, B, rcnt);
+void launch_round_counts(const u32* ntask, const u32* ntile, const u32* roffc, const u32* rk_slot, const u32* st_state, u32 nq, u32 B,
+                         u32* rcnt, u32* tcnt, hipStream_t st) {
+    hipLaunchKernelGGL(k_round_counts, dim3((nq + 1 + 255) / 256), dim3(256), 0, st, ntask, ntile, roffc, rk_slot, st_state, nq, B, rcnt,
+                       tcnt);
 }
 
-void launch_round_idx(const u32* rcnt, const u32* roff, const u32* toff, const u32* st_state, u32 nq, u32* ridx, hipStream_t st) {
+void launch_round_idx(const u32* tcnt, const u32* troff, const u32* toff, const u32* ntask, const u32* ntile, const u32* roffc,
+                      const u32* rk_slot, const u32* st_state, u32 nq, u32* ridx, hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_round_idx, dim3(nq), dim3(64), 0, st, rcnt, roff, toff, st_state, nq, ridx);
+    hipLaunchKernelGGL(k_round_idx, dim3(nq), dim3(64), 0, st, tcnt, troff, toff, ntask, ntile, roffc, rk_slot, st_state, nq, ridx);
 }
 
-void launch_stop_round(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* toff, const u32* rcnt,
-                       u32 nq, const u32* qoff, const u32* roff, const int* bittab, int bittab_n, i64 D, double expect,
-                       double max_miss, i64 v, u32* sel, u32* st_state, int* bits, hipStream_t st) {
+void launch_stop_round(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* ntile, const u32* roffc,
+                       const u32* rk_slot, const u32* toff, const u32* rcnt, u32 nq, const u32* qoff, const u32* roff,
+                       const int* bittab, int bittab_n, i64 D, double expect, double max_miss, i64 v, u32* sel, u32* st_state, int* bits,
+                       hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_stop_round, dim3((nq + 63) / 64), dim3(64), 0, st, tasks, res, qcoff, ntask, toff, rcnt, nq, qoff, roff, bittab,
-                       bittab_n, D, expect, max_miss, v, sel, st_state, bits);
+    hipLaunchKernelGGL(k_stop_round, dim3((nq + 63) / 64), dim3(64), 0, st, tasks, res, qcoff, ntask, ntile, roffc, rk_slot, toff, rcnt,
+                       nq, qoff, roff, bittab, bittab_n, D, expect, max_miss, v, sel, st_state, bits);
 }
 
 void launch_final_select(const u32* toff, u32 nq, i64 v, u32* sel, const u32* st_state, const int* bits, u32* nout, hipStream_t st) {

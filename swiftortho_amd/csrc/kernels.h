@@ -73,14 +73,18 @@ void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q
 void launch_gather_cands(const u32* src_q, const u32* src_rec, u32 n, const u32* cqoff, const u32* prior, const u32* qcoff,
                          u32* dst_rec, hipStream_t st);
 void launch_add_u32(u32* acc, const u32* x, u32 n, hipStream_t st);
-void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, u32* perm, u32* ntask, hipStream_t st);
-void launch_mktasks(const u32* rec, const u32* qcoff, const u32* perm, const u32* ntask, const u32* toff, u32 nq, AlnTask* tasks,
-                    hipStream_t st);
-void launch_round_counts(const u32* ntask, const u32* st_state, u32 nq, u32 B, u32* rcnt, hipStream_t st);
-void launch_round_idx(const u32* rcnt, const u32* roff, const u32* toff, const u32* st_state, u32 nq, u32* ridx, hipStream_t st);
-void launch_stop_round(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* toff, const u32* rcnt,
-                       u32 nq, const u32* qoff, const u32* roff, const int* bittab, int bittab_n, i64 D, double expect,
-                       double max_miss, i64 v, u32* sel, u32* st_state, int* bits, hipStream_t st);
+void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, const u32* qoff, const u32* roff, u32* perm, u32* ntask,
+                  u32* ntile, hipStream_t st);
+void launch_mktasks(const u32* rec, const u32* qcoff, const u32* perm, const u32* ntask, const u32* roffc, const u32* toff, u32 nq,
+                    const u32* qoff, const u32* roff, AlnTask* tasks, u32* rk_slot, hipStream_t st);
+void launch_round_counts(const u32* ntask, const u32* ntile, const u32* roffc, const u32* rk_slot, const u32* st_state, u32 nq, u32 B,
+                         u32* rcnt, u32* tcnt, hipStream_t st);
+void launch_round_idx(const u32* tcnt, const u32* troff, const u32* toff, const u32* ntask, const u32* ntile, const u32* roffc,
+                      const u32* rk_slot, const u32* st_state, u32 nq, u32* ridx, hipStream_t st);
+void launch_stop_round(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* ntile, const u32* roffc,
+                       const u32* rk_slot, const u32* toff, const u32* rcnt, u32 nq, const u32* qoff, const u32* roff,
+                       const int* bittab, int bittab_n, i64 D, double expect, double max_miss, i64 v, u32* sel, u32* st_state, int* bits,
+                       hipStream_t st);
 void launch_final_select(const u32* toff, u32 nq, i64 v, u32* sel, const u32* st_state, const int* bits, u32* nout, hipStream_t st);
 void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, const u32* sel, const u32* nout, const u32* ooff,
                       const int* bits, u32 nq, int* out, hipStream_t st);

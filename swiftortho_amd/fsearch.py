@@ -194,8 +194,8 @@ def blastp(qry, ref, expect=1e-5, v=500, max_miss=1e-3, st=-1, ed=-1, rst=-1, re
         s.close()
 
 
-def manual_print(out=sys.stdout):
-    w = out.write
+def manual_print(out=None):
+    w = (out or sys.stdout).write
     w("Usage:\n  fsearch -p blastp -i qry.fsa -d db.fsa\nParameters:\n")
     for line in ("-p: program", "-i: query sequences in fasta format", "-l: start index of query sequences",
                  "-u: end index of query sequences", "-L: start index of reference", "-U: end index of reference",

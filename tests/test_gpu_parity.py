@@ -172,6 +172,31 @@ def test_multiseed_two_alphabets_vs_oracle(fs, oracle, tmp_path):
     oracle_vs_gpu(fs, oracle, synthprot.synthprot(900, 150, 81), kw, tmp_path)
 
 
+def test_long_sequences_self_search_vs_oracle(fs, oracle, tmp_path):
+    """>= 4096-aa proteins in a self-search: tiled long path (kswat_st_long) for long queries and
+    long subjects, including tiles that run past a shorter subject (undefined in the reference,
+    defined here and in the oracle as "no hit from that tile")."""
+    from swiftortho_amd import synthprot
+    rng = np.random.default_rng(5)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+
+    def rnd(n):
+        return aa[rng.integers(0, 20, n)].tobytes().decode()
+
+    def mut(s, d):
+        b = np.frombuffer(s.encode(), dtype=np.uint8).copy()
+        m = rng.random(len(b)) < d
+        b[m] = aa[rng.integers(0, 20, int(m.sum()))]
+        return b.tobytes().decode()
+
+    A, B = rnd(9500), rnd(4300)
+    recs = [("L0", A), ("L1", mut(A[:6200], 0.15)), ("L2", mut(A[2500:7000], 0.3)), ("L3", B), ("L4", mut(B, 0.2) + rnd(300)),
+            ("S0", mut(A[100:420], 0.1)), ("S1", mut(A[5000:5350], 0.2)), ("S2", mut(A[9000:9490], 0.1)), ("S3", mut(B[3900:4290], 0.1))]
+    fa = "".join(">%s\n%s\n" % r for r in recs).encode() + synthprot.synthprot(300, 250, 46)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+
+
 def test_query_subrange_and_small_batches(fs, oracle, tmp_path, monkeypatch):
     """-l/-u sub-range, processed in several device batches: rows must not depend on batching."""
     from swiftortho_amd import synthprot

@@ -1,0 +1,112 @@
+"""CPU-only tests of the Python host layer: flag grammar, find_hit defaults/blocking, synthetic
+proteome determinism, query sharding, and the 2-rank gloo gather (the N > 1 path)."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_fsearch_flag_grammar():
+    from swiftortho_amd import fsearch
+    a = fsearch.parse_flags(["fsearch", "-p", "blastp", "-i", "q.fa", "-dref.fa", "-e1e-5", "bogus", "-v", "10", "--x"], fsearch.DEFAULTS)
+    assert a["-p"] == "blastp" and a["-i"] == "q.fa" and a["-d"] == "ref.fa" and a["-e"] == "1e-5" and a["-v"] == "10"
+    assert a["-j"] == "4" and a["-M"] == "-1" and a["-c"] == "50000"      # fsearch-c defaults (fsearch.py:3187-3188)
+    # a trailing flag without a value keeps its default (the reference would raise IndexError there)
+    assert fsearch.parse_flags(["x", "-v"], fsearch.DEFAULTS)["-v"] == "500"
+
+
+def test_entry_point_prints_manual_and_returns_zero(capsys):
+    from swiftortho_amd import fsearch
+    assert fsearch.entry_point(["fsearch"]) == 0
+    assert "Usage" in capsys.readouterr().out
+    assert fsearch.entry_point(["fsearch", "-p", "blastp", "-i", "x"]) == 0      # -d missing
+    assert fsearch.entry_point(["fsearch", "-p", "blastp", "-i", "x", "-d", "y", "-v", "abc"]) == 0   # bad int -> manual
+
+
+def test_find_hit_defaults_and_chunk_rule():
+    from swiftortho_amd import find_hit
+    a = find_hit.parse(["find_hit.py", "-p", "blastp", "-i", "q", "-d", "r", "-o", "out", "-r", "aa20", "-a", "4"])
+    p = find_hit.resolve(a)
+    assert p["ssd"] == "11111111" and p["ht"] == 120000000 and p["step"] == 1 and p["bv"] == 500 and p["exp"] == 1e-3
+    assert p["nr"] == find_hit.AA20 and p["chk"] == 50000 and p["ngpu"] == 4
+    two = find_hit.resolve(find_hit.parse(["x", "-p", "blastp", "-i", "q", "-d", "r", "-r", find_hit.AA9 + "/" + find_hit.AA20]))
+    assert two["chk"] == 25000                                  # chk = int(-c / number of alphabets), find_hit.py:273-274
+    assert find_hit.resolve(find_hit.parse(["x", "-p", "makedb", "-i", "q"])) is None
+    assert find_hit.resolve(find_hit.parse(["x", "-p", "blastp", "-i", "q"])) is None
+    assert find_hit.resolve(find_hit.parse(["x", "-p", "blastp", "-i", "q", "-d", "r", "-e", "zz"])) is None
+
+
+def test_find_hit_cli_manual_exit():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "find_hit.py")], capture_output=True, text=True)
+    assert "Usage" in r.stdout and r.returncode == 0
+
+
+def test_synthprot_is_deterministic():
+    from swiftortho_amd import synthprot
+    a, b = synthprot.synthprot(300, 200, 9), synthprot.synthprot(300, 200, 9)
+    assert a == b and a.count(b">") == 300
+    assert hashlib.md5(synthprot.synthprot(10000, 300)).hexdigest() == "311b5d33882ea0ded2a82dd88084bf4d"
+    u = synthprot.uniform_proteins(50, 100, 1)
+    assert u.count(b">") == 50 and all(len(l) == 100 for l in u.split(b"\n")[1::2])
+
+
+def test_shard_queries_balanced_contiguous():
+    from swiftortho_amd.dist import shard_queries
+    rng = np.random.default_rng(0)
+    lens = rng.integers(50, 2000, 1000)
+    for world in (1, 2, 3, 8):
+        sh = shard_queries(lens, world)
+        assert sh[0][0] == 0 and sh[-1][1] == 1000
+        assert all(sh[i][1] == sh[i + 1][0] for i in range(world - 1))
+        tot = [int(lens[a:b].sum()) for a, b in sh]
+        assert max(tot) - min(tot) <= 2 * 2000
+    assert shard_queries(lens, 4, 100, 200)[0][0] == 100 and shard_queries(lens, 4, 100, 200)[-1][1] == 200
+    assert shard_queries([], 3) == [(0, 0)] * 3
+    assert shard_queries([5], 4)[-1][1] == 1
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch.distributed as dist
+from swiftortho_amd import dist as sdist
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+lens = np.arange(1, 101)
+lo, hi = sdist.shard_queries(lens, world)[rank]
+# fake 80-byte hit records: one per query of the shard, tagged with the query ordinal
+recs = np.zeros((hi - lo, 10), dtype=np.int64); recs[:, 0] = np.arange(lo, hi)
+if rank == 1: recs = recs[:0] if os.environ.get("EMPTY1") else recs
+parts = sdist.gather_bytes(recs.tobytes())
+if rank == 0:
+    allr = np.frombuffer(b"".join(parts), dtype=np.int64).reshape(-1, 10)
+    print("GATHERED", len(allr), int(allr[:, 0].sum()), bool(np.all(np.diff(allr[:, 0]) > 0)))
+else:
+    assert parts is None
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("empty1", [False, True])
+def test_two_rank_gloo_gather(tmp_path, empty1):
+    """world_size-2 run of the sharding + gatherv used by bench.py / find_hit.py -a N (gloo on CPU)."""
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300 + (7 if empty1 else 0)), WORLD_SIZE="2")
+    if empty1:
+        env["EMPTY1"] = "1"
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = [l for l in outs[0][0].splitlines() if l.startswith("GATHERED")][0].split()
+    if empty1:
+        lo1 = None
+        assert line[3] == "True" and int(line[1]) < 100
+    else:
+        assert line[1:] == ["100", str(sum(range(100))), "True"]

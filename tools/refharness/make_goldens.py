@@ -51,6 +51,47 @@ def messy_fasta(rng):
 FORCE = "--force" in sys.argv
 
 
+def long_sets():
+    """Sequences >= 4096 aa (kswat_st_long tiles, fsearch.py:1480-1498, 3083-3101).
+
+    The reference is only defined when every tile of a candidate still starts inside the subject:
+    a long query whose later tiles run past a shorter subject indexes an empty string
+    (IndexError under CPython, out-of-bounds read in the RPython build).  So:
+      set A: queries < 4096 aa against long subjects (one 4096-wide tile per candidate);
+      set B: long queries against equally long subjects only (three tiles each, all in range)."""
+    rng = np.random.default_rng(44)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+
+    def rnd(n):
+        return "".join(aa[i] for i in rng.integers(0, 20, n))
+
+    def mut(s, d, indels=True):
+        s = list(s)
+        for p in range(len(s)):
+            if rng.random() < d:
+                s[p] = aa[int(rng.integers(0, 20))]
+        if indels:
+            for _ in range(max(1, len(s) // 400)):
+                p = int(rng.integers(10, len(s) - 10))
+                if rng.random() < 0.5:
+                    del s[p:p + int(rng.integers(1, 6))]
+                else:
+                    s[p:p] = list(rnd(int(rng.integers(1, 6))))
+        return "".join(s)
+
+    A = rnd(9000)
+    L3 = rnd(4100)
+    base = synthprot.synthprot(12, 250, 45).decode().split("\n")
+    normal = [(base[i][1:], base[i + 1]) for i in range(0, len(base) - 1, 2)]
+    refA = [("L0|giant", A), ("L1|first6000", mut(A[:6000], 0.15)), ("L2|mid4600", mut(A[2000:6600], 0.25)), ("L3|other4100", L3)] + normal
+    qryA = [("S0|frag_a", mut(A[100:420], 0.1)), ("S1|frag_b", mut(A[5000:5350], 0.2)), ("S2|frag_c", mut(A[8600:8990], 0.1)),
+            ("S3|frag_of_L3", mut(L3[3700:4090], 0.1)), ("S4|frag_d", mut(A[4000:4300], 0.05))] + normal[:4]
+    refB = [("L0|giant", A), ("L0m|giant_mut", mut(A, 0.2)), ("L0n|giant_mut2", mut(A, 0.35))]
+    qryB = [("L0|giant", A), ("L0q|giant_mut3", mut(A, 0.1))]
+    f = lambda recs: "".join(">%s\n%s\n" % r for r in recs).encode()
+    return f(refA), f(qryA), f(refB), f(qryB)
+
+
 def run_e2e(m, name, fasta, flags, qry=None):
     if os.path.isfile(os.path.join(GOLD, name + ".sc")) and not FORCE:
         print(name, "exists, skipped")
@@ -201,6 +242,10 @@ def main():
     run_e2e(m, "toy_uniform", synthprot.uniform_proteins(60, 150, 8), base + ["-s", "111111", "-r", AA9, "-M", "5003", "-c", "50000"])
     run_e2e(m, "toy_messy", messy_fasta(rng), ["-e", "1e-3", "-v", "5", "-j", "1", "-F", "T", "-s", "111111", "-r", AA9, "-M", "1000003", "-c", "10"])
     run_e2e(m, "toy_w10", synthprot.synthprot(70, 200, 12), base + ["-s", "11111011111", "-r", AA9, "-M", "120000000", "-c", "50000"])
+    refA, qryA, refB, qryB = long_sets()
+    lf = ["-e", "1e-5", "-v", "500", "-j", "1", "-F", "T", "-s", "111111", "-r", AA9, "-M", "1000003", "-c", "50000"]
+    run_e2e(m, "toy_long_subject", refA, lf, qry=qryA)
+    run_e2e(m, "toy_long_both", refB, lf, qry=qryB)
     run_e2e(m, "toy_aa20", synthprot.synthprot(80, 100, 4), base + ["-s", "1111111", "-r", AA20, "-M", "50021", "-c", "50000"])
     qry = open(os.path.join(refload.REFERENCE, "example", "qry.fsa"), "rb").read()
     # config 1 (example/run.sh plumbing): the shipped ref.fsa is absent -> stand-in reference with the
