@@ -547,7 +547,8 @@ struct Batch {
     DevBuf<u32> qbucket, korder, sbeg, scnt, pcnt, eff, nz, hoff, cidx;
     DevBuf<int> ksc;
     DevBuf<u8> mark;
-    DevBuf<u32> cs_hoff, cs_beg, cs_q, cs_qa, blk_first;
+    DevBuf<u32> cs_hoff, cs_beg, blk_first;
+    DevBuf<u64> cs_kbase;
     DevBuf<u64> keys, keys2;
     DevBuf<u32> flags, gidx, ghead;
     DevBuf<u64> p_qs, p_sd, p_ft, p_qs2, tmp64, q_qs, q_sd, q_ft;
@@ -708,15 +709,15 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     const int ft_bits_entry = (kl.bs + 1) + kl.ba + bsp;
     if (kl.total > 64) throw SoError("sort key needs " + std::to_string(kl.total) + " bits (> 64): lower SOHIT_BATCH or -c");
     if (kl.ba + kl.bp + ft_bits_entry > 64) throw SoError("first-touch key exceeds 64 bits: sequences too long for this build");
-    b.cs_hoff.ensure((size_t)K + 2), b.cs_beg.ensure((size_t)K + 2), b.cs_q.ensure((size_t)K + 2), b.cs_qa.ensure((size_t)K + 2);
-    launch_compact_seeds(b.eff.p, b.hoff.p, b.cidx.p, b.sbeg.p, b.dev.d_pseq.p, b.dev.d_off.p, Ppad, AS, b.cs_hoff.p, b.cs_beg.p,
-                         b.cs_q.p, b.cs_qa.p, c->st);
+    b.cs_hoff.ensure((size_t)K + 2), b.cs_beg.ensure((size_t)K + 2), b.cs_kbase.ensure((size_t)K + 2);
+    launch_compact_seeds(b.eff.p, b.hoff.p, b.cidx.p, b.sbeg.p, b.dev.d_pseq.p, b.dev.d_off.p, Ppad, AS, kl, b.cs_hoff.p, b.cs_beg.p,
+                         b.cs_kbase.p, c->st);
     b.blk_first.ensure((size_t)lookup_num_blocks(H) + 2);
     launch_lookup_blockfirst(b.cs_hoff.p, K, H, b.blk_first.p, c->st);
     b.keys.ensure((size_t)H + 2), b.keys2.ensure((size_t)H + 2);
     {
         ProfTimer pt(c, &c->cnt.lookup_ms, &c->cnt.lookup_launches);
-        launch_lookup(b.cs_hoff.p, b.cs_beg.p, b.cs_q.p, b.cs_qa.p, b.blk_first.p, K, H, ch.entries.p, c->ref.d_off.p + ch.seq_lo, kl,
+        launch_lookup(b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, b.blk_first.p, K, H, ch.entries.p, c->ref.d_off.p + ch.seq_lo, kl,
                       b.keys.p, c->st);
         pt.stop();
         if (c->profile) c->cnt.lookup_bytes += (i64)8 * (i64)H;
@@ -860,7 +861,7 @@ void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
     HIP_CHECK(hipMemsetAsync(b.ares.p, 0, ((size_t)NT + 4) * sizeof(AlnRes), c->st));  // unaligned slots count 0 cells
     launch_mktasks(b.fin_rec.p, b.qcoff.p, b.perm.p, b.ntask.p, b.roffc.p, b.toff.p, nq, b.dev.d_off.p, c->ref.d_off.p, b.tasks.p,
                    b.rk_slot.p, c->st);
-    // banded alignments in rounds (see k_stop_round): 64, 128, 256, ... ranks per query and round
+    // banded alignments in rounds (see k_round_counts / k_stop_round)
     const u32 maxwin_q = std::min<u32>(b.maxqlen, LONG_SEQ), maxwin_s = std::min<u32>(c->ref.maxlen, LONG_SEQ);
     const int maxrows = (int)std::min<u32>(std::max(maxwin_q, maxwin_s), std::min(maxwin_q, maxwin_s) + 16);
     const u32 stride = align_trace_stride(maxrows + 1);
@@ -872,8 +873,9 @@ void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
     HIP_CHECK(hipMemsetAsync(b.st_state.p, 0, (5 * (size_t)nq + 8) * sizeof(u32), c->st));
     sc.lap("phase2.mktasks");
     u32 aligned_total = 0;
-    for (u32 B = 64;; B = B < (1u << 20) ? B * 2 : B) {
-        launch_round_counts(b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.st_state.p, nq, B, b.rcnt.p, b.tcnt.p, c->st);
+    for (u32 minr = 8;; minr = minr < 256 ? minr * 2 : minr) {
+        launch_round_counts(b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.qcoff.p, b.st_state.p, nq, c->max_miss, minr, b.rcnt.p,
+                            b.tcnt.p, c->st);
         const u32* dNR = scan_u32(b.tcnt.p, b.roff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
         const u32 NR = d2h_u32(c, dNR);
         // ranks left this round (a round may hold ranks with zero tiles only)

@@ -39,7 +39,7 @@ struct UG {
     int max_score, max_qst, max_qed, max_sst, max_sed;
 };
 
-#define B62_LD 32  // LDS score table is 32 x 32 so that any 5-bit class pair indexes inside it
+#define B62_LD 36  // LDS score table: 32 rows of 36 bytes (9 dwords: rows rotate through all 32 banks); any 5-bit class pair indexes inside it
 
 __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global load
     u64 w;
@@ -122,10 +122,10 @@ __global__ __launch_bounds__(256) void k_ungap(const u64* __restrict__ keys, con
                                                const signed char* __restrict__ b62g, u32* __restrict__ shard_cnt /*[UG_SHARDS]*/,
                                                u32 shard_cap, u64* __restrict__ p_qs, u64* __restrict__ p_sd, u64* __restrict__ p_ft,
                                                unsigned long long* __restrict__ step_shards /*[UG_SHARDS]*/) {
-    __shared__ signed char s_b62[B62_LD * B62_LD];
+    __shared__ signed char s_b62[32 * B62_LD];
     __shared__ u32 s_wcnt[4];
     __shared__ u32 s_base;
-    for (int i = threadIdx.x; i < B62_LD * B62_LD; i += 256) {
+    for (int i = threadIdx.x; i < 32 * B62_LD; i += 256) {
         const int a = i / B62_LD, b = i % B62_LD;
         s_b62[i] = (a < SCLS_N && b < SCLS_N) ? b62g[a * SCLS_N + b] : (signed char)-4;
     }

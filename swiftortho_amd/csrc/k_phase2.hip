@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_add_u32(u32* __restrict__ acc, const u3
 
 // qsort(hits, key=-score) (3051) per query + number of alignment tasks min(n, vmax) (3059, 3062).
 // One wave per query: the candidates' (inverted score << 12 | index) words are staged in LDS and
-// lane 0 replays the reference quicksort there (LDS latency instead of HBM latency per compare);
+// the wave replays the reference quicksort there (wave_ref_qsort: exact wave-parallel partitions);
 // only ranges that reach into the first vmax positions are sorted.  Queries with more than
 // LDS_SORT_MAX candidates take the global-memory kernel below.
 #define LDS_SORT_MAX 4096
@@ -42,6 +42,8 @@ __global__ __launch_bounds__(64) void k_csort_lds(const u32* __restrict__ rec, c
                                                   const u32* __restrict__ qoff, const u32* __restrict__ roff, u32* __restrict__ perm,
                                                   u32* __restrict__ ntask, u32* __restrict__ ntile) {
     __shared__ u32 s_x[LDS_SORT_MAX];
+    __shared__ u16 s_L[LDS_SORT_MAX], s_R[LDS_SORT_MAX];
+    __shared__ int s_leaf[2 * WQS_LEAF];
     const u32 q = blockIdx.x;
     const u32 c0 = qcoff[q];
     const int n = (int)(qcoff[q + 1] - c0);
@@ -53,8 +55,7 @@ __global__ __launch_bounds__(64) void k_csort_lds(const u32* __restrict__ rec, c
         s_x[i] = ((SCORE_CAP - sc) << 12) | (u32)i;
     }
     __syncthreads();
-    if (threadIdx.x == 0) ref_qsort_dev(s_x, n, [](u32 v) { return (int)(v >> 12); }, (int)vmax);
-    __syncthreads();
+    wave_ref_qsort(s_x, n, [](u32 v) { return (int)(v >> 12); }, (int)vmax, s_L, s_R, s_leaf);
     const int m = n < (int)vmax ? n : (int)vmax;
     const u32 lq = qoff[q + 1] - qoff[q];
     u32 tiles = 0;
@@ -133,18 +134,30 @@ __device__ __forceinline__ u32 rank_slot(const u32* rk_slot, u32 r0, u32 r, u32 
     return r < nt ? rk_slot[r0 + r] : ntile_q;
 }
 
-// rcnt[q] = ranks aligned this round, tcnt[q] = their tasks
+// rcnt[q] = ranks aligned this round, tcnt[q] = their tasks.  A query can only stop once `unmch`
+// reaches ceil(mmiss), so a round aligns exactly the ranks that are needed before the rule could
+// fire if they all miss (at least minr, to bound the number of rounds): the device then aligns
+// almost exactly the prefix the reference's sequential loop aligns.
 __global__ __launch_bounds__(256) void k_round_counts(const u32* __restrict__ ntask, const u32* __restrict__ ntile,
                                                       const u32* __restrict__ roffc, const u32* __restrict__ rk_slot,
-                                                      const u32* __restrict__ st_state, u32 nq, u32 B, u32* __restrict__ rcnt,
-                                                      u32* __restrict__ tcnt) {
+                                                      const u32* __restrict__ qcoff, const u32* __restrict__ st_state, u32 nq,
+                                                      double max_miss, u32 minr, u32* __restrict__ rcnt, u32* __restrict__ tcnt) {
     const u32 q = blockIdx.x * 256u + threadIdx.x;
     if (q > nq) return;
     u32 c = 0, tc = 0;
     if (q < nq && !st_state[5 * (size_t)q + 4]) {
-        const u32 nt = ntask[q], next = st_state[5 * (size_t)q];
+        const u32 nt = ntask[q], next = st_state[5 * (size_t)q], unmch = st_state[5 * (size_t)q + 1];
         const u32 left = nt - next;
-        c = left < B ? left : B;
+        const u32 n = qcoff[q + 1] - qcoff[q];
+        double mmiss = (double)n * max_miss + 1;
+        const double inv = 100. / mmiss;
+        mmiss = mmiss > inv ? mmiss : inv;
+        mmiss = mmiss > 10. ? mmiss : 10.;
+        mmiss = mmiss < 120. ? mmiss : 120.;
+        const u32 cm = (u32)ceil(mmiss);
+        u32 need = cm > unmch ? cm - unmch : 1u;
+        need = need < minr ? minr : need;
+        c = left < need ? left : need;
         tc = rank_slot(rk_slot, roffc[q], next + c, nt, ntile[q]) - rank_slot(rk_slot, roffc[q], next, nt, ntile[q]);
     }
     rcnt[q] = c;
@@ -289,10 +302,10 @@ void launch_mktasks(const u32* rec, const u32* qcoff, const u32* perm, const u32
                        rk_slot);
 }
 
-void launch_round_counts(const u32* ntask, const u32* ntile, const u32* roffc, const u32* rk_slot, const u32* st_state, u32 nq, u32 B,
-                         u32* rcnt, u32* tcnt, hipStream_t st) {
-    hipLaunchKernelGGL(k_round_counts, dim3((nq + 1 + 255) / 256), dim3(256), 0, st, ntask, ntile, roffc, rk_slot, st_state, nq, B, rcnt,
-                       tcnt);
+void launch_round_counts(const u32* ntask, const u32* ntile, const u32* roffc, const u32* rk_slot, const u32* qcoff,
+                         const u32* st_state, u32 nq, double max_miss, u32 minr, u32* rcnt, u32* tcnt, hipStream_t st) {
+    hipLaunchKernelGGL(k_round_counts, dim3((nq + 1 + 255) / 256), dim3(256), 0, st, ntask, ntile, roffc, rk_slot, qcoff, st_state, nq,
+                       max_miss, minr, rcnt, tcnt);
 }
 
 void launch_round_idx(const u32* tcnt, const u32* troff, const u32* toff, const u32* ntask, const u32* ntile, const u32* roffc,

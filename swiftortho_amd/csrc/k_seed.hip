@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_bounds(const u32* __restrict__ qbucket,
 // ---- k-mer self-score order (fsearch.py:2647-2656, 2660, 2668) -----------------------------------
 // kscs over the shortest seed span on the MASKED query, then the reference quicksort of positions
 // by -ksc.  korder[qoff[q] + r] = r-th position.  One wave per query with the
-// ((KSC_BIAS - ksc) << 12 | position) words in LDS and lane 0 replaying the reference quicksort;
+// ((KSC_BIAS - ksc) << 12 | position) words in LDS and the wave replaying the reference quicksort;
 // queries longer than LDS_SORT_MAX windows take the one-thread-per-query global-memory kernel.
 #define LDS_SORT_MAX 4096
 #define KSC_BIAS (1 << 18)
@@ -64,6 +64,8 @@ __global__ __launch_bounds__(64) void k_ksc_order_lds(const u8* __restrict__ q_s
                                                       const signed char* __restrict__ b62c, u32* __restrict__ korder) {
     __shared__ signed char s_self[SCLS_N];
     __shared__ u32 s_x[LDS_SORT_MAX];
+    __shared__ u16 s_L[LDS_SORT_MAX], s_R[LDS_SORT_MAX];
+    __shared__ int s_leaf[2 * WQS_LEAF];
     if (threadIdx.x < SCLS_N) s_self[threadIdx.x] = b62c[threadIdx.x * SCLS_N + threadIdx.x];
     __syncthreads();
     const u32 q = blockIdx.x;
@@ -78,8 +80,7 @@ __global__ __launch_bounds__(64) void k_ksc_order_lds(const u8* __restrict__ q_s
         s_x[i] = ((u32)(KSC_BIAS - sc) << 12) | (u32)i;
     }
     __syncthreads();
-    if (threadIdx.x == 0) ref_qsort_dev(s_x, nk, [](u32 v) { return (int)(v >> 12); });
-    __syncthreads();
+    wave_ref_qsort(s_x, nk, [](u32 v) { return (int)(v >> 12); }, 0x7fffffff, s_L, s_R, s_leaf);
     for (int i = threadIdx.x; i < nk; i += 64) korder[base + i] = s_x[i] & 0xFFFu;
 }
 
@@ -141,109 +142,175 @@ __global__ __launch_bounds__(256) void k_effcnt(const u8* __restrict__ mark, con
     nz[t] = c ? 1u : 0u;
 }
 
-// cs_*[k] for the k-th non-empty seed: first hit ordinal, first slot, query, (as << 24) | qpos
+// cs_*[k] for the k-th non-empty seed: first hit ordinal, first slot, and the key bits that do not
+// depend on the index entry: q, qpos, as and (qpos + diag_off) in the diagonal field, so that per
+// hit   key = kbase + (subject << sh_subj) - (sst << sh_diag) + tag.
 __global__ __launch_bounds__(256) void k_compact_seeds(const u32* __restrict__ eff, const u32* __restrict__ hoff,
                                                        const u32* __restrict__ cidx, const u32* __restrict__ sbeg,
                                                        const u32* __restrict__ q_pseq, const u32* __restrict__ qoff, u32 Ppad, int AS,
-                                                       u32* __restrict__ cs_hoff, u32* __restrict__ cs_beg, u32* __restrict__ cs_q,
-                                                       u32* __restrict__ cs_qa) {
+                                                       KeyLayout kl, u32* __restrict__ cs_hoff, u32* __restrict__ cs_beg,
+                                                       u64* __restrict__ cs_kbase) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= (size_t)AS * Ppad) return;
     if (!eff[t]) return;
     const u32 as = (u32)(t / Ppad), p = (u32)(t % Ppad);
     const u32 k = cidx[t];
     const u32 q = q_pseq[p];
+    const u32 qpos = p - (qoff[q] + q);
     cs_hoff[k] = hoff[t];
     cs_beg[k] = sbeg[t];
-    cs_q[k] = q;
-    cs_qa[k] = (as << 24) | (p - (qoff[q] + q));
+    cs_kbase[k] = ((u64)q << kl.sh_q) | ((u64)((i64)qpos + kl.diag_off) << kl.sh_diag) | ((u64)qpos << kl.sh_qpos) | ((u64)as << kl.sh_as);
 }
 
-// first compacted seed of every lookup block: largest k with cs_hoff[k] <= blk * LK_HITS
-#define LK_THREADS 256
-#define LK_PER_THREAD 8
-#define LK_HITS (LK_THREADS * LK_PER_THREAD)
+// ---- the seed-lookup kernel ------------------------------------------------------------------------
+// Hit h (0 <= h < H) is slot cs_beg[k] + (h - cs_hoff[k]) of the compacted seed k that owns it.
+// Work unit = one WAVE: LW_HITS consecutive hit ordinals, no block-level barrier anywhere.  The
+// wave stages the first LW_SEEDS seeds that cover its range in LDS (further ones -- tiny buckets --
+// are read from global), builds an owner map (start marks + wave prefix-max) and then walks 64
+// consecutive ordinals per step: lanes read consecutive index slots (coalesced 8-byte entries, all
+// LW_ITERS loads of a lane in flight before the first use) and write consecutive 8-byte keys.
+// Subject resolution follows the reference's strict `soas[j] < x` rule: an entry at offset 0 of chunk
+// sequence j belongs to the previous non-empty sequence at sst = its length; at the chunk start it
+// resolves to index -1, can never score, and is dropped (key = ~0).
+#define LW_ITERS 8
+#define LW_HITS (64 * LW_ITERS)
+#define LW_SEEDS 256
+#define LW_WAVES 4
 
-__global__ __launch_bounds__(256) void k_lookup_blockfirst(const u32* __restrict__ cs_hoff, u32 K, u32 H, u32 nblk,
-                                                           u32* __restrict__ blk_first) {
+// first compacted seed of every lookup wave: largest k with cs_hoff[k] <= wave * LW_HITS
+__global__ __launch_bounds__(256) void k_lookup_blockfirst(const u32* __restrict__ cs_hoff, u32 K, u32 H, u32 nw,
+                                                           u32* __restrict__ wave_first) {
     const u32 b = blockIdx.x * 256u + threadIdx.x;
-    if (b > nblk) return;
-    if (b == nblk) {
-        blk_first[b] = K;
+    if (b > nw) return;
+    if (b == nw) {
+        wave_first[b] = K;
         return;
     }
-    const u32 h = b * LK_HITS;
+    const u32 h = b * LW_HITS;
     u32 lo = 0, hi = K;  // cs_hoff[0] == 0 <= h
     while (hi - lo > 1) {
         u32 m = (lo + hi) >> 1;
         if (cs_hoff[m] <= h) lo = m;
         else hi = m;
     }
-    blk_first[b] = lo;
+    wave_first[b] = lo;
 }
 
-// ---- the seed-lookup kernel ------------------------------------------------------------------------
-// Hit h (0 <= h < H) is slot cs_beg[k] + (h - cs_hoff[k]) of the compacted seed k that owns it.
-// Each block owns LK_HITS consecutive hit ordinals, stages the (<= LK_HITS + 1) seeds that cover
-// them in LDS, and each wave walks 64 consecutive hits per step: lanes read consecutive index
-// slots (coalesced 8-byte entries) and write consecutive 8-byte keys.
-// Per hit: subject resolution with the reference's strict `soas[j] < x` rule (an entry at offset 0
-// of chunk sequence j >= 1 belongs to sequence j-1 at sst = len(j-1); offset 0 of the chunk's
-// first sequence resolves to index -1 and can never score -> dropped, key = ~0).
-__global__ __launch_bounds__(LK_THREADS) void k_lookup(const u32* __restrict__ cs_hoff, const u32* __restrict__ cs_beg,
-                                                       const u32* __restrict__ cs_q, const u32* __restrict__ cs_qa,
-                                                       const u32* __restrict__ blk_first, u32 K, u32 H,
-                                                       const u64* __restrict__ entries, const u32* __restrict__ roff /*chunk off*/,
-                                                       KeyLayout kl, u64* __restrict__ keys) {
-    __shared__ u32 s_off[LK_HITS + 2];
-    __shared__ u32 s_beg[LK_HITS + 2];
-    __shared__ u32 s_q[LK_HITS + 2];
-    __shared__ u32 s_qa[LK_HITS + 2];
-    const u32 k0 = blk_first[blockIdx.x];
-    u32 k1 = blk_first[blockIdx.x + 1];  // last seed that can start inside this block (inclusive)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(64 * LW_WAVES, 4) void k_lookup(const u32* __restrict__ cs_hoff, const u32* __restrict__ cs_beg,
+                                                          const u64* __restrict__ cs_kbase, const u32* __restrict__ wave_first, u32 K,
+                                                          u32 H, u32 nw, const u64* __restrict__ entries,
+                                                          const u32* __restrict__ roff /*chunk off*/, KeyLayout kl,
+                                                          u64* __restrict__ keys, int variant /*diagnostic ablations; 0 = real*/) {
+    __shared__ u16 s_owner_all[LW_WAVES][LW_HITS];
+    __shared__ u32 s_off_all[LW_WAVES][LW_SEEDS];
+    __shared__ u32 s_beg_all[LW_WAVES][LW_SEEDS];
+    __shared__ u64 s_kb_all[LW_WAVES][LW_SEEDS];
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 wid = blockIdx.x * LW_WAVES + w;
+    if (wid >= nw) return;
+    u16* s_owner = s_owner_all[w];
+    u32* s_off = s_off_all[w];
+    u32* s_beg = s_beg_all[w];
+    u64* s_kb = s_kb_all[w];
+    const u32 k0 = wave_first[wid];
+    u32 k1 = wave_first[wid + 1];
     if (k1 >= K) k1 = K - 1;
-    const u32 ns = k1 - k0 + 1;  // <= LK_HITS + 1
-    for (u32 i = threadIdx.x; i < ns; i += LK_THREADS) {
+    const u32 ns = k1 - k0 + 1;  // <= LW_HITS + 1
+    const u32 lo = wid * LW_HITS;
+    const u32 nl = ns < LW_SEEDS ? ns : LW_SEEDS;
+    {
+        uint4 z = make_uint4(0, 0, 0, 0);  // LW_HITS u16, 16 B per lane and store
+        for (u32 i = lane; i < LW_HITS / 8; i += 64) reinterpret_cast<uint4*>(s_owner)[i] = z;
+    }
+    for (u32 i = lane; i < nl; i += 64) {
         s_off[i] = cs_hoff[k0 + i];
         s_beg[i] = cs_beg[k0 + i];
-        s_q[i] = cs_q[k0 + i];
-        s_qa[i] = cs_qa[k0 + i];
+        s_kb[i] = cs_kbase[k0 + i];
     }
-    __syncthreads();
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 hbase = blockIdx.x * LK_HITS + wave * (64 * LK_PER_THREAD);
-    u32 lo = 0;
-#pragma unroll 2
-    for (int it = 0; it < LK_PER_THREAD; ++it) {
-        const u32 h = hbase + it * 64 + lane;
-        if (h >= H) break;
-        // largest i in [lo, ns) with s_off[i] <= h
-        u32 a = lo, b = ns;
-        while (b - a > 1) {
-            u32 m = (a + b) >> 1;
-            if (s_off[m] <= h) a = m;
-            else b = m;
+    wave_lds_sync();
+    for (u32 i = lane + 1; i < ns; i += 64) {
+        const u32 o = (i < LW_SEEDS ? s_off[i] : cs_hoff[k0 + i]) - lo;
+        if (o < LW_HITS) s_owner[o] = (u16)i;
+    }
+    wave_lds_sync();
+    {  // prefix-max over the wave's 1024 owner marks: 16 consecutive per lane + wave scan
+        const u32 b = lane * LW_ITERS;
+        u32 v[LW_ITERS], m = 0;
+#pragma unroll
+        for (int k = 0; k < LW_ITERS; ++k) {
+            m = max(m, (u32)s_owner[b + k]);
+            v[k] = m;
         }
-        lo = a;
-        const u32 slot = s_beg[a] + (h - s_off[a]);
-        const u64 e = entries[slot];
-        const u32 qa = s_qa[a];
-        const u32 qpos = qa & 0xFFFFFFu, as = qa >> 24;
-        u32 j = (u32)(e >> 32), tag = (u32)(e >> 24) & 0xFFu, pos = (u32)e & 0xFFFFFFu;
-        u64 key;
-        if (pos == 0 && j == 0) {
-            key = ~0ull;
+        u32 inc = m;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_up(inc, o);
+            if ((int)lane >= o) inc = max(inc, t);
+        }
+        u32 pre = __shfl_up(inc, 1);
+        if (lane == 0) pre = 0;
+#pragma unroll
+        for (int k = 0; k < LW_ITERS; ++k) s_owner[b + k] = (u16)max(v[k], pre);
+    }
+    wave_lds_sync();
+    u64 e[LW_ITERS];
+    u32 own[LW_ITERS];
+#pragma unroll
+    for (int it = 0; it < LW_ITERS; ++it) {
+        const u32 hl = it * 64 + lane, h = lo + hl;
+        e[it] = 0;
+        own[it] = 0;
+        if (h < H) {
+            const u32 a = s_owner[hl];
+            own[it] = a;
+            const u32 beg = a < LW_SEEDS ? s_beg[a] : cs_beg[k0 + a], off = a < LW_SEEDS ? s_off[a] : cs_hoff[k0 + a];
+            if (variant == 1) e[it] = ((u64)(hl & 1023u) << 32) | 5u;  // ablation: no index-entry read
+            else e[it] = entries[beg + (h - off)];
+        }
+    }
+    u32 fix = 0;  // iterations whose entry sits at offset 0 of its sequence (rare): redone below
+#pragma unroll
+    for (int it = 0; it < LW_ITERS; ++it) {
+        const u32 hl = it * 64 + lane, h = lo + hl;
+        if (h >= H) continue;
+        const u32 a = own[it];
+        const u64 kb = a < LW_SEEDS ? s_kb[a] : cs_kbase[k0 + a];
+        const u32 j = (u32)(e[it] >> 32), pos = (u32)e[it] & 0xFFFFFFu, tag = (u32)(e[it] >> 24) & 0xFFu;
+        if (pos == 0) fix |= 1u << it;
+        const u64 key = kb + ((u64)j << kl.sh_subj) - ((u64)pos << kl.sh_diag) + (u64)tag;
+        if (variant == 2) {
+            if (key == 0x1234567ull) keys[h] = key;  // ablation: (practically) no key write
         } else {
-            u32 sst = pos;
-            if (pos == 0) {
-                j -= 1;
-                sst = roff[j + 1] - roff[j];
-            }
-            const u64 diag = (u64)((i64)qpos - (i64)sst + kl.diag_off);
-            key = ((u64)s_q[a] << kl.sh_q) | ((u64)j << kl.sh_subj) | (diag << kl.sh_diag) | ((u64)qpos << kl.sh_qpos) |
-                  ((u64)as << kl.sh_as) | (u64)tag;
+            keys[h] = key;
         }
-        keys[h] = key;
+    }
+    if (fix) {
+#pragma unroll 1
+        for (int it = 0; it < LW_ITERS; ++it) {
+            if (!((fix >> it) & 1u)) continue;
+            const u32 hl = it * 64 + lane, h = lo + hl;
+            const u32 a = s_owner[hl];
+            const u32 beg = a < LW_SEEDS ? s_beg[a] : cs_beg[k0 + a], off = a < LW_SEEDS ? s_off[a] : cs_hoff[k0 + a];
+            const u64 kb = a < LW_SEEDS ? s_kb[a] : cs_kbase[k0 + a];
+            const u64 en = entries[beg + (h - off)];
+            u32 j = (u32)(en >> 32);
+            const u32 tag = (u32)(en >> 24) & 0xFFu;
+            // previous NON-EMPTY sequence at sst = its length; none -> index -1 -> dropped
+            while (j > 0 && roff[j] == roff[j - 1]) --j;
+            u64 key = ~0ull;
+            if (j > 0) {
+                j -= 1;
+                const u32 sst = roff[j + 1] - roff[j];
+                key = kb + ((u64)j << kl.sh_subj) - ((u64)sst << kl.sh_diag) + (u64)tag;
+            }
+            if (variant != 2) keys[h] = key;
+        }
     }
 }
 
@@ -278,23 +345,25 @@ void launch_effcnt(const u8* mark, const u32* scnt, u32 Ppad, int AS, u32* eff, 
 }
 
 void launch_compact_seeds(const u32* eff, const u32* hoff, const u32* cidx, const u32* sbeg, const u32* q_pseq, const u32* qoff,
-                          u32 Ppad, int AS, u32* cs_hoff, u32* cs_beg, u32* cs_q, u32* cs_qa, hipStream_t st) {
+                          u32 Ppad, int AS, const KeyLayout& kl, u32* cs_hoff, u32* cs_beg, u64* cs_kbase, hipStream_t st) {
     size_t T = (size_t)AS * Ppad;
     if (!T) return;
     hipLaunchKernelGGL(k_compact_seeds, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, eff, hoff, cidx, sbeg, q_pseq, qoff,
-                       Ppad, AS, cs_hoff, cs_beg, cs_q, cs_qa);
+                       Ppad, AS, kl, cs_hoff, cs_beg, cs_kbase);
 }
 
-u32 lookup_num_blocks(u32 H) { return (H + LK_HITS - 1) / LK_HITS; }
+u32 lookup_num_blocks(u32 H) { return (H + LW_HITS - 1) / LW_HITS; }  // number of lookup WAVES
 
-void launch_lookup_blockfirst(const u32* cs_hoff, u32 K, u32 H, u32* blk_first, hipStream_t st) {
-    u32 nblk = lookup_num_blocks(H);
-    hipLaunchKernelGGL(k_lookup_blockfirst, dim3((nblk + 1 + 255) / 256), dim3(256), 0, st, cs_hoff, K, H, nblk, blk_first);
+void launch_lookup_blockfirst(const u32* cs_hoff, u32 K, u32 H, u32* wave_first, hipStream_t st) {
+    u32 nw = lookup_num_blocks(H);
+    hipLaunchKernelGGL(k_lookup_blockfirst, dim3((nw + 1 + 255) / 256), dim3(256), 0, st, cs_hoff, K, H, nw, wave_first);
 }
 
-void launch_lookup(const u32* cs_hoff, const u32* cs_beg, const u32* cs_q, const u32* cs_qa, const u32* blk_first, u32 K, u32 H,
+void launch_lookup(const u32* cs_hoff, const u32* cs_beg, const u64* cs_kbase, const u32* wave_first, u32 K, u32 H,
                    const u64* entries, const u32* roff, const KeyLayout& kl, u64* keys, hipStream_t st) {
     if (!H) return;
-    hipLaunchKernelGGL(k_lookup, dim3(lookup_num_blocks(H)), dim3(LK_THREADS), 0, st, cs_hoff, cs_beg, cs_q, cs_qa, blk_first, K, H,
-                       entries, roff, kl, keys);
+    static const int variant = getenv("SOHIT_LK_VARIANT") ? atoi(getenv("SOHIT_LK_VARIANT")) : 0;
+    const u32 nw = lookup_num_blocks(H);
+    hipLaunchKernelGGL(k_lookup, dim3((nw + LW_WAVES - 1) / LW_WAVES), dim3(64 * LW_WAVES), 0, st, cs_hoff, cs_beg, cs_kbase, wave_first,
+                       K, H, nw, entries, roff, kl, keys, variant);
 }

@@ -39,10 +39,10 @@ void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, int mink, const
 void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark, hipStream_t st);
 void launch_effcnt(const u8* mark, const u32* scnt, u32 Ppad, int AS, u32* eff, u32* nz, hipStream_t st);
 void launch_compact_seeds(const u32* eff, const u32* hoff, const u32* cidx, const u32* sbeg, const u32* q_pseq, const u32* qoff,
-                          u32 Ppad, int AS, u32* cs_hoff, u32* cs_beg, u32* cs_q, u32* cs_qa, hipStream_t st);
+                          u32 Ppad, int AS, const KeyLayout& kl, u32* cs_hoff, u32* cs_beg, u64* cs_kbase, hipStream_t st);
 u32 lookup_num_blocks(u32 H);
-void launch_lookup_blockfirst(const u32* cs_hoff, u32 K, u32 H, u32* blk_first, hipStream_t st);
-void launch_lookup(const u32* cs_hoff, const u32* cs_beg, const u32* cs_q, const u32* cs_qa, const u32* blk_first, u32 K, u32 H,
+void launch_lookup_blockfirst(const u32* cs_hoff, u32 K, u32 H, u32* wave_first, hipStream_t st);
+void launch_lookup(const u32* cs_hoff, const u32* cs_beg, const u64* cs_kbase, const u32* wave_first, u32 K, u32 H,
                    const u64* entries, const u32* roff, const KeyLayout& kl, u64* keys, hipStream_t st);
 
 // k_group.hip
@@ -77,8 +77,8 @@ void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, const u32*
                   u32* ntile, hipStream_t st);
 void launch_mktasks(const u32* rec, const u32* qcoff, const u32* perm, const u32* ntask, const u32* roffc, const u32* toff, u32 nq,
                     const u32* qoff, const u32* roff, AlnTask* tasks, u32* rk_slot, hipStream_t st);
-void launch_round_counts(const u32* ntask, const u32* ntile, const u32* roffc, const u32* rk_slot, const u32* st_state, u32 nq, u32 B,
-                         u32* rcnt, u32* tcnt, hipStream_t st);
+void launch_round_counts(const u32* ntask, const u32* ntile, const u32* roffc, const u32* rk_slot, const u32* qcoff,
+                         const u32* st_state, u32 nq, double max_miss, u32 minr, u32* rcnt, u32* tcnt, hipStream_t st);
 void launch_round_idx(const u32* tcnt, const u32* troff, const u32* toff, const u32* ntask, const u32* ntile, const u32* roffc,
                       const u32* rk_slot, const u32* st_state, u32 nq, u32* ridx, hipStream_t st);
 void launch_stop_round(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* ntile, const u32* roffc,

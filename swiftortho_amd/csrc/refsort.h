@@ -1,20 +1,25 @@
 // refsort.h -- the reference's non-stable fixed-pivot quicksort (fsearch.py:260-327; *_u twins
-// 189-256) as a device function.  Ties decide cap membership, the top-vmax cut and output order,
+// 189-256) as device functions.  Ties decide cap membership, the top-vmax cut and output order,
 // so the algorithm is reproduced move for move: insertion sort below 7 elements, pivot index
 // l + 3 at exactly 7, else l + int(0.3745401188473625 * gap) (MT19937 re-seeded with 42 on every
-// call), Hoare-style partition.  Sub-ranges are independent, so an explicit stack that handles
-// the smaller side first (depth <= log2 n) gives the same result as the recursion.
+// call), Hoare-style partition.  Sub-ranges are independent, so the order in which they are
+// processed does not matter.
+//
+//   ref_qsort_range   one thread, explicit stack (smaller side first, depth <= log2 n)
+//   wave_ref_qsort    one wave64, array in LDS: ranges >= WQS_PAR are partitioned by the whole
+//                     wave with EXACTLY the permutation the sequential partition produces; smaller
+//                     ranges are collected and sorted afterwards one per lane with ref_qsort_range.
 #pragma once
 #include "common.h"
 
 // `limit`: only positions [0, limit) of the result are needed -- sub-ranges that start at or beyond
-// it are left unsorted (they cannot influence earlier positions: sub-ranges are independent).
+// it are left unsorted (they cannot influence earlier positions).
 template <class KeyFn>
-__device__ inline void ref_qsort_dev(u32* x, int n, KeyFn key, int limit = 0x7fffffff) {
+__device__ inline void ref_qsort_range(u32* x, int l0, int r0, KeyFn key, int limit = 0x7fffffff) {
     int stk[2 * 48];
     int sp = 0;
-    stk[sp++] = 0;
-    stk[sp++] = n - 1;
+    stk[sp++] = l0;
+    stk[sp++] = r0;
     while (sp > 0) {
         int r = stk[--sp], l = stk[--sp];
         if (r <= l || l >= limit) continue;
@@ -53,7 +58,6 @@ __device__ inline void ref_qsort_dev(u32* x, int n, KeyFn key, int limit = 0x7ff
         x[l] = x[j];
         x[j] = t;
         int med = j;
-        // ranges [l, med-1] and [med+1, r]; push the larger first so the smaller is handled next
         int n1 = med - l, n2 = r - med;
         if (n1 > n2) {
             stk[sp++] = l, stk[sp++] = med - 1;
@@ -63,4 +67,107 @@ __device__ inline void ref_qsort_dev(u32* x, int n, KeyFn key, int limit = 0x7ff
             stk[sp++] = l, stk[sp++] = med - 1;
         }
     }
+}
+
+template <class KeyFn>
+__device__ inline void ref_qsort_dev(u32* x, int n, KeyFn key, int limit = 0x7fffffff) {
+    ref_qsort_range(x, 0, n - 1, key, limit);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-parallel exact replay.  For a range [l, r] with pivot p = key(x[l]) (after the pivot swap):
+//   L_1 < L_2 < ...   positions in (l, r] with key >= p   (where the upward scan stops)
+//   R_1 > R_2 > ...   positions in [l, r] with key <= p   (where the downward scan stops; x[l] is the last)
+// The sequential partition swaps (L_k, R_k) for k = 1..m, m = #{k : L_k < R_k} (swapped elements are
+// never revisited, so the pairing is a function of the ORIGINAL array), then exchanges the pivot
+// with j = max(R_{m+1}, L_m), or max(R_{m+2}, L_m) when L_{m+1} == R_{m+1} (the scans meet on an
+// element equal to the pivot: a self-swap, one more scan step).  Ranks come from ballots.
+// Block = exactly one wave (64 threads); x, Lpos, Rpos (n u16 each) and leaf (2 * WQS_LEAF ints) in LDS.
+// ---------------------------------------------------------------------------------------------
+#define WQS_PAR 64
+#define WQS_LEAF 512
+
+template <class KeyFn>
+__device__ inline void wave_ref_qsort(u32* x, int n, KeyFn key, int limit, u16* Lpos, u16* Rpos, int* leaf) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int stk[2 * 40];
+    int sp = 0, nleaf = 0;
+    stk[sp++] = 0;
+    stk[sp++] = n - 1;
+    while (sp > 0) {  // wave-uniform control flow: every lane holds the same stack
+        const int r = stk[--sp], l = stk[--sp];
+        if (r <= l || l >= limit) continue;
+        const int gap = r - l + 1;
+        if (gap < WQS_PAR || nleaf >= WQS_LEAF - 1) {
+            if (gap < WQS_PAR && nleaf < WQS_LEAF) {
+                if (lane == 0) leaf[2 * nleaf] = l, leaf[2 * nleaf + 1] = r;
+                ++nleaf;
+            } else {  // leaf list full (cannot happen for n <= 4096): sort it right here on one lane
+                __syncthreads();
+                if (lane == 0) ref_qsort_range(x, l, r, key, limit);
+                __syncthreads();
+            }
+            continue;
+        }
+        const int m = l + (int)(0.3745401188473625 * (double)gap);
+        if (lane == 0) {
+            u32 t = x[l];
+            x[l] = x[m];
+            x[m] = t;
+        }
+        __syncthreads();
+        const auto p = key(x[l]);
+        int cntL = 0, cntR = 0;
+        for (int base = l + 1; base <= r; base += 64) {
+            const int t = base + lane;
+            const bool f = (t <= r) && !(key(x[t <= r ? t : r]) < p);
+            const unsigned long long bal = __ballot(f);
+            if (f) Lpos[cntL + __popcll(bal & lt)] = (u16)(t - l);
+            cntL += __popcll(bal);
+        }
+        for (int base = r; base >= l; base -= 64) {
+            const int t = base - lane;
+            const bool f = (t >= l) && !(key(x[t >= l ? t : l]) > p);
+            const unsigned long long bal = __ballot(f);
+            if (f) Rpos[cntR + __popcll(bal & lt)] = (u16)(t - l);
+            cntR += __popcll(bal);
+        }
+        __syncthreads();
+        const int K = cntL < cntR ? cntL : cntR;
+        int mm = 0;
+        for (int base = 0; base < K; base += 64) {
+            const int k = base + lane;
+            const bool f = (k < K) && (Lpos[k < K ? k : 0] < Rpos[k < K ? k : 0]);
+            mm += __popcll(__ballot(f));
+        }
+        for (int k = lane; k < mm; k += 64) {
+            const int a = l + Lpos[k], b = l + Rpos[k];
+            const u32 t = x[a];
+            x[a] = x[b];
+            x[b] = t;
+        }
+        const int Lm = mm > 0 ? (int)Lpos[mm - 1] : -1;
+        const bool tie = (mm < cntL) && (Lpos[mm] == Rpos[mm]);
+        const int Rn = tie ? (int)Rpos[mm + 1] : (int)Rpos[mm];
+        const int jrel = Rn > Lm ? Rn : Lm;
+        __syncthreads();
+        if (lane == 0) {
+            u32 t = x[l];
+            x[l] = x[l + jrel];
+            x[l + jrel] = t;
+        }
+        __syncthreads();
+        const int med = l + jrel;
+        if (med - l > r - med) {
+            stk[sp++] = l, stk[sp++] = med - 1;
+            stk[sp++] = med + 1, stk[sp++] = r;
+        } else {
+            stk[sp++] = med + 1, stk[sp++] = r;
+            stk[sp++] = l, stk[sp++] = med - 1;
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < nleaf; i += 64) ref_qsort_range(x, leaf[2 * i], leaf[2 * i + 1], key, limit);
+    __syncthreads();
 }
