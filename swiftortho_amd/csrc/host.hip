@@ -159,9 +159,13 @@ struct SeqSet {
 };
 
 // 5-bit hash classes for one residue array under the run's alphabets
-void build_hash_classes(const u8* bytes, size_t n, const std::vector<std::array<int, 256>>& codes, u8 hmap[256], HashLut& lut) {
-    bool present[256] = {false};
-    for (size_t i = 0; i < n; ++i) present[bytes[i]] = true;
+void byte_presence(const u8* bytes, size_t n, bool present[256]) {
+    u64 cnt[256] = {0};
+    for (size_t i = 0; i < n; ++i) cnt[bytes[i]]++;
+    for (int b = 0; b < 256; ++b) present[b] = cnt[b] != 0;
+}
+
+void build_hash_classes(const bool present[256], const std::vector<std::array<int, 256>>& codes, u8 hmap[256], HashLut& lut) {
     memset(&lut, 0, sizeof lut);
     std::vector<std::vector<int>> tuples;
     for (int b = 0; b < 256; ++b) {
@@ -231,6 +235,10 @@ struct so_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t max_hits_per_pass = (size_t)1 << 30;
     u32 max_batch = 16384;
+    // device SEG: tables, symbol folding of the loaded query set
+    DevBuf<u8> d_segtab, d_symmap, d_upmap, d_segmask;
+    bool seg_on_device = false;
+    bool q_present[256];               // bytes that can occur in (masked) query residues
     std::map<std::string, double> tm;  // per-stage wall ms (only with params.profile)
     std::shared_ptr<void> batch;       // persistent per-batch scratch (struct Batch)
 };
@@ -298,15 +306,12 @@ void upload_constants(so_ctx* c) {
 }
 
 // device-resident arrays of a sequence set given its (possibly masked) residues
-void upload_set(so_ctx* c, SeqSet& s, const u8* residues, const std::vector<u32>& off, u32 nseq, bool want_pseq) {
-    const size_t nres = off[nseq];
+// Derived device arrays of a sequence set whose residues (s.d_res) and offsets (s.d_off) are already
+// on the device: score classes, 5-bit hash-class stream, owner map.  `present` = bytes that can occur.
+void layout_set(so_ctx* c, SeqSet& s, const bool present[256], size_t nres, u32 nseq) {
     u8 hmap[256];
-    build_hash_classes(residues, nres, c->codes, hmap, s.lut);
-    s.d_res.ensure(nres + 64);
+    build_hash_classes(present, c->codes, hmap, s.lut);
     s.d_scls.ensure(nres + 64);
-    s.d_off.ensure((size_t)nseq + 1);
-    HIP_CHECK(hipMemcpyAsync(s.d_res.p, residues, nres, hipMemcpyHostToDevice, c->st));
-    HIP_CHECK(hipMemcpyAsync(s.d_off.p, off.data(), ((size_t)nseq + 1) * sizeof(u32), hipMemcpyHostToDevice, c->st));
     HIP_CHECK(hipMemcpyAsync(c->d_hmap.p, hmap, 256, hipMemcpyHostToDevice, c->st));
     launch_scls(s.d_res.p, nres, c->d_smap.p, s.d_scls.p, c->st);
     if ((u64)nres + nseq + 64 > 0xFFFFFFF0ull) throw SoError("sequence set too large for 32-bit packed positions");
@@ -318,8 +323,20 @@ void upload_set(so_ctx* c, SeqSet& s, const u8* residues, const std::vector<u32>
     s.d_pseq.ensure(s.Ppad);
     c->d_pcls.ensure(s.Ppad);
     launch_layout(s.d_res.p, s.d_off.p, nseq, s.P, s.Ppad, c->d_hmap.p, s.d_pseq.p, c->d_pcls.p, s.d_words.p, c->st);
-    HIP_CHECK(hipStreamSynchronize(c->st));  // hmap (stack) and host buffers must outlive the copies
-    (void)want_pseq;
+    HIP_CHECK(hipStreamSynchronize(c->st));  // hmap (stack) must outlive the copy
+}
+
+// host residues -> device, then layout
+void upload_set(so_ctx* c, SeqSet& s, const u8* residues, const std::vector<u32>& off, u32 nseq, const bool* present_in = nullptr) {
+    const size_t nres = off[nseq];
+    bool present[256];
+    if (present_in) memcpy(present, present_in, sizeof present);
+    else byte_presence(residues, nres, present);
+    s.d_res.ensure(nres + 64);
+    s.d_off.ensure((size_t)nseq + 1);
+    HIP_CHECK(hipMemcpyAsync(s.d_res.p, residues, nres, hipMemcpyHostToDevice, c->st));
+    HIP_CHECK(hipMemcpyAsync(s.d_off.p, off.data(), ((size_t)nseq + 1) * sizeof(u32), hipMemcpyHostToDevice, c->st));
+    layout_set(c, s, present, nres, nseq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -447,7 +464,7 @@ void parallel_for(i64 n, F f) {
 void load_ref_common(so_ctx* c, i64 r_lo, i64 r_hi) {
     c->ref.parse();
     c->r_lo = r_lo, c->r_hi = r_hi;
-    upload_set(c, c->ref, c->ref.res.data(), c->ref.off, (u32)c->ref.N, true);
+    upload_set(c, c->ref, c->ref.res.data(), c->ref.off, (u32)c->ref.N);
     c->ref_loaded = true;
     c->index_built = false;
     c->chunks.clear();
@@ -581,17 +598,29 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
         b.h_off[i + 1] = b.h_off[i] + ln;
         b.maxqlen = std::max(b.maxqlen, ln);
     }
-    b.h_res.resize(b.h_off[b.nq] + 16);
-    const u8* src = Q.res.data();
-    if (c->filter) {
-        parallel_for((i64)b.nq, [&](i64 i) {
-            seg_mask(src + Q.off[q_lo + i], (int)Q.len(q_lo + i), b.h_res.data() + b.h_off[i]);
-        });
-    } else if (b.h_off[b.nq]) {
-        memcpy(b.h_res.data(), src + Q.off[q_lo], b.h_off[b.nq]);
-    }
+    const size_t nres_b = b.h_off[b.nq];
     c->masked_lo = q_lo;
-    upload_set(c, b.dev, b.h_res.data(), b.h_off, b.nq, true);
+    if (c->seg_on_device || !c->filter) {
+        // residues never leave the device: SEG kernel (or plain copy) from the resident raw queries
+        b.dev.d_res.ensure(nres_b + 64);
+        b.dev.d_off.ensure((size_t)b.nq + 1);
+        HIP_CHECK(hipMemcpyAsync(b.dev.d_off.p, b.h_off.data(), ((size_t)b.nq + 1) * sizeof(u32), hipMemcpyHostToDevice, c->st));
+        if (c->filter) {
+            c->d_segmask.ensure(nres_b + 64);
+            launch_seg(c->qry.d_res.p, c->qry.d_off.p, (u32)q_lo, b.nq, b.dev.d_off.p, c->d_symmap.p, c->d_upmap.p, c->d_segtab.p,
+                       c->d_segmask.p, b.dev.d_res.p, c->st);
+        } else {
+            launch_copy_range(c->qry.d_res.p + Q.off[q_lo], b.dev.d_res.p, nres_b, c->st);
+        }
+        layout_set(c, b.dev, c->q_present, nres_b, b.nq);
+        b.h_res.clear();
+    } else {
+        // more than 64 distinct residue bytes: SEG on the host (same arithmetic, same tables)
+        b.h_res.resize(nres_b + 16);
+        const u8* src = Q.res.data();
+        parallel_for((i64)b.nq, [&](i64 i) { seg_mask(src + Q.off[q_lo + i], (int)Q.len(q_lo + i), b.h_res.data() + b.h_off[i]); });
+        upload_set(c, b.dev, b.h_res.data(), b.h_off, b.nq);
+    }
     const int AS = c->cfg.A * c->cfg.S;
     const u32 Ppad = b.dev.Ppad;
     const size_t T = (size_t)AS * Ppad;
@@ -779,12 +808,21 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     launch_group_list(b.flags.p, b.gidx.p, NP, b.shead.p, c->st);
     b.c_ft.ensure((size_t)NS + 2), b.c_ft2.ensure((size_t)NS + 2), b.c_q.ensure((size_t)NS + 2), b.c_rec.ensure(4 * (size_t)NS + 8);
     launch_best(b.p_qs2.p, b.pidx2.p, b.shead.p, NS, NP, b.q_sd.p, b.q_ft.p, (u32)ch.seq_lo, b.c_ft.p, b.c_q.p, b.c_rec.p, c->st);
-    // order candidates by (query, first-touch): sort by first-touch, then stable sort by query
+    // order candidates by (query, first-touch): one sort on (q << ftbits | ft) when that fits 64 bits,
+    // else sort by first-touch and then stable-sort by query; only the populated bits are sorted
+    const int ftbits = kl.ba + kl.bp + ft_bits_entry;
     b.order.ensure((size_t)NS + 2), b.order2.ensure((size_t)NS + 2), b.tmp64.ensure((size_t)NS + 2);
     launch_iota(b.order.p, NS, c->st);
-    sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.c_ft.p, b.c_ft2.p, b.order.p, b.order2.p, NS, 64, c->st);
-    launch_gather_u32_as_u64(b.c_q.p, b.order2.p, NS, b.tmp64.p, c->st);
-    sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, b.order2.p, b.order.p, NS, kl.bq, c->st);
+    if (ftbits + kl.bq <= 64) {
+        launch_combine_q_ft(b.c_q.p, b.c_ft.p, NS, ftbits, b.tmp64.p, c->st);
+        sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, b.order.p, b.order2.p, NS, ftbits + kl.bq, c->st);
+        std::swap(b.order.p, b.order2.p);
+        std::swap(b.order.cap, b.order2.cap);
+    } else {
+        sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.c_ft.p, b.c_ft2.p, b.order.p, b.order2.p, NS, ftbits, c->st);
+        launch_gather_u32_as_u64(b.c_q.p, b.order2.p, NS, b.tmp64.p, c->st);
+        sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, b.order2.p, b.order.p, NS, kl.bq, c->st);
+    }
     // append to the candidate store
     const u32 base = b.chunk_base.back();
     b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
@@ -969,6 +1007,10 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, std::vector<so_hit>& out) {
         c->cnt.query_aa += b.h_off[b.nq];
         if (getenv("SOHIT_KEEP_MASKED")) {
             if (c->masked.empty()) c->masked_lo = st;
+            if (b.h_res.empty() && b.h_off[b.nq]) {
+                b.h_res.resize(b.h_off[b.nq] + 16);
+                HIP_CHECK(hipMemcpy(b.h_res.data(), b.dev.d_res.p, b.h_off[b.nq], hipMemcpyDeviceToHost));
+            }
             for (u32 i = 0; i < b.nq; ++i)
                 c->masked.emplace_back((const char*)b.h_res.data() + b.h_off[i], (size_t)(b.h_off[i + 1] - b.h_off[i]));
         }
@@ -1031,6 +1073,47 @@ bool read_file(const char* path, std::string& out) {
     bool ok = n <= 0 || fread(&out[0], 1, (size_t)n, f) == (size_t)n;
     fclose(f);
     return ok;
+}
+
+// queries: parse, make the raw residues resident, and prepare the device SEG symbol folding
+void load_queries_common(so_ctx* c) {
+    SeqSet& Q = c->qry;
+    Q.parse();
+    const size_t nres = Q.res.size();
+    Q.d_res.ensure(nres + 64);
+    Q.d_off.ensure((size_t)Q.N + 1);
+    if (nres) HIP_CHECK(hipMemcpyAsync(Q.d_res.p, Q.res.data(), nres, hipMemcpyHostToDevice, c->st));
+    HIP_CHECK(hipMemcpyAsync(Q.d_off.p, Q.off.data(), ((size_t)Q.N + 1) * sizeof(u32), hipMemcpyHostToDevice, c->st));
+    bool raw_present[256];
+    byte_presence(Q.res.data(), nres, raw_present);
+    u8 up[256], sym[256];
+    for (int b = 0; b < 256; ++b) up[b] = (b >= 'a' && b <= 'z') ? (u8)(b - 32) : (u8)b;
+    memset(c->q_present, 0, sizeof c->q_present);
+    if (c->filter) {
+        // masked residues are upper-cased raw bytes plus 'x'
+        for (int b = 0; b < 256; ++b)
+            if (raw_present[b]) c->q_present[up[b]] = true;
+        c->q_present['x'] = true;
+        int nsym = 0;
+        int id[256];
+        for (int b = 0; b < 256; ++b) id[b] = -1;
+        for (int b = 0; b < 256; ++b)
+            if (raw_present[b] && id[up[b]] < 0) id[up[b]] = nsym++;
+        c->seg_on_device = nsym <= 64;
+        for (int b = 0; b < 256; ++b) sym[b] = (u8)((id[up[b]] >= 0 && id[up[b]] < 64) ? id[up[b]] : 0);
+        const SegTables& T = seg_tables();
+        c->d_segtab.ensure(sizeof(SegTables));
+        c->d_symmap.ensure(256);
+        c->d_upmap.ensure(256);
+        HIP_CHECK(hipMemcpyAsync(c->d_segtab.p, &T, sizeof(SegTables), hipMemcpyHostToDevice, c->st));
+        HIP_CHECK(hipMemcpyAsync(c->d_symmap.p, sym, 256, hipMemcpyHostToDevice, c->st));
+        HIP_CHECK(hipMemcpyAsync(c->d_upmap.p, up, 256, hipMemcpyHostToDevice, c->st));
+    } else {
+        memcpy(c->q_present, raw_present, sizeof raw_present);
+        c->seg_on_device = false;
+    }
+    HIP_CHECK(hipStreamSynchronize(c->st));
+    c->qry_loaded = true;
 }
 
 template <class F>
@@ -1122,16 +1205,14 @@ int so_drop_index(so_ctx* c) {
 int so_load_queries(so_ctx* c, const char* path) {
     return guarded(c, [&] {
         if (!read_file(path, c->qry.data)) throw SoError(std::string("cannot read query FASTA ") + path);
-        c->qry.parse();
-        c->qry_loaded = true;
+        load_queries_common(c);
     });
 }
 
 int so_load_queries_mem(so_ctx* c, const char* bytes, int64_t n) {
     return guarded(c, [&] {
         c->qry.data.assign(bytes, (size_t)n);
-        c->qry.parse();
-        c->qry_loaded = true;
+        load_queries_common(c);
     });
 }
 

@@ -276,6 +276,12 @@ __global__ __launch_bounds__(256) void k_gather_u32_as_u64(const u32* __restrict
     if (i < n) dst[i] = src[idx[i]];
 }
 
+__global__ __launch_bounds__(256) void k_combine_q_ft(const u32* __restrict__ c_q, const u64* __restrict__ c_ft, u32 n, int ftbits,
+                                                      u64* __restrict__ dst) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) dst[i] = ((u64)c_q[i] << ftbits) | c_ft[i];
+}
+
 __global__ __launch_bounds__(256) void k_iota(u32* __restrict__ p, u32 n) {
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) p[i] = i;
@@ -353,6 +359,11 @@ void launch_best(const u64* sorted_qs, const u32* idx, const u32* shead, u32 nse
 void launch_gather_u32_as_u64(const u32* src, const u32* idx, u32 n, u64* dst, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(k_gather_u32_as_u64, dim3((n + 255) / 256), dim3(256), 0, st, src, idx, n, dst);
+}
+
+void launch_combine_q_ft(const u32* c_q, const u64* c_ft, u32 n, int ftbits, u64* dst, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_combine_q_ft, dim3((n + 255) / 256), dim3(256), 0, st, c_q, c_ft, n, ftbits, dst);
 }
 
 void launch_iota(u32* p, u32 n, hipStream_t st) {

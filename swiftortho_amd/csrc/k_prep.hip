@@ -72,6 +72,121 @@ __global__ __launch_bounds__(256) void k_scls(const u8* __restrict__ res, size_t
     }
 }
 
+// ---- SEG-like query masking (fsearch.py:2872-2928; entropy 2854-2868; Counter 157-177) ------------
+// One thread per query, sequential like the reference (the entropy is updated incrementally and
+// its rounding is order dependent).  All logarithms come from host tables of libm values
+// (lg12[k] = log(k / 12.), lgn[w][j] = log(j / w), log2v = log(2)), so the device only performs
+// IEEE fp64 multiply / subtract / divide / compare (the library is built with -ffp-contract=off)
+// and reproduces the reference's doubles bit for bit.  symmap folds the upper-cased byte to one
+// of <= 64 symbols; per-thread counters live in LDS.  Only output[:n] is produced (2996, 3034).
+struct SegTab {
+    double lg12[64];
+    double lgn[13][32];
+    double log2v;
+};
+
+__global__ __launch_bounds__(64) void k_seg(const u8* __restrict__ raw, const u32* __restrict__ src_off, u32 q_lo, u32 nq,
+                                            const u32* __restrict__ dst_off, const u8* __restrict__ symmap /*256: upper-cased byte*/,
+                                            const u8* __restrict__ upmap /*256*/, const SegTab* __restrict__ tab, u8* __restrict__ mk,
+                                            u8* __restrict__ out) {
+    __shared__ u8 s_cnt[64][64];  // [symbol][thread]: conflict-free per-thread counters
+    __shared__ u8 s_sym[256], s_up[256];
+    for (int i = threadIdx.x; i < 256; i += 64) s_sym[i] = symmap[i], s_up[i] = upmap[i];
+    for (int k = 0; k < 64; ++k) s_cnt[k][threadIdx.x] = 0;
+    __syncthreads();
+    const u32 q = blockIdx.x * 64u + threadIdx.x;
+    if (q >= nq) return;
+    const u8* S = raw + src_off[q_lo + q];
+    const int n = (int)(src_off[q_lo + q + 1] - src_off[q_lo + q]);
+    u8* o = out + dst_off[q];
+    u8* m = mk + dst_off[q];
+    if (n <= 0) return;
+    const double minent = 2.2, window = 12.;
+    const int tx = threadIdx.x;
+#define CNT(c) s_cnt[c][tx]
+    const int w = n < 12 ? n : 12;
+    for (int i = 0; i < w; ++i) {  // Counter(seq) + one more per char: 2 * occ - 1
+        const int c = s_sym[S[i]];
+        CNT(c) = CNT(c) == 0 ? 1 : CNT(c) + 2;
+    }
+    double ent = 0;
+    for (int i = 0; i < w; ++i) {  // values() in first-seen order
+        const int c = s_sym[S[i]];
+        bool first = true;
+        for (int k = 0; k < i; ++k) first = first && (s_sym[S[k]] != c);
+        if (!first) continue;
+        const int j = CNT(c);
+        const double freq = (double)j / ((double)w * 1.);
+        ent -= freq * tab->lgn[w][j];
+    }
+    ent /= tab->log2v;
+    int prev = ent < minent ? 1 : 0;
+    m[0] = (u8)prev;
+    for (int i = 1; i < n - 12 + 1; ++i) {
+        const int pre = s_sym[S[i - 1]], cur = s_sym[S[i + 11]];
+        if (pre == cur) {
+            m[i] = (u8)prev;
+            continue;
+        }
+        const int pre_count = CNT(pre);
+        CNT(pre) = pre_count - 1;
+        const int cur_count = CNT(cur);
+        CNT(cur) = cur_count + 1;
+        const int pre_after = pre_count - 1, cur_after = cur_count + 1;
+        double a = (double)pre_count / window, b = (double)pre_after / window, t;
+        if (pre_after != 0) {
+            t = (a * tab->lg12[pre_count] - b * tab->lg12[pre_after]) / tab->log2v;
+            if (t == 0) t = a * tab->lg12[pre_count] / tab->log2v;
+        } else {
+            t = a * tab->lg12[pre_count] / tab->log2v;
+        }
+        ent += t;
+        a = (double)cur_count / window;
+        b = (double)cur_after / window;
+        if (cur_count != 0) {
+            t = (a * tab->lg12[cur_count] - b * tab->lg12[cur_after]) / tab->log2v;
+            if (t == 0) t = -b * tab->lg12[cur_after] / tab->log2v;
+        } else {
+            t = -b * tab->lg12[cur_after] / tab->log2v;
+        }
+        ent += t;
+        prev = ent < minent ? 1 : 0;
+        m[i] = (u8)prev;
+    }
+#undef CNT
+    const int Nws = n - 12 > 0 ? n - 12 : 0;
+    const int tail = m[Nws];  // if mask[Nws]: mask[Nws:] = 1 ; positions past n - 12 are otherwise 0
+    int st = 0, oo = 0;
+    while (st < n) {
+        const int mv = st <= Nws ? (int)m[st] : tail;
+        if (mv == 0) {
+            o[oo++] = s_up[S[st]];
+            st += 1;
+        } else {
+            for (int k = 0; k < 12 && oo < n; ++k) o[oo++] = 'x';
+            st += 12;
+        }
+    }
+}
+
+// no masking (-F other than T): batch residues = raw residues
+__global__ __launch_bounds__(256) void k_copy_range(const u8* __restrict__ src, u8* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+void launch_seg(const u8* raw, const u32* src_off, u32 q_lo, u32 nq, const u32* dst_off, const u8* symmap, const u8* upmap,
+                const void* tab, u8* mk, u8* out, hipStream_t st) {
+    if (!nq) return;
+    hipLaunchKernelGGL(k_seg, dim3((nq + 63) / 64), dim3(64), 0, st, raw, src_off, q_lo, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk,
+                       out);
+}
+
+void launch_copy_range(const u8* src, u8* dst, size_t n, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_copy_range, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+}
+
 void launch_layout(const u8* res, const u32* off, u32 nseq, u32 P, u32 Ppad, const u8* hmap, u32* pseq, u8* pcls, u32* words,
                    hipStream_t st) {
     if (Ppad == 0) return;

@@ -20,6 +20,9 @@ void sort_pairs_u64_u32(void* temp, size_t temp_bytes, const u64* kin, u64* kout
 void launch_layout(const u8* res, const u32* off, u32 nseq, u32 P, u32 Ppad, const u8* hmap, u32* pseq, u8* pcls, u32* words,
                    hipStream_t st);
 void launch_scls(const u8* res, size_t n, const u8* smap, u8* scls, hipStream_t st);
+void launch_seg(const u8* raw, const u32* src_off, u32 q_lo, u32 nq, const u32* dst_off, const u8* symmap, const u8* upmap,
+                const void* tab /*SegTab on the device*/, u8* mk, u8* out, hipStream_t st);
+void launch_copy_range(const u8* src, u8* dst, size_t n, hipStream_t st);
 
 // k_index.hip
 void launch_index_count(const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
@@ -60,6 +63,7 @@ void launch_best(const u64* sorted_qs, const u32* idx, const u32* shead, u32 nse
                  u32 seq_lo, u64* c_ft, u32* c_q, u32* c_rec, hipStream_t st);
 void launch_gather_u32_as_u64(const u32* src, const u32* idx, u32 n, u64* dst, hipStream_t st);
 void launch_iota(u32* p, u32 n, hipStream_t st);
+void launch_combine_q_ft(const u32* c_q, const u64* c_ft, u32 n, int ftbits, u64* dst, hipStream_t st);
 void launch_emit_cands(const u32* order, u32 n, const u32* c_q, const u32* c_rec, u32* out_q, u32* out_rec, u32* qcnt,
                        u32* seg_first, hipStream_t st);
 
