@@ -239,6 +239,8 @@ struct so_ctx {
     DevBuf<u8> d_segtab, d_symmap, d_upmap, d_segmask;
     bool seg_on_device = false;
     bool q_present[256];               // bytes that can occur in (masked) query residues
+    void* pinned = nullptr;            // pinned host staging for result rows
+    size_t pinned_cap = 0;
     std::map<std::string, double> tm;  // per-stage wall ms (only with params.profile)
     std::shared_ptr<void> batch;       // persistent per-batch scratch (struct Batch)
 };
@@ -441,7 +443,7 @@ void seg_mask(const u8* S, int n, u8* out) {
 template <class F>
 void parallel_for(i64 n, F f) {
     unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    if (n < 256 || nt == 1) {
+    if (n < 200000 || nt == 1) {  // thread start-up costs ~0.3 ms: only worth it for big loops
         for (i64 i = 0; i < n; ++i) f(i);
         return;
     }
@@ -450,9 +452,9 @@ void parallel_for(i64 n, F f) {
     for (unsigned t = 0; t < nt; ++t)
         th.emplace_back([&] {
             for (;;) {
-                i64 b = next.fetch_add(64);
+                i64 b = next.fetch_add(4096);
                 if (b >= n) break;
-                for (i64 i = b; i < std::min(n, b + 64); ++i) f(i);
+                for (i64 i = b; i < std::min(n, b + 4096); ++i) f(i);
             }
         });
     for (auto& t : th) t.join();
@@ -565,6 +567,7 @@ struct Batch {
     DevBuf<int> ksc;
     DevBuf<u8> mark;
     DevBuf<u32> cs_hoff, cs_beg, blk_first;
+    DevBuf<unsigned long long> qhits;
     DevBuf<u64> cs_kbase;
     DevBuf<u64> keys, keys2;
     DevBuf<u32> flags, gidx, ghead;
@@ -689,16 +692,15 @@ struct ProfTimer {
 };
 
 // seed stage of one (batch, chunk): candidates appended to the batch's candidate store
+void seed_pass(so_ctx* c, Batch& b, int ci, u32 p_lo, u32 p_hi, double t0, StageClock& sc);
+
 void seed_stage(so_ctx* c, Batch& b, int ci) {
     ChunkIndex& ch = *c->chunks[ci];
     const int AS = c->cfg.A * c->cfg.S;
     const u32 Ppad = b.dev.Ppad, NC = (u32)c->nc;
-    const size_t T = (size_t)AS * Ppad;
     const u32 nseq_chunk = (u32)(ch.seq_hi - ch.seq_lo);
-    u32* qcnt = b.ccnt.p + (size_t)ci * b.nq;
     b.chunk_base.push_back(b.chunk_base.empty() ? 0u : b.chunk_base.back());
     if (nseq_chunk == 0 || ch.E == 0 || b.nq == 0) return;
-    const double t0 = wall();
     StageClock sc(c);
     {
         ProfTimer pt(c, &c->cnt.bounds_ms, &c->cnt.bounds_launches);
@@ -709,13 +711,36 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     HIP_CHECK(hipMemsetAsync(b.mark.p, 0, Ppad, c->st));
     i64 threshold = ch.threshold;
     if (c->thr >= 1 || threshold == 0) threshold = c->thr;  // `thr < 1 and DB.threshold or thr`, fsearch.py:2992
-    launch_cap(b.korder.p, b.dev.d_off.p, b.nq, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, c->st);
-    launch_effcnt(b.mark.p, b.scnt.p, Ppad, AS, b.eff.p, b.nz.p, c->st);
+    b.qhits.ensure((size_t)b.nq + 2);
+    launch_cap(b.korder.p, b.dev.d_off.p, b.nq, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, c->st);
+    // Split the batch into query sub-ranges whose seed hits fit the per-pass budget (keys, sort
+    // scratch and group arrays are sized by it; 32-bit hit ordinals need < 2^32 per pass).
+    std::vector<unsigned long long> qh(b.nq);
+    HIP_CHECK(hipMemcpyAsync(qh.data(), b.qhits.p, (size_t)b.nq * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
+    HIP_CHECK(hipStreamSynchronize(c->st));
+    const unsigned long long budget = c->max_hits_per_pass;
+    u32 qa = 0;
+    while (qa < b.nq) {
+        unsigned long long acc = 0;
+        u32 qb = qa;
+        while (qb < b.nq && (qb == qa || acc + qh[qb] <= budget)) acc += qh[qb++];
+        if (acc >= 0xFFFFFFF0ull) throw SoError("a single query visits >= 2^32 index entries in one chunk: lower -c");
+        if (acc) seed_pass(c, b, ci, b.h_off[qa] + qa, b.h_off[qb] + qb, wall(), sc);
+        qa = qb;
+    }
+}
+
+// one hit-budgeted pass of the seed stage: queries whose packed positions lie in [p_lo, p_hi)
+void seed_pass(so_ctx* c, Batch& b, int ci, u32 p_lo, u32 p_hi, double t0, StageClock& sc) {
+    ChunkIndex& ch = *c->chunks[ci];
+    const int AS = c->cfg.A * c->cfg.S;
+    const u32 Ppad = b.dev.Ppad;
+    const size_t T = (size_t)AS * Ppad;
+    const u32 nseq_chunk = (u32)(ch.seq_hi - ch.seq_lo);
+    u32* qcnt = b.ccnt.p + (size_t)ci * b.nq;
+    launch_effcnt(b.mark.p, b.scnt.p, Ppad, AS, p_lo, p_hi, b.eff.p, b.nz.p, c->st);
     const u32* dH = scan_u32(b.eff.p, b.hoff.p, T, false, c->d_scan_tmp.p, c->st);
-    // NOTE: the scan's total lives in d_scan_tmp; fetch before the next scan overwrites it
-    u64 Hcheck = 0;
-    const u32 H = d2h_u32(c, dH);
-    (void)Hcheck;
+    const u32 H = d2h_u32(c, dH);  // the scan's total lives in d_scan_tmp: fetch before the next scan
     const u32* dK = scan_u32(b.nz.p, b.cidx.p, T, false, c->d_scan_tmp.p, c->st);
     const u32 K = d2h_u32(c, dK);
     sc.lap("seed.bounds_cap_scan");
@@ -724,7 +749,6 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
         c->cnt.seed_ms += (wall() - t0) * 1e3;
         return;
     }
-    if ((size_t)H > c->max_hits_per_pass * 3) throw SoError("seed hits of one (batch, chunk) exceed the pass budget; lower SOHIT_BATCH");
     // key layout
     KeyLayout kl;
     kl.bq = ceil_log2((u64)b.nq + 1);
@@ -837,11 +861,32 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     c->cnt.group_ms += (wall() - t1) * 1e3;
 }
 
+// growable result array handed to the caller as-is (so_free_hits == free): no zero-fill, no final copy
+struct HitBuf {
+    so_hit* p = nullptr;
+    size_t n = 0, cap = 0;
+    void grow(size_t extra) {
+        if (n + extra <= cap) return;
+        size_t nc = std::max<size_t>(n + extra, cap + cap / 2 + 1024);
+        so_hit* np_ = (so_hit*)realloc(p, nc * sizeof(so_hit));
+        if (!np_) throw SoError("out of host memory for the result rows");
+        p = np_;
+        cap = nc;
+    }
+    so_hit* release() {
+        so_hit* r = p ? p : (so_hit*)malloc(sizeof(so_hit));
+        p = nullptr;
+        n = cap = 0;
+        return r;
+    }
+    ~HitBuf() { free(p); }
+};
+
 struct HostRow {
     int v[12];
 };
 
-void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
+void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     const double t0 = wall();
     StageClock sc(c);
     const int nchunks = (int)c->chunks.size();
@@ -948,14 +993,32 @@ void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
     if (NO) {
         b.outrec.ensure(12 * (size_t)NO + 16);
         launch_emit_hits(b.tasks.p, b.ares.p, b.toff.p, b.sel.p, b.nout.p, b.ooff.p, b.bits.p, nq, b.outrec.p, c->st);
-        std::vector<HostRow> rows(NO);
-        HIP_CHECK(hipMemcpyAsync(rows.data(), b.outrec.p, 12 * (size_t)NO * sizeof(int), hipMemcpyDeviceToHost, c->st));
+        // pinned staging buffer: pageable D2H runs at ~1 GB/s, pinned at PCIe speed
+        if (c->pinned_cap < (size_t)NO * sizeof(HostRow)) {
+            if (c->pinned) (void)hipHostFree(c->pinned);
+            c->pinned_cap = (size_t)NO * sizeof(HostRow) * 5 / 4 + 4096;
+            HIP_CHECK(hipHostMalloc(&c->pinned, c->pinned_cap, hipHostMallocDefault));
+        }
+        const HostRow* rows = (const HostRow*)c->pinned;
+        sc.lap("phase2.emit_alloc");
+        HIP_CHECK(hipMemcpyAsync(c->pinned, b.outrec.p, 12 * (size_t)NO * sizeof(int), hipMemcpyDeviceToHost, c->st));
         HIP_CHECK(hipStreamSynchronize(c->st));
+        sc.lap("phase2.emit_d2h");
         const i64 D = c->ref.N;
-        for (u32 i = 0; i < NO; ++i) {
+        // pow(2, -bit) (bit2e, fsearch.py:1086) tabulated once with libm: exact powers of two, 0 past the subnormals
+        static std::vector<double> p2;
+        if (p2.empty()) {
+            p2.resize(1200);
+            for (int k = 0; k < 1200; ++k) p2[k] = p_pow(2, (double)(-k));
+        }
+        const size_t base = out.n;
+        out.grow(NO);
+        so_hit* dst = out.p + base;
+        const double expect = c->expect;
+        std::atomic<i64> dropped(0);
+        parallel_for((i64)NO, [&](i64 i) {
             const int* v = rows[i].v;
             so_hit h;
-            memset(&h, 0, sizeof h);
             h.qidx = b.q_lo + v[0];
             h.sidx = v[1];
             h.aln = v[2], h.mis = v[3], h.gap = v[4], h.qst = v[5], h.qed = v[6], h.sst = v[7], h.sed = v[8], h.bit = v[9];
@@ -965,15 +1028,26 @@ void phase2(so_ctx* c, Batch& b, std::vector<so_hit>& out) {
             // idy: one += 1. per identical column, then idy *= (100. / AL) (fsearch.py:1458-1459, 1471)
             h.identity = (double)h.matches * (100. / (double)h.aln);
             // bit2e (1086): D * len(sqi) * len(sqj) * pow(2, -bit)
-            h.evalue = (double)(D * (i64)h.qlen * (i64)h.slen) * p_pow(2, (double)(-h.bit));
-            if (h.evalue <= c->expect) out.push_back(h);  // entry_point re-check (3234)
+            const double pw = (h.bit >= 0 && h.bit < 1200) ? p2[h.bit] : p_pow(2, (double)(-h.bit));
+            h.evalue = (double)(D * (i64)h.qlen * (i64)h.slen) * pw;
+            if (!(h.evalue <= expect)) dropped.fetch_add(1);
+            dst[i] = h;
+        });
+        out.n = base + NO;
+        if (dropped.load()) {
+            // entry_point re-checks e <= expect (3234).  k_stop_round applied the same test to the same
+            // doubles, so this never fires; kept as the reference has it.
+            size_t wpos = base;
+            for (size_t k = base; k < base + NO; ++k)
+                if (out.p[k].evalue <= expect) out.p[wpos++] = out.p[k];
+            out.n = wpos;
         }
     }
-    sc.lap("phase2.emit_d2h");
+    sc.lap("phase2.emit_host");
     c->cnt.phase2_ms += (wall() - t0) * 1e3;
 }
 
-void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, std::vector<so_hit>& out) {
+void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
     if (!c->ref_loaded) throw SoError("so_search: no reference loaded");
     if (!c->qry_loaded) throw SoError("so_search: no queries loaded");
     build_index(c);
@@ -987,6 +1061,7 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, std::vector<so_hit>& out) {
     c->masked.clear();
     const int nchunks = (int)c->chunks.size();
     if (const char* e = getenv("SOHIT_BATCH")) c->max_batch = (u32)std::max(1, atoi(e));
+    if (const char* e = getenv("SOHIT_MAX_HITS")) c->max_hits_per_pass = (size_t)std::max(1ll, atoll(e));
     for (i64 b0 = st; b0 < ed; b0 += c->max_batch) {
         const i64 b1 = std::min<i64>(ed, b0 + c->max_batch);
         if (!c->batch) c->batch = std::make_shared<Batch>();
@@ -1015,7 +1090,7 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, std::vector<so_hit>& out) {
                 c->masked.emplace_back((const char*)b.h_res.data() + b.h_off[i], (size_t)(b.h_off[i + 1] - b.h_off[i]));
         }
     }
-    c->cnt.rows += (i64)out.size();
+    c->cnt.rows += (i64)out.n;
     c->cnt.total_ms += (wall() - t0) * 1e3;
 }
 
@@ -1169,6 +1244,7 @@ void so_destroy(so_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->st) (void)hipStreamSynchronize(c->st);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->st) (void)hipStreamDestroy(c->st);
@@ -1225,13 +1301,10 @@ int so_search_loaded(so_ctx* c, int64_t q_lo, int64_t q_hi, so_hit** hits, int64
         if (!hits || !n_hits) throw SoError("so_search: output pointers are NULL");
         *hits = nullptr;
         *n_hits = 0;
-        std::vector<so_hit> out;
+        HitBuf out;
         search_loaded(c, q_lo, q_hi, out);
-        so_hit* p = (so_hit*)malloc(std::max<size_t>(1, out.size()) * sizeof(so_hit));
-        if (!p) throw SoError("out of host memory");
-        if (!out.empty()) memcpy(p, out.data(), out.size() * sizeof(so_hit));
-        *hits = p;
-        *n_hits = (int64_t)out.size();
+        *n_hits = (int64_t)out.n;
+        *hits = out.release();
     });
 }
 

@@ -11,25 +11,56 @@
 // d = j - i + 16 in [0, 32); anti-diagonal step t = 2i + d.  At step t lane l owns d = 2l + (t & 1):
 //   left (i, d-1) and up (i-1, d+1) were produced at step t-1 (own lane or the DPP-row neighbour),
 //   diag (i-1, d) at step t-2 by the same lane.
-// So every step is one row_shr / row_shl DPP move plus ~25 VALU ops, no LDS traffic for the DP
-// state; LDS holds only the 24x24 score table.  2-bit traces go to a per-task scratch slab.
+// One loop iteration = one row per lane (its even and odd cell), one DPP move per cell, residues
+// streamed through 8-byte register windows, no LDS traffic for the DP state; LDS holds only the
+// score table.  2-bit traces go to a per-task scratch slab; the traceback caches its trace word.
 #include "common.h"
 #include "kernels.h"
 
 #define KB 16  // kbound
 
-__device__ __forceinline__ int dpp_row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); }
-__device__ __forceinline__ int dpp_row_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true); }
+// neighbour lane's value inside the 16-lane DPP row; lanes without a source keep `oob`
+__device__ __forceinline__ int dpp_row_shr1(int oob, int v) { return __builtin_amdgcn_update_dpp(oob, v, 0x111, 0xF, 0xF, false); }
+__device__ __forceinline__ int dpp_row_shl1(int oob, int v) { return __builtin_amdgcn_update_dpp(oob, v, 0x101, 0xF, 0xF, false); }
+
+__device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global load
+    u64 w;
+    __builtin_memcpy(&w, p, 8);
+    return w;
+}
+
+#define GO (-11)
+#define GE (-1)
+
+// One band cell.  I / D arrive ready-made from the producing cells (their score plus the gap cost
+// that applies when stepping out of them: extend iff their own trace is that gap direction, else
+// open); Bd = diagonal neighbour's score.  Publishes B, Iout (for the cell to the right),
+// Dout (for the cell below) and the 2-bit trace code: 0 '*', 1 '\\', 2 '-', 3 '|'.
+__device__ __forceinline__ void dp_cell(bool valid, int I, int D, int Bd, int s, int& B, int& Iout, int& Dout, int& trc) {
+    const int M = Bd + s;
+    int b = max(max(I, D), max(M, 0));
+    const bool isM = (b == M), isI = (b == I), isD = (b == D);
+    int tc = isM ? 1 : (isI ? 2 : (isD ? 3 : 0));
+    b = valid ? b : 0;
+    tc = valid ? tc : 0;
+    B = b;
+    trc = tc;
+    Iout = b + ((tc == 2) ? GE : GO);
+    Dout = b + ((tc == 3) ? GE : GO);
+}
 
 // trace codes: 0 '*' (stop), 1 '\\' (diag), 2 '-' (left), 3 '|' (up)
 __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 ntasks,
-                                               const u8* __restrict__ q_res,
-                                               const u8* __restrict__ q_scls, const u32* __restrict__ qoff,
-                                               const u8* __restrict__ r_res, const u8* __restrict__ r_scls,
-                                               const u32* __restrict__ roff, const signed char* __restrict__ b62g,
-                                               u32* __restrict__ trace, u32 trace_stride, AlnRes* __restrict__ out) {
-    __shared__ signed char s_b62[SCLS_N * SCLS_N];
-    for (int i = threadIdx.x; i < SCLS_N * SCLS_N; i += 256) s_b62[i] = b62g[i];
+                                               const u8* __restrict__ q_res, const u8* __restrict__ q_scls,
+                                               const u32* __restrict__ qoff, const u8* __restrict__ r_res,
+                                               const u8* __restrict__ r_scls, const u32* __restrict__ roff,
+                                               const signed char* __restrict__ b62g, u32* __restrict__ trace, u32 trace_stride,
+                                               AlnRes* __restrict__ out) {
+    __shared__ signed char s_b62[32 * 36];  // rows of 36 bytes: any two 5-bit classes index inside; rows rotate over the banks
+    for (int i = threadIdx.x; i < 32 * 36; i += 256) {
+        const int a = i / 36, b = i % 36;
+        s_b62[i] = (a < SCLS_N && b < SCLS_N) ? b62g[a * SCLS_N + b] : (signed char)-4;
+    }
     __syncthreads();
     const u32 tid = blockIdx.x * 16u + (threadIdx.x >> 4);
     const int l = threadIdx.x & 15;
@@ -44,62 +75,94 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     const int ncols = swp ? lb : la, nrows = swp ? la : lb;
     const u8* ccls = swp ? (r_scls + sb + qj) : (q_scls + qb + qi);
     const u8* rcls = swp ? (q_scls + qb + qi) : (r_scls + sb + qj);
-    const u8* craw = swp ? (r_res + sb + qj) : (q_res + qb + qi);
-    const u8* rraw = swp ? (q_res + qb + qi) : (r_res + sb + qj);
     const int R = min(nrows, ncols + KB);  // rows beyond ncols + 16 have an empty band
     u32* tr = trace + (size_t)tid * trace_stride;
 
-    int pv = 0, pv2 = 0;  // own packed results (B << 2 | trace) of steps t-1, t-2
+    // Per iteration m every lane handles ONE row i = m - l and its two band cells
+    //   even half: d = 2l   (j0 = i + 2l - 16)      odd half: d = 2l + 1   (j1 = j0 + 1)
+    // even: left = lane l-1's odd cell of iteration m-1, up = own odd cell of m-1, diag = own even cell of m-1
+    // odd : left = own even cell of m,               up = lane l+1's even cell of m, diag = own odd cell of m-1
+    int Be = 0, Bo = 0, Io_out = GO, Do_out = GO;  // results of iteration m-1
     int best = 0, bi = 0, bj = 0, ncell = 0;
     u32 tw = 0;
-    int rc = 0, cc = 0;  // current row / column residue classes
-    const int t_end = 2 * R + 31;
-    for (int t = 2 + KB; t <= t_end; ++t) {
-        const int par = t & 1;
-        const int d = 2 * l + par;
-        const int i = (t - d) >> 1;
-        const int j = i + d - KB;
-        const int nbL = dpp_row_shr1(pv);
-        const int nbR = dpp_row_shl1(pv);
-        const int left = par ? pv : nbL;
-        const int up = par ? nbR : pv;
-        const int dg = pv2;
-        const bool valid = (i >= 1) && (i <= R) && (j >= 1) && (j <= ncols);
-        int B = 0, trc = 0;
-        if (valid) {
-            // residues change every other step; reloading both keeps the code simple (L1 hits)
-            rc = rcls[i - 1];
-            cc = ccls[j - 1];
-            const int I = (left >> 2) + (((left & 3) == 2) ? -1 : -11);
-            const int M = (dg >> 2) + s_b62[rc * SCLS_N + cc];
-            const int D = (up >> 2) + (((up & 3) == 3) ? -1 : -11);
-            B = max(max(0, I), max(M, D));
-            trc = (B == M) ? 1 : (B == I) ? 2 : (B == D) ? 3 : 0;
-            ++ncell;
-            if (B > best) best = B, bi = i, bj = j;
+    u64 rw = 0, cw = 0;
+    const int m_end = R + 15;
+    for (int m = 9; m <= m_end; ++m) {
+        const int i = m - l;
+        const int j0 = i + 2 * l - KB;
+        const bool row_ok = (u32)(i - 1) < (u32)R;
+        // residue windows: one row class per iteration, two consecutive column classes
+        if (row_ok && ((((i - 1) & 7) == 0) || m == 9)) {  // (a lane's first row need not start an 8-row block)
+            const int a = (i - 1) & ~7;
+            rw = load8u(rcls + a) >> (8 * ((i - 1) - a));
         }
-        if (i >= 1 && i <= R) {
-            tw |= (u32)trc << ((((i - 1) & 7) << 2) + (par << 1));
-            if (par && ((((i - 1) & 7) == 7) || i == R)) {
+        if ((m & 3) == 0 || m == 9) {
+            const int base = j0 - 1;
+            if (base >= 0) cw = base < ncols ? load8u(ccls + base) : 0ull;
+            else cw = base > -8 ? (load8u(ccls) << (8 * (-base))) : 0ull;
+        }
+        const int rc = (int)(rw & 31u);
+        const int cc0 = (int)(cw & 31u), cc1 = (int)((cw >> 8) & 31u);
+        if (row_ok) rw >>= 8;
+        cw >>= 8;
+        const bool ve = row_ok && ((u32)(j0 - 1) < (u32)ncols);
+        const bool vo = row_ok && ((u32)j0 < (u32)ncols);
+        const int s0 = s_b62[rc * 36 + cc0], s1 = s_b62[rc * 36 + cc1];
+        int nBe, Ie_out, De_out, te, nBo, nIo, nDo, to;
+        dp_cell(ve, dpp_row_shr1(GO, Io_out), Do_out, Be, s0, nBe, Ie_out, De_out, te);
+        dp_cell(vo, Ie_out, dpp_row_shl1(GO, De_out), Bo, s1, nBo, nIo, nDo, to);
+        Be = nBe, Bo = nBo, Io_out = nIo, Do_out = nDo;
+        ncell += (ve ? 1 : 0) + (vo ? 1 : 0);
+        if (nBe > best) best = nBe, bi = i, bj = j0;          // row-major: the even cell (smaller j) first
+        if (nBo > best) best = nBo, bi = i, bj = j0 + 1;
+        if (row_ok) {
+            tw |= (u32)(te | (to << 2)) << (((i - 1) & 7) << 2);
+            if (((i - 1) & 7) == 7 || i == R) {
                 tr[((i - 1) >> 3) * 16 + l] = tw;
                 tw = 0;
             }
         }
-        pv2 = pv;
-        pv = (B << 2) | trc;
     }
     // reduce (best, bi, bj) over the 16 lanes: max score, then smallest i, then smallest j
-    for (int m = 8; m > 0; m >>= 1) {
-        const int ob = __shfl_xor(best, m, 16), oi = __shfl_xor(bi, m, 16), oj = __shfl_xor(bj, m, 16);
-        const int oc = __shfl_xor(ncell, m, 16);
+    for (int msk = 8; msk > 0; msk >>= 1) {
+        const int ob = __shfl_xor(best, msk, 16), oi = __shfl_xor(bi, msk, 16), oj = __shfl_xor(bj, msk, 16);
+        const int oc = __shfl_xor(ncell, msk, 16);
         ncell += oc;
         if (ob > best || (ob == best && (oi < bi || (oi == bi && oj < bj)))) best = ob, bi = oi, bj = oj;
     }
-    // make the trace words of all 16 lanes visible to the lane that walks them
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    // the traceback runs in k_traceback (one thread per alignment: 64 walks per wave instead of 4)
     if (l != 0) return;
+    AlnRes r;
+    r.maxscore = best, r.aln = 0, r.matches = 0, r.gap = 0, r.cells = ncell, r.pad = 0;
+    r.qst = bi, r.qed = bj, r.sst = 0, r.sed = 0;  // (i_max, j_max) parked for k_traceback
+    out[slot] = r;
+}
+
+// Traceback from the best cell until a stop cell (1418-1443), walking through row 0 ('-'), column 0
+// ('|') and the left boundary cell (i, i-17) ('|'), plus the alignment statistics (1454-1471).
+// One thread per alignment; the 2-bit traces come from the slab k_align wrote in the same launch
+// sequence (kernel boundary = visibility), with the current trace word cached in a register.
+__global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 ntasks,
+                                                  const u8* __restrict__ q_res, const u32* __restrict__ qoff,
+                                                  const u8* __restrict__ r_res, const u32* __restrict__ roff,
+                                                  const u32* __restrict__ trace, u32 trace_stride, AlnRes* __restrict__ out) {
+    const u32 tid = blockIdx.x * 64u + threadIdx.x;
+    if (tid >= ntasks) return;
+    const u32 slot = ridx ? ridx[tid] : tid;
+    const AlnTask tk = tasks[slot];
+    AlnRes r = out[slot];
+    const u32 qb = qoff[tk.q], sb = roff[tk.subj];
+    const int lq = min((int)(qoff[tk.q + 1] - qb), (int)tk.qe), ls = min((int)(roff[tk.subj + 1] - sb), (int)tk.se);
+    const int qi = min((int)tk.qi, lq), qj = min((int)tk.qj, ls);
+    const int la = lq - qi, lb = ls - qj;
+    const bool swp = !(la < lb);
+    const u8* craw = swp ? (r_res + sb + qj) : (q_res + qb + qi);
+    const u8* rraw = swp ? (q_res + qb + qi) : (r_res + sb + qj);
+    const u32* tr = trace + (size_t)tid * trace_stride;
+    const int bi = r.qst, bj = r.qed;
     int i = bi, j = bj, AL = 0, matches = 0, gaps = 0, run = 0, rtype = 0;
+    int wkey = -1;  // (8-row block, lane) of the cached trace word
+    u32 wv = 0;
     while (i > 0 || j > 0) {
         int tc;
         if (i == 0) tc = 2;
@@ -107,7 +170,11 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
         else {
             const int d = j - i + KB;
             if (d < 0) tc = 3;  // left boundary cell (i, i-17): '|'
-            else tc = (int)((tr[((i - 1) >> 3) * 16 + (d >> 1)] >> ((((i - 1) & 7) << 2) + ((d & 1) << 1))) & 3u);
+            else {
+                const int key = ((i - 1) >> 3) * 16 + (d >> 1);
+                if (key != wkey) wkey = key, wv = tr[key];
+                tc = (int)((wv >> ((((i - 1) & 7) << 2) + ((d & 1) << 1))) & 3u);
+            }
         }
         if (tc == 0) break;
         ++AL;
@@ -124,8 +191,7 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
             else --i;
         }
     }
-    AlnRes r;
-    r.maxscore = best, r.aln = AL, r.matches = matches, r.gap = gaps, r.cells = ncell, r.pad = 0;
+    r.aln = AL, r.matches = matches, r.gap = gaps;
     if (swp) {  // rows = query, columns = subject (1473-1474)
         r.qst = i + qi, r.qed = bi + qi, r.sst = j + qj, r.sed = bj + qj;
     } else {
@@ -146,4 +212,6 @@ void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q
     if (!ntasks) return;
     hipLaunchKernelGGL(k_align, dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_res, q_scls, qoff, r_res, r_scls, roff,
                        b62g, trace, trace_stride, out);
+    hipLaunchKernelGGL(k_traceback, dim3((ntasks + 63) / 64), dim3(64), 0, st, tasks, ridx, ntasks, q_res, qoff, r_res, roff, trace,
+                       trace_stride, out);
 }

@@ -113,9 +113,11 @@ __global__ __launch_bounds__(64) void k_ksc_order(const u8* __restrict__ q_scls,
 
 // ---- high-frequency cap (fsearch.py:2667-2677) ---------------------------------------------------
 __global__ __launch_bounds__(64) void k_cap(const u32* __restrict__ korder, const u32* __restrict__ qoff, u32 nq, int mink,
-                                            const u32* __restrict__ pcnt, i64 threshold, u8* __restrict__ mark) {
+                                            const u32* __restrict__ pcnt, i64 threshold, u8* __restrict__ mark,
+                                            unsigned long long* __restrict__ qhits) {
     const u32 q = blockIdx.x * 64u + threadIdx.x;
     if (q >= nq) return;
+    qhits[q] = 0;
     const u32 base = qoff[q];
     const int ql = (int)(qoff[q + 1] - base);
     const int nk = ql - mink + 1;
@@ -129,15 +131,16 @@ __global__ __launch_bounds__(64) void k_cap(const u32* __restrict__ korder, cons
         cum += pcnt[pbase + pos];
         mark[pbase + pos] = 1;
     }
+    qhits[q] = (unsigned long long)cum;  // seed hits this query will visit in this chunk
 }
 
 // ---- effective per-seed hit counts + compaction of non-empty seeds --------------------------------
 __global__ __launch_bounds__(256) void k_effcnt(const u8* __restrict__ mark, const u32* __restrict__ scnt, u32 Ppad, int AS,
-                                                u32* __restrict__ eff, u32* __restrict__ nz) {
+                                                u32 p_lo, u32 p_hi, u32* __restrict__ eff, u32* __restrict__ nz) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= (size_t)AS * Ppad) return;
     const u32 p = (u32)(t % Ppad);
-    u32 c = mark[p] ? scnt[t] : 0u;
+    u32 c = (mark[p] && p >= p_lo && p < p_hi) ? scnt[t] : 0u;  // [p_lo, p_hi): packed range of the query sub-range
     eff[t] = c;
     nz[t] = c ? 1u : 0u;
 }
@@ -333,15 +336,16 @@ void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, int mink, const
     hipLaunchKernelGGL(k_ksc_order, dim3((nq + 63) / 64), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, ksc, korder);
 }
 
-void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark, hipStream_t st) {
+void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark,
+                unsigned long long* qhits, hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_cap, dim3((nq + 63) / 64), dim3(64), 0, st, korder, qoff, nq, mink, pcnt, threshold, mark);
+    hipLaunchKernelGGL(k_cap, dim3((nq + 63) / 64), dim3(64), 0, st, korder, qoff, nq, mink, pcnt, threshold, mark, qhits);
 }
 
-void launch_effcnt(const u8* mark, const u32* scnt, u32 Ppad, int AS, u32* eff, u32* nz, hipStream_t st) {
+void launch_effcnt(const u8* mark, const u32* scnt, u32 Ppad, int AS, u32 p_lo, u32 p_hi, u32* eff, u32* nz, hipStream_t st) {
     size_t T = (size_t)AS * Ppad;
     if (!T) return;
-    hipLaunchKernelGGL(k_effcnt, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, mark, scnt, Ppad, AS, eff, nz);
+    hipLaunchKernelGGL(k_effcnt, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, mark, scnt, Ppad, AS, p_lo, p_hi, eff, nz);
 }
 
 void launch_compact_seeds(const u32* eff, const u32* hoff, const u32* cidx, const u32* sbeg, const u32* q_pseq, const u32* qoff,

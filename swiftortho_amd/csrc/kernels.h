@@ -39,8 +39,9 @@ void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* start, u32 N
                    hipStream_t st);
 void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, int mink, const signed char* b62c, int* ksc, u32* korder,
                       hipStream_t st);
-void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark, hipStream_t st);
-void launch_effcnt(const u8* mark, const u32* scnt, u32 Ppad, int AS, u32* eff, u32* nz, hipStream_t st);
+void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark,
+                unsigned long long* qhits, hipStream_t st);
+void launch_effcnt(const u8* mark, const u32* scnt, u32 Ppad, int AS, u32 p_lo, u32 p_hi, u32* eff, u32* nz, hipStream_t st);
 void launch_compact_seeds(const u32* eff, const u32* hoff, const u32* cidx, const u32* sbeg, const u32* q_pseq, const u32* qoff,
                           u32 Ppad, int AS, const KeyLayout& kl, u32* cs_hoff, u32* cs_beg, u64* cs_kbase, hipStream_t st);
 u32 lookup_num_blocks(u32 H);

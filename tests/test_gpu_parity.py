@@ -205,6 +205,14 @@ def test_query_subrange_and_small_batches(fs, oracle, tmp_path, monkeypatch):
     oracle_vs_gpu(fs, oracle, synthprot.synthprot(500, 120, 82), kw, tmp_path, sub=(100, 333))
 
 
+def test_hit_budget_splits_passes(fs, oracle, tmp_path, monkeypatch):
+    """a tiny per-pass hit budget forces many query sub-range passes per (batch, chunk)"""
+    from swiftortho_amd import synthprot
+    monkeypatch.setenv("SOHIT_MAX_HITS", "20000")
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=150, step=1, v=500, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, synthprot.synthprot(400, 150, 84), kw, tmp_path)
+
+
 def test_exact_threshold_replay(fs, oracle, monkeypatch):
     """the rare exact get_mu_sd replay path gives the same threshold as the integer-sum path"""
     from swiftortho_amd import synthprot
