@@ -23,10 +23,17 @@
 __device__ __forceinline__ int dpp_row_shr1(int oob, int v) { return __builtin_amdgcn_update_dpp(oob, v, 0x111, 0xF, 0xF, false); }
 __device__ __forceinline__ int dpp_row_shl1(int oob, int v) { return __builtin_amdgcn_update_dpp(oob, v, 0x101, 0xF, 0xF, false); }
 
-__device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global load
-    u64 w;
-    __builtin_memcpy(&w, p, 8);
+__device__ __forceinline__ u32 load4u(const u8* p) {  // unaligned 4-byte global load
+    u32 w;
+    __builtin_memcpy(&w, p, 4);
     return w;
+}
+
+// class bytes [idx, idx + 4) of a sequence of `len` classes; bytes outside [0, len) are don't-care
+// (they only ever feed invalid cells) but the load never leaves the padded array
+__device__ __forceinline__ u32 win4(const u8* __restrict__ base, int idx, int len) {
+    if (idx >= 0) return idx < len ? load4u(base + idx) : 0u;
+    return idx > -4 ? load4u(base) << (8 * (-idx)) : 0u;
 }
 
 #define GO (-11)
@@ -35,18 +42,19 @@ __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global
 // One band cell.  I / D arrive ready-made from the producing cells (their score plus the gap cost
 // that applies when stepping out of them: extend iff their own trace is that gap direction, else
 // open); Bd = diagonal neighbour's score.  Publishes B, Iout (for the cell to the right),
-// Dout (for the cell below) and the 2-bit trace code: 0 '*', 1 '\\', 2 '-', 3 '|'.
-__device__ __forceinline__ void dp_cell(bool valid, int I, int D, int Bd, int s, int& B, int& Iout, int& Dout, int& trc) {
+// Dout (for the cell below) and the 2-bit trace code: 0 '*', 1 '\\', 2 '-', 3 '|'
+// (priority diag > left > up, fsearch.py:1404-1411).
+__device__ __forceinline__ void dp_cell(bool valid, int I, int D, int Bd, int s, int& B, int& Iout, int& Dout, u32& trc) {
     const int M = Bd + s;
-    int b = max(max(I, D), max(M, 0));
-    const bool isM = (b == M), isI = (b == I), isD = (b == D);
-    int tc = isM ? 1 : (isI ? 2 : (isD ? 3 : 0));
-    b = valid ? b : 0;
-    tc = valid ? tc : 0;
+    const int b0 = max(max(I, D), max(M, 0));
+    const bool isM = valid && (b0 == M);
+    const bool eI = valid && !isM && (b0 == I);
+    const bool eD = valid && !isM && !eI && (b0 == D);
+    const int b = valid ? b0 : 0;
     B = b;
-    trc = tc;
-    Iout = b + ((tc == 2) ? GE : GO);
-    Dout = b + ((tc == 3) ? GE : GO);
+    trc = isM ? 1u : (eI ? 2u : (eD ? 3u : 0u));
+    Iout = b + (eI ? GE : GO);
+    Dout = b + (eD ? GE : GO);
 }
 
 // trace codes: 0 '*' (stop), 1 '\\' (diag), 2 '-' (left), 3 '|' (up)
@@ -78,50 +86,64 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     const int R = min(nrows, ncols + KB);  // rows beyond ncols + 16 have an empty band
     u32* tr = trace + (size_t)tid * trace_stride;
 
-    // Per iteration m every lane handles ONE row i = m - l and its two band cells
-    //   even half: d = 2l   (j0 = i + 2l - 16)      odd half: d = 2l + 1   (j1 = j0 + 1)
+    // Iteration m: every lane handles ONE row i = m - l and its two band cells
+    //   even cell: d = 2l   (column j0 = m + l - 16)        odd cell: d = 2l + 1   (column j0 + 1)
     // even: left = lane l-1's odd cell of iteration m-1, up = own odd cell of m-1, diag = own even cell of m-1
     // odd : left = own even cell of m,               up = lane l+1's even cell of m, diag = own odd cell of m-1
+    // Per iteration a lane consumes one new row class (row i) and one new column class (column j0 + 1;
+    // column j0's class is last iteration's).  Both stream through 4-byte register windows that are
+    // refilled every 4th iteration on a wave-uniform schedule.
     int Be = 0, Bo = 0, Io_out = GO, Do_out = GO;  // results of iteration m-1
-    int best = 0, bi = 0, bj = 0, ncell = 0;
+    u32 keyE = 0, keyO = 0;                        // best even / odd cell: score << 13 | (8191 - i)
+    int ncell = 0;
     u32 tw = 0;
-    u64 rw = 0, cw = 0;
+    u32 cc0 = 0;
     const int m_end = R + 15;
-    for (int m = 9; m <= m_end; ++m) {
-        const int i = m - l;
-        const int j0 = i + 2 * l - KB;
-        const bool row_ok = (u32)(i - 1) < (u32)R;
-        // residue windows: one row class per iteration, two consecutive column classes
-        if (row_ok && ((((i - 1) & 7) == 0) || m == 9)) {  // (a lane's first row need not start an 8-row block)
-            const int a = (i - 1) & ~7;
-            rw = load8u(rcls + a) >> (8 * ((i - 1) - a));
-        }
-        if ((m & 3) == 0 || m == 9) {
-            const int base = j0 - 1;
-            if (base >= 0) cw = base < ncols ? load8u(ccls + base) : 0ull;
-            else cw = base > -8 ? (load8u(ccls) << (8 * (-base))) : 0ull;
-        }
-        const int rc = (int)(rw & 31u);
-        const int cc0 = (int)(cw & 31u), cc1 = (int)((cw >> 8) & 31u);
-        if (row_ok) rw >>= 8;
-        cw >>= 8;
-        const bool ve = row_ok && ((u32)(j0 - 1) < (u32)ncols);
-        const bool vo = row_ok && ((u32)j0 < (u32)ncols);
-        const int s0 = s_b62[rc * 36 + cc0], s1 = s_b62[rc * 36 + cc1];
-        int nBe, Ie_out, De_out, te, nBo, nIo, nDo, to;
-        dp_cell(ve, dpp_row_shr1(GO, Io_out), Do_out, Be, s0, nBe, Ie_out, De_out, te);
-        dp_cell(vo, Ie_out, dpp_row_shl1(GO, De_out), Bo, s1, nBo, nIo, nDo, to);
-        Be = nBe, Bo = nBo, Io_out = nIo, Do_out = nDo;
-        ncell += (ve ? 1 : 0) + (vo ? 1 : 0);
-        if (nBe > best) best = nBe, bi = i, bj = j0;          // row-major: the even cell (smaller j) first
-        if (nBo > best) best = nBo, bi = i, bj = j0 + 1;
-        if (row_ok) {
-            tw |= (u32)(te | (to << 2)) << (((i - 1) & 7) << 2);
-            if (((i - 1) & 7) == 7 || i == R) {
-                tr[((i - 1) >> 3) * 16 + l] = tw;
-                tw = 0;
+    for (int m0 = 8; m0 <= m_end; m0 += 4) {
+        u32 rw = win4(rcls, m0 - l - 1, nrows);
+        u32 cw = win4(ccls, m0 + l - KB, ncols);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = m0 + k;
+            const int i = m - l;
+            const int j0 = m + l - KB;
+            const u32 rc = rw & 31u, cc1 = cw & 31u;
+            rw >>= 8;
+            cw >>= 8;
+            const bool row_ok = (u32)(i - 1) < (u32)R;
+            const bool ve = row_ok && ((u32)(j0 - 1) < (u32)ncols);
+            const bool vo = row_ok && ((u32)j0 < (u32)ncols);
+            const int s0 = s_b62[rc * 36u + cc0], s1 = s_b62[rc * 36u + cc1];
+            cc0 = cc1;
+            int nBe, Ie_out, De_out, nBo, nIo, nDo;
+            u32 te, to;
+            dp_cell(ve, dpp_row_shr1(GO, Io_out), Do_out, Be, s0, nBe, Ie_out, De_out, te);
+            dp_cell(vo, Ie_out, dpp_row_shl1(GO, De_out), Bo, s1, nBo, nIo, nDo, to);
+            Be = nBe, Bo = nBo, Io_out = nIo, Do_out = nDo;
+            ncell += (ve ? 1 : 0) + (vo ? 1 : 0);
+            // first strict maximum in row-major order == largest (score, 8191 - i) key; keys of invalid cells are < any valid one
+            const u32 rk = (u32)(8191 - i) & 8191u;
+            keyE = max(keyE, ((u32)nBe << 13) | rk);
+            keyO = max(keyO, ((u32)nBo << 13) | rk);
+            if (row_ok) {
+                tw |= (te | (to << 2)) << (((u32)(i - 1) & 7u) << 2);
+                if ((((u32)(i - 1)) & 7u) == 7u || i == R) {
+                    tr[((u32)(i - 1) >> 3) * 16u + (u32)l] = tw;
+                    tw = 0;
+                }
             }
         }
+    }
+    // lane best: max score, then smallest i, then the even cell (smaller j)
+    int best, bi, bj;
+    {
+        const int sE = (int)(keyE >> 13), sO = (int)(keyO >> 13);
+        const int iE = 8191 - (int)(keyE & 8191u), iO = 8191 - (int)(keyO & 8191u);
+        const bool takeO = (sO > sE) || (sO == sE && iO < iE);
+        best = takeO ? sO : sE;
+        bi = takeO ? iO : iE;
+        bj = bi + 2 * l - KB + (takeO ? 1 : 0);
+        if (best == 0) bi = 0, bj = 0;  // nothing scored: (i_max, j_max) stay (0, 0) (1391)
     }
     // reduce (best, bi, bj) over the 16 lanes: max score, then smallest i, then smallest j
     for (int msk = 8; msk > 0; msk >>= 1) {
