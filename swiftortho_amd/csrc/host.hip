@@ -779,7 +779,10 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 p_lo, u32 p_hi, double t0, Stage
     sc.lap("seed.compact_lookup");
     // diagonal binning: sort keys, find group heads
     ensure_sort_tmp(c, sort_keys_u64_temp_bytes(H, kl.total));
-    sort_keys_u64(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.keys.p, b.keys2.p, H, kl.total, c->st);
+    // Hits are generated in (query, qpos, as) order (position-major seed ordinals) and the radix sort is
+    // stable, so sorting on the (query, subject, diagonal) bits alone leaves every group ordered by query
+    // position -- one radix pass fewer than sorting the whole key.  (Dropped hits carry ~0 and sort last.)
+    sort_keys_u64(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.keys.p, b.keys2.p, H, kl.sh_diag, kl.total, c->st);
     sc.lap("group.sort_keys");
     b.flags.ensure((size_t)H + 4), b.gidx.ensure((size_t)H + 4);
     launch_group_flags(b.keys2.p, H, kl, b.flags.p, b.counters.p + 1, c->st);

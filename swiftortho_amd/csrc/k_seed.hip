@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void k_bounds(const u32* __restrict__ qbucket,
     const i64 L = (i64)E - 1;  // self.L = len(self.locus) - 1
     u32 tot = 0;
     for (int as = 0; as < AS; ++as) {
-        const size_t t = (size_t)as * Ppad + p;
-        const u32 b = qbucket[t];
+        const size_t t = (size_t)p * AS + as;  // seed ordinal: position-major, so hits are generated in (query, qpos, as) order
+        const u32 b = qbucket[(size_t)as * Ppad + p];
         u32 beg = 0, cnt = 0;
         if (b != 0xFFFFFFFFu) {
             i64 st = start[b];
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_effcnt(const u8* __restrict__ mark, con
                                                 u32 p_lo, u32 p_hi, u32* __restrict__ eff, u32* __restrict__ nz) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= (size_t)AS * Ppad) return;
-    const u32 p = (u32)(t % Ppad);
+    const u32 p = (u32)(t / AS);
     u32 c = (mark[p] && p >= p_lo && p < p_hi) ? scnt[t] : 0u;  // [p_lo, p_hi): packed range of the query sub-range
     eff[t] = c;
     nz[t] = c ? 1u : 0u;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_compact_seeds(const u32* __restrict__ e
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= (size_t)AS * Ppad) return;
     if (!eff[t]) return;
-    const u32 as = (u32)(t / Ppad), p = (u32)(t % Ppad);
+    const u32 as = (u32)(t % AS), p = (u32)(t / AS);
     const u32 k = cidx[t];
     const u32 q = q_pseq[p];
     const u32 qpos = p - (qoff[q] + q);

@@ -8,18 +8,19 @@
 
 size_t sort_keys_u64_temp_bytes(size_t n, int bits) {
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortKeys((void*)nullptr, bytes, (const u64*)nullptr, (u64*)nullptr, (int)n, 0, bits, (hipStream_t)0);
+    (void)hipcub::DeviceRadixSort::SortKeys((void*)nullptr, bytes, (const u64*)nullptr, (u64*)nullptr, (int)n, 0, bits, (hipStream_t)0);
     return bytes;
 }
 
-void sort_keys_u64(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, int bits, hipStream_t st) {
+// stable LSD radix sort on key bits [begin_bit, end_bit)
+void sort_keys_u64(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, int begin_bit, int end_bit, hipStream_t st) {
     if (n == 0) return;
-    HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, in, out, (int)n, 0, bits, st));
+    HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, in, out, (int)n, begin_bit, end_bit, st));
 }
 
 size_t sort_pairs_u64_u32_temp_bytes(size_t n, int bits) {
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs((void*)nullptr, bytes, (const u64*)nullptr, (u64*)nullptr, (const u32*)nullptr, (u32*)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs((void*)nullptr, bytes, (const u64*)nullptr, (u64*)nullptr, (const u32*)nullptr, (u32*)nullptr,
                                        (int)n, 0, bits, (hipStream_t)0);
     return bytes;
 }

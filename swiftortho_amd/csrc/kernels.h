@@ -11,7 +11,7 @@ void fill_u32(u32* p, size_t n, u32 v, hipStream_t st);
 
 // k_sort.hip
 size_t sort_keys_u64_temp_bytes(size_t n, int bits);
-void sort_keys_u64(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, int bits, hipStream_t st);
+void sort_keys_u64(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, int begin_bit, int end_bit, hipStream_t st);
 size_t sort_pairs_u64_u32_temp_bytes(size_t n, int bits);
 void sort_pairs_u64_u32(void* temp, size_t temp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, int bits,
                         hipStream_t st);

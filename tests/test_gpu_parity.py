@@ -108,7 +108,7 @@ def oracle_vs_gpu(fs, oracle, fasta, kw, tmp_path, sub=None):
     out = str(tmp_path / "o.sc")
     st, ed = sub if sub else (-1, -1)
     r = oracle.blastp(fa, fa, out, ssd=kw["ssd"], nr=kw["nr"], expect=kw["expect"], v=kw["v"], step=kw["step"], flt=kw["flt"],
-                      ht=kw["ht"], chk=kw["chk"], st=st, ed=ed)
+                      ht=kw["ht"], chk=kw["chk"], st=st, ed=ed, thr=kw.get("thr", -1), max_miss=kw.get("max_miss", 1e-3))
     s, hits, rows = gpu_rows(fs, fasta, fasta, kw, st, ed, keep=True)
     want = open(out, "rb").read()
     # stage: candidates of every query, in the reference's spill order
@@ -203,6 +203,18 @@ def test_query_subrange_and_small_batches(fs, oracle, tmp_path, monkeypatch):
     monkeypatch.setenv("SOHIT_BATCH", "64")
     kw = dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=50000, step=1, v=500, expect=1e-5, flt="T")
     oracle_vs_gpu(fs, oracle, synthprot.synthprot(500, 120, 82), kw, tmp_path, sub=(100, 333))
+
+
+def test_no_filter_threshold_override_small_v(fs, oracle, tmp_path):
+    """-F F (no SEG masking), -t override of the seed-frequency threshold, -v 3, -m 0.5, lower-case residues"""
+    from swiftortho_amd import synthprot
+    fa = synthprot.synthprot(600, 180, 85)
+    lines = fa.split(b"\n")
+    for k in range(1, len(lines), 14):   # lower-case every 7th sequence: hashed/scored like upper case, never identical to it
+        lines[k] = lines[k].lower()
+    fa = b"\n".join(lines)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=2000003, chk=50000, step=1, v=3, expect=1e-3, flt="F", thr=7, max_miss=0.5)
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
 
 
 def test_hit_budget_splits_passes(fs, oracle, tmp_path, monkeypatch):
