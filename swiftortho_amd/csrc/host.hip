@@ -784,30 +784,22 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 p_lo, u32 p_hi, double t0, Stage
     // position -- one radix pass fewer than sorting the whole key.  (Dropped hits carry ~0 and sort last.)
     sort_keys_u64(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.keys.p, b.keys2.p, H, kl.sh_diag, kl.total, c->st);
     sc.lap("group.sort_keys");
-    b.flags.ensure((size_t)H + 4), b.gidx.ensure((size_t)H + 4);
-    launch_group_flags(b.keys2.p, H, kl, b.flags.p, b.counters.p + 1, c->st);
-    c->d_scan_tmp.ensure(scan_u32_temp_elems(H) + 8);
-    const u32* dG = scan_u32(b.flags.p, b.gidx.p, H, false, c->d_scan_tmp.p, c->st);
-    const u32 G = d2h_u32(c, dG);
-    const u32 Hvalid = d2h_u32(c, b.counters.p + 1);
-    c->cnt.groups += G;
-    if (G == 0) {
-        c->cnt.seed_ms += (t1 - t0) * 1e3;
-        c->cnt.group_ms += (wall() - t1) * 1e3;
-        return;
-    }
-    b.ghead.ensure((size_t)G + 2);
-    launch_group_list(b.flags.p, b.gidx.p, H, b.ghead.p, c->st);
-    sc.lap("group.heads");
-    const u32 shard_cap = ungap_shard_cap(G);
+    // group walk + chained ungapped extension (the kernel finds the group heads itself)
+    const u32 shard_cap = ungap_shard_cap(H);
     const size_t pcap = (size_t)shard_cap * UG_SHARDS + 2;
     b.p_qs.ensure(pcap), b.p_sd.ensure(pcap), b.p_ft.ensure(pcap);
     b.shard.ensure(2 * UG_SHARDS + 8);
     b.stepshard.ensure(UG_SHARDS);
     HIP_CHECK(hipMemsetAsync(b.shard.p, 0, (2 * UG_SHARDS + 8) * sizeof(u32), c->st));
     HIP_CHECK(hipMemsetAsync(b.stepshard.p, 0, UG_SHARDS * sizeof(unsigned long long), c->st));
-    launch_ungap(b.keys2.p, b.ghead.p, G, Hvalid, kl, ft_bits_entry, bsp, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls.p,
-                 c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
+    launch_ungap(b.keys2.p, H, kl, ft_bits_entry, bsp, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_off.p + ch.seq_lo,
+                 c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
+    {
+        unsigned long long gc[UG_SHARDS];
+        HIP_CHECK(hipMemcpyAsync(gc, b.stepshard.p, sizeof gc, hipMemcpyDeviceToHost, c->st));
+        HIP_CHECK(hipStreamSynchronize(c->st));
+        for (int k = 0; k < UG_SHARDS; ++k) c->cnt.groups += (i64)gc[k];
+    }
     // contiguous pass list
     u32* shard_off = b.shard.p + UG_SHARDS;
     launch_shard_scan(b.shard.p, shard_off, c->st);

@@ -112,100 +112,289 @@ __device__ __forceinline__ UG ungap_dev(const u8* __restrict__ q, int ql, i64 qa
     return {max_score, max_qst, max_qed, max_sst, max_sed};
 }
 
-// One thread per (query, subject, diagonal) group.  Passing groups (score >= 25) are appended to
-// the pass list with a wave-ballot compaction: one atomicAdd per wave, lanes take consecutive slots.
-//   p_qs[i] = (q << 32) | subject_local     p_sd[i] = (score << 32) | (u32)dist      p_ft[i] = first-touch key
-__global__ __launch_bounds__(256) void k_ungap(const u64* __restrict__ keys, const u32* __restrict__ ghead, u32 G, u32 Hvalid,
-                                               KeyLayout kl, int ft_bits_entry, int bsp, const u8* __restrict__ q_scls,
-                                               const u32* __restrict__ qoff, const u8* __restrict__ r_scls,
-                                               const u32* __restrict__ roff /*chunk-local offsets (absolute values)*/,
-                                               const signed char* __restrict__ b62g, u32* __restrict__ shard_cnt /*[UG_SHARDS]*/,
-                                               u32 shard_cap, u64* __restrict__ p_qs, u64* __restrict__ p_sd, u64* __restrict__ p_ft,
-                                               unsigned long long* __restrict__ step_shards /*[UG_SHARDS]*/) {
+// ---- group walk + chained ungapped extension --------------------------------------------------------
+// One WAVE owns the groups whose first hit lies in a fixed range of the sorted key array.  It scans
+// that range 64 keys at a time for group heads (key prefix != previous key's), keeps them in a small
+// LDS ring, and every lane runs a state machine
+//     NEED_GROUP -> NEXT_HIT -> RIGHT pass -> LEFT pass -> NEXT_HIT -> ... -> (group done) -> NEED_GROUP
+// pulling the next group as soon as it finishes one: a wave's time is (sum of its lanes' work) / 64
+// instead of 64 x the slowest group, and no separate head-flag / scan / list kernels are needed.
+// One loop iteration = one 8-residue chunk for every lane that is inside a pass; the bookkeeping part
+// (group fetch, hit walk) runs only when enough lanes wait for it.  Passing groups (score >= 25) are
+// buffered in LDS and flushed to one of UG_SHARDS regions with ONE atomic per flush (wave-ballot
+// compaction inside the wave).   p_qs = (q << 32) | subject_local, p_sd = (score << 32) | (u32)dist,
+// p_ft = first-touch key.
+#define UW_WAVES 4
+#define UW_RANGE 2048   // head positions owned by one wave
+#define UW_QCAP 256     // group-head ring (u32 hit indices)
+#define UW_PCAP 192     // buffered pass records per wave
+#define UW_WAIT 24      // run the bookkeeping part when this many lanes wait for it
+
+enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN = 5 };
+
+__global__ __launch_bounds__(64 * UW_WAVES) void k_ungap(const u64* __restrict__ keys, u32 H, KeyLayout kl, int ft_bits_entry, int bsp,
+                                                         const u8* __restrict__ q_scls, const u32* __restrict__ qoff,
+                                                         const u8* __restrict__ r_scls,
+                                                         const u32* __restrict__ roff /*chunk-local offsets (absolute values)*/,
+                                                         const signed char* __restrict__ b62g, u32* __restrict__ shard_cnt /*[UG_SHARDS]*/,
+                                                         u32 shard_cap, u64* __restrict__ p_qs, u64* __restrict__ p_sd,
+                                                         u64* __restrict__ p_ft, unsigned long long* __restrict__ group_count) {
     __shared__ signed char s_b62[32 * B62_LD];
-    __shared__ u32 s_wcnt[4];
-    __shared__ u32 s_base;
-    for (int i = threadIdx.x; i < 32 * B62_LD; i += 256) {
+    __shared__ u32 s_queue_all[UW_WAVES][UW_QCAP];   // head position | (1 << 31) when the group is a singleton
+    __shared__ u64 s_qkey_all[UW_WAVES][UW_QCAP];    // the head's (masked) key
+    __shared__ u64 s_pb_all[UW_WAVES][3][UW_PCAP];
+    for (int i = threadIdx.x; i < 32 * B62_LD; i += 64 * UW_WAVES) {
         const int a = i / B62_LD, b = i % B62_LD;
-        s_b62[i] = (a < SCLS_N && b < SCLS_N) ? b62g[a * SCLS_N + b] : (signed char)-4;
+        // class 31 never occurs in data: it marks elements past a pass limit and scores -128
+        s_b62[i] = (a < SCLS_N && b < SCLS_N) ? b62g[a * SCLS_N + b] : ((a == 31 || b == 31) ? (signed char)-128 : (signed char)-4);
     }
     __syncthreads();
-    const u32 g = blockIdx.x * 256u + threadIdx.x;
-    bool pass = false;
-    u64 o_qs = 0, o_sd = 0, o_ft = 0;
-    if (g < G) {
-        const u32 h0 = ghead[g], h1 = (g + 1 < G) ? ghead[g + 1] : Hvalid;
-        const u64 k0 = keys[h0];
-        const u32 q = (u32)((k0 >> kl.sh_q) & ((1ull << kl.bq) - 1ull));
-        const u32 subj = (u32)((k0 >> kl.sh_subj) & ((1ull << kl.bs) - 1ull));
-        const i64 diag = (i64)((k0 >> kl.sh_diag) & ((1ull << kl.bd) - 1ull)) - kl.diag_off;  // qpos - sst
-        const u32 qb = qoff[q], sb = roff[subj];
-        const int ql = (int)(qoff[q + 1] - qb), sl = (int)(roff[subj + 1] - sb);
-        const u8* qs = q_scls + qb;
-        const u8* ss = r_scls + sb;
-        const u64 pmask = (1ull << kl.bp) - 1ull, amask = (1ull << kl.ba) - 1ull;
-        int prev_qpos = -1;
-        int scores = 0, x0 = 0, y0 = 0, x = 0, y = 0;
-        bool first = true;
-        u64 ft = ~0ull;
-        for (u32 h = h0; h < h1; ++h) {
-            const u64 k = keys[h];
-            const int qpos = (int)((k >> kl.sh_qpos) & pmask);
-            const u32 as = kl.ba ? (u32)((k >> kl.sh_as) & amask) : 0u;
-            const u32 tag = kl.ba ? (u32)(k & amask) : 0u;
-            const int sst = (int)((i64)qpos - diag);
-            // first-touch key: emission order (as, qpos) ascending, then index slot order ==
-            // descending (true subject j, tag, pos)
-            {
-                u32 j = subj, pos = (u32)sst;
-                if (sst == sl) j = subj + 1, pos = 0;  // offset-0 entry of the next chunk sequence
-                const u64 jmax = (1ull << (kl.bs + 1)) - 1ull, tmax = amask, pmax = (1ull << bsp) - 1ull;
-                u64 inv = ((jmax - j) << (kl.ba + bsp)) | ((tmax - tag) << bsp) | (pmax - pos);
-                u64 emit = ((u64)as << kl.bp) | (u64)qpos;
-                u64 f = (emit << ft_bits_entry) | inv;
-                ft = f < ft ? f : ft;
-            }
-            if (qpos == prev_qpos) continue;  // duplicate (qst, sst) pair: dropped by lis()
-            prev_qpos = qpos;
-            if (first) {
-                UG u = ungap_dev(qs, ql, (i64)qb, ss, sl, (i64)sb, qpos, sst, 0, 0, s_b62);
-                scores = u.max_score, x0 = u.max_qst, y0 = u.max_sst, x = u.max_qed, y = u.max_sed;
-                first = false;
-            } else {
-                UG u = ungap_dev(qs, ql, (i64)qb, ss, sl, (i64)sb, qpos, sst, x, y, s_b62);
-                scores += u.max_score, x = u.max_qed, y = u.max_sed;
-            }
-        }
-        if (scores >= MIN_UNGAP) {
-            pass = true;
-            // guess_start over [[x0, y0], [x, y]]: floor(((y0 - x0) + (y - x)) / 2)
-            int d2 = (y0 - x0) + (y - x);
-            int dist = (d2 >= 0) ? d2 / 2 : -((-d2 + 1) / 2);
-            o_qs = ((u64)q << 32) | subj;
-            o_sd = ((u64)(u32)scores << 32) | (u64)(u32)dist;
-            o_ft = ft;
-        }
-    }
-    // Wave-ballot compaction, aggregated per block, into one of UG_SHARDS regions: a single global
-    // counter would serialise ~3 M same-address atomics (one per wave) and dominated this kernel;
-    // with one atomic per block spread over 64 addresses the tail is free.  Shard s owns slots
-    // [s * shard_cap, (s + 1) * shard_cap); k_compact_shards makes the list contiguous afterwards.
-    const unsigned long long bal = __ballot(pass);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) s_wcnt[w] = (u32)__popcll(bal);
-    __syncthreads();
+    const u32 wid = blockIdx.x * UW_WAVES + w;
+    const u64 ra = (u64)wid * UW_RANGE;
+    if (ra >= H) return;
+    const u32 a0 = (u32)ra, b0 = (u32)min((u64)H, ra + UW_RANGE);
+    u32* s_queue = s_queue_all[w];
+    u64* s_qkey = s_qkey_all[w];
+    u64* s_pqs = s_pb_all[w][0];
+    u64* s_psd = s_pb_all[w][1];
+    u64* s_pft = s_pb_all[w][2];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const u64 kmask = (kl.total >= 64) ? ~0ull : ((1ull << kl.total) - 1ull);
+    const u64 qall = (1ull << kl.bq) - 1ull;
+    const u64 pmask = (1ull << kl.bp) - 1ull, amask = (1ull << kl.ba) - 1ull;
     const u32 shard = blockIdx.x & (UG_SHARDS - 1);
-    if (threadIdx.x == 0) {
-        const u32 tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        s_base = tot ? atomicAdd(&shard_cnt[shard], tot) : 0u;
+
+    // wave-uniform bookkeeping
+    u32 cur = a0;              // next position to scan for heads
+    u32 qfront = 0, qback = 0;  // ring counters
+    u32 npb = 0;               // buffered pass records
+    u32 ngroups = 0;
+
+    // lane state
+    int phase = PH_NEED;
+    u32 h = 0;
+    u64 gpre = 0;
+    u32 gq = 0, gsubj = 0;
+    i64 gdiag = 0;
+    u32 qb = 0, sb = 0;
+    int ql = 0, sl = 0;
+    int prev_qpos = -1, scores = 0, x0 = 0, y0 = 0, x = 0, y = 0;
+    bool first = true, single = false, havekey = false;
+    u64 ft = ~0ull, hkey = 0;
+    u32 cq = 0xFFFFFFFFu, cqb = 0;  // last query looked up (groups arrive sorted by query)
+    int cql = 0;
+    int Qst = 0, Sst = 0, qlo = 0, slo = 0, ci = 0, cn = 0, score = 0, max_score = 0, best = -1, r_qed = 0, r_sed = 0;
+    bool stop = false;
+
+    for (;;) {
+        const unsigned long long waitb = __ballot(phase == PH_NEED || phase == PH_HIT);
+        const unsigned long long workb = __ballot(phase == PH_RIGHT || phase == PH_LEFT);
+        if (!waitb && !workb) break;
+        if (waitb && (!workb || __popcll(waitb) >= UW_WAIT)) {
+            // ---- refill the head ring -----------------------------------------------------------------
+            while (qback - qfront < 64u && cur < b0) {
+                const u32 pos = cur + (u32)lane;
+                u64 k = ~0ull, kp = ~0ull;
+                if (pos < H) k = keys[pos] & kmask;
+                kp = __shfl_up(k, 1);
+                if (lane == 0) kp = (cur == 0) ? ~0ull : (keys[cur - 1] & kmask);
+                const bool valid = (pos < b0) && ((k >> kl.sh_q) != qall);
+                const bool head = valid && (cur + (u32)lane == 0 || (k >> kl.sh_diag) != (kp >> kl.sh_diag));
+                // singleton: the next key starts another group (lane 63 would need one more load: treated as unknown)
+                const u64 kn = __shfl_down(k, 1);
+                const bool sing = (lane < 63) && ((kn >> kl.sh_diag) != (k >> kl.sh_diag));
+                const unsigned long long hb = __ballot(head);
+                if (head) {
+                    const u32 slot = (qback + (u32)__popcll(hb & lt)) & (UW_QCAP - 1);
+                    s_queue[slot] = pos | (sing ? 0x80000000u : 0u);
+                    s_qkey[slot] = k;
+                }
+                qback += (u32)__popcll(hb);
+                cur += 64;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- finished groups: buffer the passing ones ----------------------------------------------
+            // (a lane in PH_HIT discovers the end of its group below; results are buffered one iteration later)
+            // ---- hand out groups ------------------------------------------------------------------------
+            {
+                const unsigned long long needb = __ballot(phase == PH_NEED);
+                const u32 avail = qback - qfront;
+                if (phase == PH_NEED) {
+                    const u32 r = (u32)__popcll(needb & lt);
+                    if (r < avail) {
+                        const u32 qe = s_queue[(qfront + r) & (UW_QCAP - 1)];
+                        const u64 k0 = s_qkey[(qfront + r) & (UW_QCAP - 1)];
+                        h = qe & 0x7FFFFFFFu;
+                        single = (qe >> 31) != 0;
+                        hkey = k0, havekey = true;
+                        gpre = k0 >> kl.sh_diag;
+                        gq = (u32)((k0 >> kl.sh_q) & qall);
+                        gsubj = (u32)((k0 >> kl.sh_subj) & ((1ull << kl.bs) - 1ull));
+                        gdiag = (i64)((k0 >> kl.sh_diag) & ((1ull << kl.bd) - 1ull)) - kl.diag_off;  // qpos - sst
+                        if (gq != cq) cq = gq, cqb = qoff[gq], cql = (int)(qoff[gq + 1] - cqb);
+                        qb = cqb, ql = cql;
+                        sb = roff[gsubj];
+                        sl = (int)(roff[gsubj + 1] - sb);
+                        prev_qpos = -1, scores = 0, x0 = y0 = x = y = 0, first = true, ft = ~0ull;
+                        phase = PH_HIT;
+                    } else if (cur >= b0) {
+                        phase = PH_DONE;  // nothing left to hand out
+                    }
+                }
+                const u32 taken = min((u32)__popcll(needb), avail);
+                qfront += taken;
+                ngroups += taken;
+            }
+            // ---- walk to the next distinct seed of the group, or finish the group --------------------------
+            bool fin = false;
+            if (phase == PH_HIT) {
+                bool in_group = false;
+                u64 k = 0;
+                if (havekey) {
+                    k = hkey, in_group = true, havekey = false;  // the head's key came with the hand-out
+                } else if (h < H) {
+                    k = keys[h] & kmask;
+                    in_group = (k >> kl.sh_diag) == gpre;
+                }
+                if (!in_group) {
+                    fin = true;
+                } else {
+                    const int qpos = (int)((k >> kl.sh_qpos) & pmask);
+                    const u32 as = kl.ba ? (u32)((k >> kl.sh_as) & amask) : 0u;
+                    const u32 tag = kl.ba ? (u32)(k & amask) : 0u;
+                    const int sst = (int)((i64)qpos - gdiag);
+                    {  // first-touch key: emission order (as, qpos), then index slot order == descending (j, tag, pos)
+                        u32 j = gsubj, pos = (u32)sst;
+                        if (sst == sl) j = gsubj + 1, pos = 0;  // offset-0 entry of the next chunk sequence
+                        const u64 jmax = (1ull << (kl.bs + 1)) - 1ull, tmax = amask, pmax = (1ull << bsp) - 1ull;
+                        const u64 inv = ((jmax - j) << (kl.ba + bsp)) | ((tmax - tag) << bsp) | (pmax - pos);
+                        const u64 emit = ((u64)as << kl.bp) | (u64)qpos;
+                        const u64 f = (emit << ft_bits_entry) | inv;
+                        ft = f < ft ? f : ft;
+                    }
+                    if (qpos == prev_qpos) {
+                        ++h;  // duplicate (qst, sst) pair: dropped by lis()
+                    } else {
+                        prev_qpos = qpos;
+                        // Fasta.ungap set-up (2455-2464): first seed unbounded, later ones bounded by the previous segment's end
+                        qlo = first ? 0 : x;
+                        slo = first ? 0 : y;
+                        const int off = max(max(qlo - qpos, slo - sst), 0);
+                        Qst = qpos + off;
+                        Sst = sst + off;
+                        cn = (qlo < Qst && slo < Sst) ? min(ql - Qst, sl - Sst) : 0;
+                        ci = 0, score = 0, max_score = 0, best = -1, stop = false;
+                        phase = PH_RIGHT;
+                    }
+                }
+            }
+            if (fin) phase = PH_FIN;
+        }
+        // ---- one 8-residue chunk for every lane inside a pass ---------------------------------------------------
+        // Branch-free: one load path for both directions (left-pass windows are byte-reversed), elements past
+        // the pass limit get class 31 (scores -128 against everything: an immediate X-drop), and after a
+        // drop the running score is pinned far below zero so later elements can neither raise the maximum
+        // nor matter -- exactly the sequential loop's `break`.
+        if (phase == PH_RIGHT || phase == PH_LEFT) {
+            if (ci < cn && !stop) {
+                const bool left = phase == PH_LEFT;
+                // right: bytes [Qst + ci, +8), element k in byte k;  left: bytes [Qst - 8 - ci, +8), element k in byte 7 - k
+                const i64 qa = (i64)qb + (left ? (i64)Qst - 8 - ci : (i64)Qst + ci);
+                const i64 sa = (i64)sb + (left ? (i64)Sst - 8 - ci : (i64)Sst + ci);
+                u64 qw = load8u(q_scls + (qa < 0 ? 0 : qa)), sw = load8u(r_scls + (sa < 0 ? 0 : sa));
+                if (qa < 0) qw <<= 8 * (int)(-qa);  // array start (left pass only): the missing low bytes are never active
+                if (sa < 0) sw <<= 8 * (int)(-sa);
+                const u64 qr = __builtin_bswap64(qw), sr = __builtin_bswap64(sw);
+                qw = left ? qr : qw;
+                sw = left ? sr : sw;
+                const int m = cn - ci;
+                if (m < 8) qw |= 0x1F1F1F1F1F1F1F1Full << (8 * m);  // elements >= m: class 31
+                int sc[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sc[k] = s_b62[(((u32)(qw >> (8 * k)) & 31u) * B62_LD) + ((u32)(sw >> (8 * k)) & 31u)];
+                bool dropped = false;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int ns = score + sc[k];
+                    const bool better = ns > max_score;
+                    const bool drop = ns + DROPX < max_score;  // (never together with `better`)
+                    best = better ? ci + k : best;
+                    max_score = max(max_score, ns);
+                    score = drop ? -(1 << 28) : ns;
+                    dropped = dropped || drop;
+                }
+                stop = dropped;
+                ci += 8;
+            }
+            if (phase == PH_RIGHT && (ci >= cn || stop)) {
+                r_qed = best >= 0 ? Qst + best : Qst;
+                r_sed = best >= 0 ? Sst + best : Sst;
+                // left pass from (Qst - 1, Sst - 1); the score continues from the maximum (2479-2492)
+                score = max_score;
+                stop = false, best = -1, ci = 0;
+                cn = (Qst - 1 < ql && Sst - 1 < sl) ? min(Qst - 1 - qlo, Sst - 1 - slo) : 0;
+                phase = PH_LEFT;
+            }
+            if (phase == PH_LEFT && (ci >= cn || stop)) {
+                const int l_qst = best >= 0 ? Qst - 1 - best : Qst - 1, l_sst = best >= 0 ? Sst - 1 - best : Sst - 1;
+                if (first) {  // get_ungap_scores (2497-2509)
+                    scores = max_score, x0 = l_qst, y0 = l_sst;
+                    first = false;
+                } else {
+                    scores += max_score;
+                }
+                x = r_qed, y = r_sed;
+                ++h;
+                phase = single ? PH_FIN : PH_HIT;  // a singleton group is complete: no second visit to find its end
+            }
+        }
+        // ---- buffer the groups that just finished with score >= 25 (wave-ballot compaction into LDS) ------------
+        {
+            const bool fin = phase == PH_FIN;
+            const bool pass = fin && scores >= MIN_UNGAP;
+            const unsigned long long pb = __ballot(pass);
+            if (pb) {
+                const u32 np = (u32)__popcll(pb);
+                if (npb + np > UW_PCAP) {  // flush (wave-uniform)
+                    u32 base = 0;
+                    if (lane == 0) base = atomicAdd(&shard_cnt[shard], npb);
+                    base = __shfl(base, 0);
+                    for (u32 i = (u32)lane; i < npb; i += 64) {
+                        const size_t o = (size_t)shard * shard_cap + base + i;
+                        p_qs[o] = s_pqs[i], p_sd[o] = s_psd[i], p_ft[o] = s_pft[i];
+                    }
+                    npb = 0;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (pass) {
+                    // guess_start over [[x0, y0], [x, y]]: floor(((y0 - x0) + (y - x)) / 2)
+                    const int d2 = (y0 - x0) + (y - x);
+                    const int dist = (d2 >= 0) ? d2 / 2 : -((-d2 + 1) / 2);
+                    const u32 i = npb + (u32)__popcll(pb & lt);
+                    s_pqs[i] = ((u64)gq << 32) | gsubj;
+                    s_psd[i] = ((u64)(u32)scores << 32) | (u64)(u32)dist;
+                    s_pft[i] = ft;
+                }
+                npb += np;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (fin) phase = PH_NEED;
+        }
     }
-    __syncthreads();
-    if (pass) {
-        u32 i = s_base + (u32)__popcll(bal & ((1ull << lane) - 1ull));
-        for (int k = 0; k < w; ++k) i += s_wcnt[k];
-        const size_t o = (size_t)shard * shard_cap + i;
-        p_qs[o] = o_qs, p_sd[o] = o_sd, p_ft[o] = o_ft;
+    if (npb) {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&shard_cnt[shard], npb);
+        base = __shfl(base, 0);
+        for (u32 i = (u32)lane; i < npb; i += 64) {
+            const size_t o = (size_t)shard * shard_cap + base + i;
+            p_qs[o] = s_pqs[i], p_sd[o] = s_psd[i], p_ft[o] = s_pft[i];
+        }
     }
+    if (lane == 0 && ngroups) atomicAdd(&group_count[shard], (unsigned long long)ngroups);
 }
 
 // shard offsets (exclusive scan over UG_SHARDS counters) + total
@@ -322,17 +511,19 @@ void launch_group_list(const u32* flags, const u32* gidx, u32 H, u32* ghead, hip
     hipLaunchKernelGGL(k_group_list, dim3((H + 255) / 256), dim3(256), 0, st, flags, gidx, H, ghead);
 }
 
-u32 ungap_shard_cap(u32 G) {
-    const u32 nblk = (G + 255) / 256;
-    return ((nblk + UG_SHARDS - 1) / UG_SHARDS) * 256u;
+// pass-list capacity per shard: every block can emit at most the groups whose heads it owns
+u32 ungap_num_blocks(u32 H) { return (u32)(((u64)H + (u64)UW_RANGE * UW_WAVES - 1) / ((u64)UW_RANGE * UW_WAVES)); }
+u32 ungap_shard_cap(u32 H) {
+    const u32 nblk = ungap_num_blocks(H);
+    return ((nblk + UG_SHARDS - 1) / UG_SHARDS) * (UW_RANGE * UW_WAVES);
 }
 
-void launch_ungap(const u64* keys, const u32* ghead, u32 G, u32 Hvalid, const KeyLayout& kl, int ft_bits_entry, int bsp,
-                  const u8* q_scls, const u32* qoff, const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt,
-                  u32 shard_cap, u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* step_shards, hipStream_t st) {
-    if (!G) return;
-    hipLaunchKernelGGL(k_ungap, dim3((G + 255) / 256), dim3(256), 0, st, keys, ghead, G, Hvalid, kl, ft_bits_entry, bsp, q_scls, qoff,
-                       r_scls, roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, step_shards);
+void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, int ft_bits_entry, int bsp, const u8* q_scls, const u32* qoff,
+                  const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt, u32 shard_cap, u64* p_qs, u64* p_sd,
+                  u64* p_ft, unsigned long long* group_count, hipStream_t st) {
+    if (!H) return;
+    hipLaunchKernelGGL(k_ungap, dim3(ungap_num_blocks(H)), dim3(64 * UW_WAVES), 0, st, keys, H, kl, ft_bits_entry, bsp, q_scls, qoff, r_scls,
+                       roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count);
 }
 
 void launch_shard_scan(const u32* shard_cnt, u32* shard_off, hipStream_t st) {

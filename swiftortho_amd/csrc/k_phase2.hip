@@ -91,26 +91,43 @@ __global__ __launch_bounds__(64) void k_csort(const u32* __restrict__ rec, const
     ntask[q] = m, ntile[q] = tiles;
 }
 
-// tasks of a query in rank order; rk_slot[roffc[q] + r] = first task slot (relative to toff[q]) of rank r
+// tasks of a query in rank order; rk_slot[roffc[q] + r] = first task slot (relative to toff[q]) of rank r.
+// One wave per query: lanes take ranks 64 at a time, a wave prefix sum of the per-rank tile counts
+// gives the slots (1 per rank unless a sequence is >= 4096 aa).
 __global__ __launch_bounds__(64) void k_mktasks(const u32* __restrict__ rec, const u32* __restrict__ qcoff, const u32* __restrict__ perm,
                                                 const u32* __restrict__ ntask, const u32* __restrict__ roffc, const u32* __restrict__ toff,
                                                 u32 nq, const u32* __restrict__ qoff, const u32* __restrict__ roff,
                                                 AlnTask* __restrict__ tasks, u32* __restrict__ rk_slot) {
-    const u32 q = blockIdx.x * 64u + threadIdx.x;
-    if (q >= nq) return;
+    const u32 q = blockIdx.x;
+    const int lane = threadIdx.x;
     const u32 c0 = qcoff[q], t0 = toff[q], nt = ntask[q], r0 = roffc[q];
     const u32 lq = qoff[q + 1] - qoff[q];
-    u32 slot = 0;
-    for (u32 k = 0; k < nt; ++k) {
-        const u32 c = c0 + perm[c0 + k];
+    u32 carry = 0;
+    for (u32 kb = 0; kb < nt; kb += 64) {
+        const u32 k = kb + lane;
         AlnTask t;
-        t.q = q, t.subj = rec[4 * (size_t)c], t.score = rec[4 * (size_t)c + 1], t.qi = rec[4 * (size_t)c + 2],
-        t.qj = rec[4 * (size_t)c + 3], t.rank = k;
-        const u32 ls = roff[t.subj + 1] - roff[t.subj];
+        u32 ls = 0, tiles = 0;
+        if (k < nt) {
+            const u32 c = c0 + perm[c0 + k];
+            const uint4 v = *reinterpret_cast<const uint4*>(rec + 4 * (size_t)c);
+            t.q = q, t.subj = v.x, t.score = v.y, t.qi = v.z, t.qj = v.w, t.rank = k;
+            ls = roff[t.subj + 1] - roff[t.subj];
+            tiles = cand_tiles(lq, ls, t.qi);
+        }
+        u32 inc = tiles;  // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 x = __shfl_up(inc, o);
+            if (lane >= o) inc += x;
+        }
+        const u32 total = __shfl(inc, 63);
+        u32 slot = carry + inc - tiles;
+        carry += total;
+        if (k >= nt) continue;
         rk_slot[r0 + k] = slot;
         if (lq < LONG_SEQ && ls < LONG_SEQ) {
             t.qe = lq, t.se = ls;
-            tasks[t0 + slot++] = t;
+            tasks[t0 + slot] = t;
         } else {
             // kswat_st_long (1480-1498): tile i over [qi + 4096 i, +4096) x [qj + 4096 i, +4096), each aligned from its corner
             const u32 qi0 = t.qi, qj0 = t.qj;
@@ -298,8 +315,7 @@ void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, const u32*
 void launch_mktasks(const u32* rec, const u32* qcoff, const u32* perm, const u32* ntask, const u32* roffc, const u32* toff, u32 nq,
                     const u32* qoff, const u32* roff, AlnTask* tasks, u32* rk_slot, hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_mktasks, dim3((nq + 63) / 64), dim3(64), 0, st, rec, qcoff, perm, ntask, roffc, toff, nq, qoff, roff, tasks,
-                       rk_slot);
+    hipLaunchKernelGGL(k_mktasks, dim3(nq), dim3(64), 0, st, rec, qcoff, perm, ntask, roffc, toff, nq, qoff, roff, tasks, rk_slot);
 }
 
 void launch_round_counts(const u32* ntask, const u32* ntile, const u32* roffc, const u32* rk_slot, const u32* qcoff,

@@ -52,10 +52,10 @@ void launch_lookup(const u32* cs_hoff, const u32* cs_beg, const u64* cs_kbase, c
 // k_group.hip
 void launch_group_flags(const u64* keys, u32 H, const KeyLayout& kl, u32* flags, u32* hvalid, hipStream_t st);
 void launch_group_list(const u32* flags, const u32* gidx, u32 H, u32* ghead, hipStream_t st);
-u32 ungap_shard_cap(u32 G);
-void launch_ungap(const u64* keys, const u32* ghead, u32 G, u32 Hvalid, const KeyLayout& kl, int ft_bits_entry, int bsp,
-                  const u8* q_scls, const u32* qoff, const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt,
-                  u32 shard_cap, u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* step_shards, hipStream_t st);
+u32 ungap_shard_cap(u32 H);
+void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, int ft_bits_entry, int bsp, const u8* q_scls, const u32* qoff,
+                  const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt, u32 shard_cap, u64* p_qs, u64* p_sd,
+                  u64* p_ft, unsigned long long* group_count, hipStream_t st);
 void launch_shard_scan(const u32* shard_cnt, u32* shard_off, hipStream_t st);
 void launch_compact_shards(const u32* shard_cnt, u32* shard_off, u32 shard_cap, const u64* a0, const u64* a1, const u64* a2, u64* b0,
                            u64* b1, u64* b2, hipStream_t st);
