@@ -125,10 +125,10 @@ __device__ __forceinline__ UG ungap_dev(const u8* __restrict__ q, int ql, i64 qa
 // compaction inside the wave).   p_qs = (q << 32) | subject_local, p_sd = (score << 32) | (u32)dist,
 // p_ft = first-touch key.
 #define UW_WAVES 4
-#define UW_RANGE 2048   // head positions owned by one wave
+#define UW_RANGE 4096   // head positions owned by one wave
 #define UW_QCAP 256     // group-head ring (u32 hit indices)
 #define UW_PCAP 192     // buffered pass records per wave
-#define UW_WAIT 24      // run the bookkeeping part when this many lanes wait for it
+#define UW_WAIT 20      // run the bookkeeping part when this many lanes wait for it
 
 enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN = 5 };
 
