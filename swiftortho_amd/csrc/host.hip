@@ -583,6 +583,8 @@ struct Batch {
     DevBuf<u32> cand_q, cand_rec;             // all chunks' regions concatenated
     std::vector<u32> chunk_base;              // region start per chunk (+ total)
     DevBuf<u32> ccnt;                         // [nchunks][nq] per-query counts
+    DevBuf<u64> gx;
+    DevBuf<u32> gL, gR;
     DevBuf<u32> segfirst, st_state, rcnt, tcnt, roff, ridx, ntile, roffc, rk_slot, order_tmp;
     DevBuf<u32> cqoff, prior, qtot, qcoff, fin_rec, perm, ntask, toff, sel, nout, ooff;
     DevBuf<AlnTask> tasks;
@@ -928,7 +930,21 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     b.toff.ensure((size_t)nq + 4), b.roffc.ensure((size_t)nq + 4);
     HIP_CHECK(hipMemsetAsync(b.ntask.p, 0, ((size_t)nq + 4) * sizeof(u32), c->st));
     HIP_CHECK(hipMemsetAsync(b.ntile.p, 0, ((size_t)nq + 4) * sizeof(u32), c->st));
-    launch_csort(b.fin_rec.p, b.qcoff.p, nq, vmax, b.dev.d_off.p, c->ref.d_off.p, b.perm.p, b.ntask.p, b.ntile.p, c->st);
+    {
+        // queries with more candidates than the LDS sort holds need global scratch for the wave sort
+        std::vector<u32> qt(nq);
+        HIP_CHECK(hipMemcpyAsync(qt.data(), b.qtot.p, (size_t)nq * sizeof(u32), hipMemcpyDeviceToHost, c->st));
+        HIP_CHECK(hipStreamSynchronize(c->st));
+        u32 mx = 0;
+        for (u32 v : qt) mx = std::max(mx, v);
+        u64* gx = nullptr;
+        u32 *gL = nullptr, *gR = nullptr;
+        if ((int)mx > csort_lds_max()) {
+            b.gx.ensure((size_t)Ntot + 4), b.gL.ensure((size_t)Ntot + 4), b.gR.ensure((size_t)Ntot + 4);
+            gx = b.gx.p, gL = b.gL.p, gR = b.gR.p;
+        }
+        launch_csort(b.fin_rec.p, b.qcoff.p, nq, vmax, b.dev.d_off.p, c->ref.d_off.p, b.perm.p, b.ntask.p, b.ntile.p, gx, gL, gR, c->st);
+    }
     const u32* dNRk = scan_u32(b.ntask.p, b.roffc.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
     const u32 NRK = d2h_u32(c, dNRk);
     const u32* dNT = scan_u32(b.ntile.p, b.toff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);

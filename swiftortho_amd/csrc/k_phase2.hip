@@ -69,26 +69,38 @@ __global__ __launch_bounds__(64) void k_csort_lds(const u32* __restrict__ rec, c
     if (threadIdx.x == 0) ntask[q] = (u32)m, ntile[q] = tiles;
 }
 
+// queries with more than LDS_SORT_MAX candidates: the same exact wave-parallel quicksort on 64-bit words
+// ((inverted score << 32) | index) and 32-bit misfit lists in global scratch (slices of the arrays at
+// the query's candidate offset).  __syncthreads() in a one-wave block orders the global accesses.
 __global__ __launch_bounds__(64) void k_csort(const u32* __restrict__ rec, const u32* __restrict__ qcoff, u32 nq, u32 vmax,
                                               const u32* __restrict__ qoff, const u32* __restrict__ roff, u32* __restrict__ perm,
-                                              u32* __restrict__ ntask, u32* __restrict__ ntile) {
-    const u32 q = blockIdx.x * 64u + threadIdx.x;
-    if (q >= nq) return;
+                                              u32* __restrict__ ntask, u32* __restrict__ ntile, u64* __restrict__ gx,
+                                              u32* __restrict__ gL, u32* __restrict__ gR) {
+    __shared__ int s_leaf[2 * WQS_LEAF];
+    const u32 q = blockIdx.x;
     const u32 c0 = qcoff[q];
     const int n = (int)(qcoff[q + 1] - c0);
     if (n <= LDS_SORT_MAX) return;  // done by k_csort_lds
-    u32* x = perm + c0;
-    for (int i = 0; i < n; ++i) x[i] = (u32)i;
     const u32* r = rec + 4 * (size_t)c0;
-    ref_qsort_dev(x, n, [r](u32 i) { return -(i64)r[4 * (size_t)i + 1]; }, (int)vmax);
+    u64* x = gx + c0;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        u32 sc = r[4 * (size_t)i + 1];
+        sc = sc > SCORE_CAP ? SCORE_CAP : sc;
+        x[i] = ((u64)(SCORE_CAP - sc) << 32) | (u32)i;
+    }
+    __syncthreads();
+    wave_ref_qsort(x, n, [](u64 v) { return (int)(v >> 32); }, (int)vmax, gL + c0, gR + c0, s_leaf);
     const u32 m = (u32)n < vmax ? (u32)n : vmax;
     const u32 lq = qoff[q + 1] - qoff[q];
     u32 tiles = 0;
-    for (u32 i = 0; i < m; ++i) {
-        const u32 subj = r[4 * (size_t)x[i]], qi = r[4 * (size_t)x[i] + 2];
+    for (u32 i = threadIdx.x; i < m; i += 64) {
+        const u32 c = (u32)x[i];
+        perm[c0 + i] = c;
+        const u32 subj = r[4 * (size_t)c], qi = r[4 * (size_t)c + 2];
         tiles += cand_tiles(lq, roff[subj + 1] - roff[subj], qi);
     }
-    ntask[q] = m, ntile[q] = tiles;
+    for (int o = 32; o > 0; o >>= 1) tiles += __shfl_down(tiles, o);
+    if (threadIdx.x == 0) ntask[q] = m, ntile[q] = tiles;
 }
 
 // tasks of a query in rank order; rk_slot[roffc[q] + r] = first task slot (relative to toff[q]) of rank r.
@@ -306,11 +318,13 @@ void launch_add_u32(u32* acc, const u32* x, u32 n, hipStream_t st) {
 }
 
 void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, const u32* qoff, const u32* roff, u32* perm, u32* ntask,
-                  u32* ntile, hipStream_t st) {
+                  u32* ntile, u64* gx, u32* gL, u32* gR, hipStream_t st) {
     if (!nq) return;
     hipLaunchKernelGGL(k_csort_lds, dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile);
-    hipLaunchKernelGGL(k_csort, dim3((nq + 63) / 64), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile);
+    if (gx) hipLaunchKernelGGL(k_csort, dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile, gx, gL, gR);
 }
+
+int csort_lds_max() { return LDS_SORT_MAX; }
 
 void launch_mktasks(const u32* rec, const u32* qcoff, const u32* perm, const u32* ntask, const u32* roffc, const u32* toff, u32 nq,
                     const u32* qoff, const u32* roff, AlnTask* tasks, u32* rk_slot, hipStream_t st) {

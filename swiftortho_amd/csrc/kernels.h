@@ -79,7 +79,9 @@ void launch_gather_cands(const u32* src_q, const u32* src_rec, u32 n, const u32*
                          u32* dst_rec, hipStream_t st);
 void launch_add_u32(u32* acc, const u32* x, u32 n, hipStream_t st);
 void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, const u32* qoff, const u32* roff, u32* perm, u32* ntask,
-                  u32* ntile, hipStream_t st);
+                  u32* ntile, u64* gx /*scratch, only for queries with > csort_lds_max() candidates; may be null*/, u32* gL, u32* gR,
+                  hipStream_t st);
+int csort_lds_max();
 void launch_mktasks(const u32* rec, const u32* qcoff, const u32* perm, const u32* ntask, const u32* roffc, const u32* toff, u32 nq,
                     const u32* qoff, const u32* roff, AlnTask* tasks, u32* rk_slot, hipStream_t st);
 void launch_round_counts(const u32* ntask, const u32* ntile, const u32* roffc, const u32* rk_slot, const u32* qcoff,

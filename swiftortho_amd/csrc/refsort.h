@@ -14,8 +14,8 @@
 
 // `limit`: only positions [0, limit) of the result are needed -- sub-ranges that start at or beyond
 // it are left unsorted (they cannot influence earlier positions).
-template <class KeyFn>
-__device__ inline void ref_qsort_range(u32* x, int l0, int r0, KeyFn key, int limit = 0x7fffffff) {
+template <class T, class KeyFn>
+__device__ inline void ref_qsort_range(T* x, int l0, int r0, KeyFn key, int limit = 0x7fffffff) {
     int stk[2 * 48];
     int sp = 0;
     stk[sp++] = l0;
@@ -26,7 +26,7 @@ __device__ inline void ref_qsort_range(u32* x, int l0, int r0, KeyFn key, int li
         int gap = r - l + 1;
         if (gap < 7) {
             for (int i = l; i < r + 1; ++i) {  // insort(x, l, r + 1)
-                u32 v = x[i];
+                T v = x[i];
                 auto pivot = key(v);
                 int j = i - 1;
                 while (j >= l) {
@@ -39,7 +39,7 @@ __device__ inline void ref_qsort_range(u32* x, int l0, int r0, KeyFn key, int li
             continue;
         }
         int m = (gap == 7) ? l + 3 : l + (int)(0.3745401188473625 * (double)gap);
-        u32 t = x[l];
+        T t = x[l];
         x[l] = x[m];
         x[m] = t;
         auto pivot = key(x[l]);
@@ -69,8 +69,8 @@ __device__ inline void ref_qsort_range(u32* x, int l0, int r0, KeyFn key, int li
     }
 }
 
-template <class KeyFn>
-__device__ inline void ref_qsort_dev(u32* x, int n, KeyFn key, int limit = 0x7fffffff) {
+template <class T, class KeyFn>
+__device__ inline void ref_qsort_dev(T* x, int n, KeyFn key, int limit = 0x7fffffff) {
     ref_qsort_range(x, 0, n - 1, key, limit);
 }
 
@@ -87,8 +87,10 @@ __device__ inline void ref_qsort_dev(u32* x, int n, KeyFn key, int limit = 0x7ff
 #define WQS_PAR 64
 #define WQS_LEAF 512
 
-template <class KeyFn>
-__device__ inline void wave_ref_qsort(u32* x, int n, KeyFn key, int limit, u16* Lpos, u16* Rpos, int* leaf) {
+// T = element type (u32 words in LDS, or u64 words in global memory for segments that do not fit),
+// PT = position type of the misfit lists (u16 / u32).
+template <class T, class PT, class KeyFn>
+__device__ inline void wave_ref_qsort(T* x, int n, KeyFn key, int limit, PT* Lpos, PT* Rpos, int* leaf) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int stk[2 * 40];
@@ -112,7 +114,7 @@ __device__ inline void wave_ref_qsort(u32* x, int n, KeyFn key, int limit, u16* 
         }
         const int m = l + (int)(0.3745401188473625 * (double)gap);
         if (lane == 0) {
-            u32 t = x[l];
+            T t = x[l];
             x[l] = x[m];
             x[m] = t;
         }
@@ -123,14 +125,14 @@ __device__ inline void wave_ref_qsort(u32* x, int n, KeyFn key, int limit, u16* 
             const int t = base + lane;
             const bool f = (t <= r) && !(key(x[t <= r ? t : r]) < p);
             const unsigned long long bal = __ballot(f);
-            if (f) Lpos[cntL + __popcll(bal & lt)] = (u16)(t - l);
+            if (f) Lpos[cntL + __popcll(bal & lt)] = (PT)(t - l);
             cntL += __popcll(bal);
         }
         for (int base = r; base >= l; base -= 64) {
             const int t = base - lane;
             const bool f = (t >= l) && !(key(x[t >= l ? t : l]) > p);
             const unsigned long long bal = __ballot(f);
-            if (f) Rpos[cntR + __popcll(bal & lt)] = (u16)(t - l);
+            if (f) Rpos[cntR + __popcll(bal & lt)] = (PT)(t - l);
             cntR += __popcll(bal);
         }
         __syncthreads();
@@ -142,8 +144,8 @@ __device__ inline void wave_ref_qsort(u32* x, int n, KeyFn key, int limit, u16* 
             mm += __popcll(__ballot(f));
         }
         for (int k = lane; k < mm; k += 64) {
-            const int a = l + Lpos[k], b = l + Rpos[k];
-            const u32 t = x[a];
+            const int a = l + (int)Lpos[k], b = l + (int)Rpos[k];
+            const T t = x[a];
             x[a] = x[b];
             x[b] = t;
         }
@@ -153,7 +155,7 @@ __device__ inline void wave_ref_qsort(u32* x, int n, KeyFn key, int limit, u16* 
         const int jrel = Rn > Lm ? Rn : Lm;
         __syncthreads();
         if (lane == 0) {
-            u32 t = x[l];
+            T t = x[l];
             x[l] = x[l + jrel];
             x[l + jrel] = t;
         }

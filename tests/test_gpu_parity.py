@@ -225,6 +225,23 @@ def test_hit_budget_splits_passes(fs, oracle, tmp_path, monkeypatch):
     oracle_vs_gpu(fs, oracle, synthprot.synthprot(400, 150, 84), kw, tmp_path)
 
 
+def test_huge_family_over_4096_candidates_per_query(fs, oracle, tmp_path):
+    """one 6000-member family: every query collects > 4096 candidates, which takes the global-memory
+    variant of the exact wave quicksort (phase 2 ordering) instead of the LDS one."""
+    rng = np.random.default_rng(11)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    anc = aa[rng.integers(0, 20, 150)]
+    recs = []
+    for i in range(6000):
+        b = anc.copy()
+        m = rng.random(150) < rng.uniform(0.05, 0.3)
+        b[m] = aa[rng.integers(0, 20, int(m.sum()))]
+        recs.append(">f%d\n%s\n" % (i, b.tobytes().decode()))
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=3000017, chk=50000, step=1, v=500, expect=1e-5, flt="T", thr=100000)
+    c, _ = oracle_vs_gpu(fs, oracle, "".join(recs).encode(), kw, tmp_path, sub=(17, 23))
+    assert c["candidates"] > 6 * 4096
+
+
 def test_exact_threshold_replay(fs, oracle, monkeypatch):
     """the rare exact get_mu_sd replay path gives the same threshold as the integer-sum path"""
     from swiftortho_amd import synthprot
