@@ -194,6 +194,8 @@ struct ChunkIndex {
     u32 maxslen = 0;
     DevBuf<u32> start;    // NC + 1
     DevBuf<u64> entries;  // E
+    DevBuf<u64> dkeys;    // E: per-entry key addends for the layout (d_sh_subj, d_sh_diag) -- k_encode_delta
+    int d_sh_subj = -1, d_sh_diag = -1;
 };
 
 }  // namespace
@@ -534,7 +536,7 @@ void build_index(so_ctx* c) {
         HIP_CHECK(hipMemcpyAsync(stats, c->d_stats.p, sizeof stats, hipMemcpyDeviceToHost, c->st));
         HIP_CHECK(hipStreamSynchronize(c->st));
         const u64 E64 = stats[0];
-        if (E64 >= 0xFFFFFFF0ull) throw SoError("chunk index exceeds 2^32 entries; lower -c");
+        if (E64 >= (1ull << 29)) throw SoError("chunk index exceeds 2^29 entries (the lookup kernel addresses 8-byte slots with 32-bit byte offsets); lower -c");
         ch->E = (u32)E64;
         ch->threshold = chunk_threshold(c, ch->start.p, stats[0], stats[1], stats[2]);
         // inclusive scan in place: start[b] = end of bucket b; the fill pass walks it back to the begin
@@ -566,7 +568,7 @@ struct Batch {
     DevBuf<u32> qbucket, korder, sbeg, scnt, pcnt, eff, nz, hoff, cidx;
     DevBuf<int> ksc;
     DevBuf<u8> mark;
-    DevBuf<u32> cs_hoff, cs_beg, blk_first;
+    DevBuf<u32> cs_hoff, cs_beg, blk_first, qseg;
     DevBuf<unsigned long long> qhits;
     DevBuf<u64> cs_kbase;
     DevBuf<u64> keys, keys2;
@@ -694,7 +696,7 @@ struct ProfTimer {
 };
 
 // seed stage of one (batch, chunk): candidates appended to the batch's candidate store
-void seed_pass(so_ctx* c, Batch& b, int ci, u32 p_lo, u32 p_hi, double t0, StageClock& sc);
+void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageClock& sc);
 
 void seed_stage(so_ctx* c, Batch& b, int ci) {
     ChunkIndex& ch = *c->chunks[ci];
@@ -727,14 +729,15 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
         u32 qb = qa;
         while (qb < b.nq && (qb == qa || acc + qh[qb] <= budget)) acc += qh[qb++];
         if (acc >= 0xFFFFFFF0ull) throw SoError("a single query visits >= 2^32 index entries in one chunk: lower -c");
-        if (acc) seed_pass(c, b, ci, b.h_off[qa] + qa, b.h_off[qb] + qb, wall(), sc);
+        if (acc) seed_pass(c, b, ci, qa, qb, wall(), sc);
         qa = qb;
     }
 }
 
-// one hit-budgeted pass of the seed stage: queries whose packed positions lie in [p_lo, p_hi)
-void seed_pass(so_ctx* c, Batch& b, int ci, u32 p_lo, u32 p_hi, double t0, StageClock& sc) {
+// one hit-budgeted pass of the seed stage: batch queries [qa, qb) = packed positions [p_lo, p_hi)
+void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageClock& sc) {
     ChunkIndex& ch = *c->chunks[ci];
+    const u32 p_lo = b.h_off[qa] + qa, p_hi = b.h_off[qb] + qb;
     const int AS = c->cfg.A * c->cfg.S;
     const u32 Ppad = b.dev.Ppad;
     const size_t T = (size_t)AS * Ppad;
@@ -767,24 +770,40 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 p_lo, u32 p_hi, double t0, Stage
     b.cs_hoff.ensure((size_t)K + 2), b.cs_beg.ensure((size_t)K + 2), b.cs_kbase.ensure((size_t)K + 2);
     launch_compact_seeds(b.eff.p, b.hoff.p, b.cidx.p, b.sbeg.p, b.dev.d_pseq.p, b.dev.d_off.p, Ppad, AS, kl, b.cs_hoff.p, b.cs_beg.p,
                          b.cs_kbase.p, c->st);
+    if (ch.d_sh_subj != kl.sh_subj || ch.d_sh_diag != kl.sh_diag) {  // (re-)encode the chunk's key addends for this layout
+        ch.dkeys.ensure((size_t)ch.E + 2);
+        launch_encode_delta(ch.entries.p, ch.E, kl.sh_subj, kl.sh_diag, ch.maxslen, ch.dkeys.p, c->st);
+        ch.d_sh_subj = kl.sh_subj, ch.d_sh_diag = kl.sh_diag;
+    }
     b.blk_first.ensure((size_t)lookup_num_blocks(H) + 2);
     launch_lookup_blockfirst(b.cs_hoff.p, K, H, b.blk_first.p, c->st);
     b.keys.ensure((size_t)H + 2), b.keys2.ensure((size_t)H + 2);
     {
         ProfTimer pt(c, &c->cnt.lookup_ms, &c->cnt.lookup_launches);
-        launch_lookup(b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, b.blk_first.p, K, H, ch.entries.p, c->ref.d_off.p + ch.seq_lo, kl,
-                      b.keys.p, c->st);
+        launch_lookup(b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, b.blk_first.p, K, H, ch.dkeys.p, c->ref.d_off.p + ch.seq_lo, kl,
+                      ch.maxslen, b.keys.p, c->st);
         pt.stop();
         if (c->profile) c->cnt.lookup_bytes += (i64)8 * (i64)H;
     }
     const double t1 = wall();
     sc.lap("seed.compact_lookup");
     // diagonal binning: sort keys, find group heads
+    // Hits are generated in (query, qpos, as) order (position-major seed ordinals) and the radix sorts are
+    // stable, so only the (subject, diagonal) bits need sorting, inside each query's segment: 2 radix passes
+    // fewer than a device-wide sort of the (query, subject, diagonal) bits.  One block sorts one segment, so
+    // passes with few queries (huge per-query hit lists) use the device-wide sort instead.
+    // (Dropped hits carry ~0 and sort last in their segment.)
+    static const int seg_mode = getenv("SOHIT_SEGSORT") ? atoi(getenv("SOHIT_SEGSORT")) : 1;
+    const u32 nseg = qb - qa;
+    if (seg_mode && nseg >= 256) {
+        b.qseg.ensure((size_t)b.nq + 4);
+        launch_query_segments(b.hoff.p, T, b.dev.d_off.p, b.nq, AS, H, b.qseg.p, c->st);
+        ensure_sort_tmp(c, sort_keys_u64_seg_temp_bytes(H, nseg, kl.sh_diag, kl.sh_q));
+        sort_keys_u64_seg(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.keys.p, b.keys2.p, H, nseg, b.qseg.p + qa, kl.sh_diag, kl.sh_q, c->st);
+    } else {
     ensure_sort_tmp(c, sort_keys_u64_temp_bytes(H, kl.total));
-    // Hits are generated in (query, qpos, as) order (position-major seed ordinals) and the radix sort is
-    // stable, so sorting on the (query, subject, diagonal) bits alone leaves every group ordered by query
-    // position -- one radix pass fewer than sorting the whole key.  (Dropped hits carry ~0 and sort last.)
     sort_keys_u64(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.keys.p, b.keys2.p, H, kl.sh_diag, kl.total, c->st);
+    }
     sc.lap("group.sort_keys");
     // group walk + chained ungapped extension (the kernel finds the group heads itself)
     const u32 shard_cap = ungap_shard_cap(H);

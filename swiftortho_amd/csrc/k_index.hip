@@ -122,6 +122,29 @@ __global__ __launch_bounds__(256) void k_index_counts_from_start(const u32* __re
     if (i < NC) counts[i] = start[i + 1] - start[i];
 }
 
+
+// ---- key deltas for the seed-lookup kernel ----------------------------------------------------------
+// For one key layout (sh_subj, sh_diag) every index entry contributes a FIXED 64-bit addend to the sort
+// key of any hit that visits it:   D = (subject << sh_subj) + ((maxslen - pos) << sh_diag) + tag,
+// so the lookup kernel computes  key = kbase(seed) + D  with one 64-bit add.  D < 2^sh_q <= 2^63, which
+// leaves bit 63 for the rare entries at offset 0 of their sequence (the reference attributes those to
+// the previous non-empty sequence, fsearch.py:134-153 strict bisect): they carry
+// (1 << 63) | (subject << 8) | tag and are resolved on a slow path.
+__global__ __launch_bounds__(256) void k_encode_delta(const u64* __restrict__ entries, u32 E, int sh_subj, int sh_diag, u32 maxslen,
+                                                      u64* __restrict__ dkeys) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= E) return;
+    const u64 e = entries[i];
+    const u32 j = (u32)(e >> 32), pos = (u32)e & 0xFFFFFFu, tag = (u32)(e >> 24) & 0xFFu;
+    dkeys[i] = pos == 0 ? ((1ull << 63) | ((u64)j << 8) | (u64)tag)
+                        : (((u64)j << sh_subj) + ((u64)(maxslen - pos) << sh_diag) + (u64)tag);
+}
+
+void launch_encode_delta(const u64* entries, u32 E, int sh_subj, int sh_diag, u32 maxslen, u64* dkeys, hipStream_t st) {
+    if (!E) return;
+    hipLaunchKernelGGL(k_encode_delta, dim3((E + 255) / 256), dim3(256), 0, st, entries, E, sh_subj, sh_diag, maxslen, dkeys);
+}
+
 void launch_index_count(const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
                         const SeedCfg& cfg, const HashLut& lut, u32 step, u32* start, hipStream_t st) {
     if (p_hi <= p_lo) return;

@@ -145,13 +145,15 @@ __global__ __launch_bounds__(256) void k_effcnt(const u8* __restrict__ mark, con
     nz[t] = c ? 1u : 0u;
 }
 
-// cs_*[k] for the k-th non-empty seed: first hit ordinal, first slot, and the key bits that do not
-// depend on the index entry: q, qpos, as and (qpos + diag_off) in the diagonal field, so that per
-// hit   key = kbase + (subject << sh_subj) - (sst << sh_diag) + tag.
+// Compacted seed list for the lookup kernel: one record per cap-selected seed window with a non-empty
+// bucket.  cs_hoff = first hit ordinal, cs_base = bucket begin - first hit ordinal (so that hit h reads
+// slot cs_base + h, u32 wrap-around intended), cs_kbase = the part of the sort key that does not
+// depend on the index entry: q, qpos (twice: diagonal field and position field) and as.  Per hit
+//   key = kbase + D(entry)      (k_index.hip: k_encode_delta).
 __global__ __launch_bounds__(256) void k_compact_seeds(const u32* __restrict__ eff, const u32* __restrict__ hoff,
                                                        const u32* __restrict__ cidx, const u32* __restrict__ sbeg,
                                                        const u32* __restrict__ q_pseq, const u32* __restrict__ qoff, u32 Ppad, int AS,
-                                                       KeyLayout kl, u32* __restrict__ cs_hoff, u32* __restrict__ cs_beg,
+                                                       KeyLayout kl, u32* __restrict__ cs_hoff, u32* __restrict__ cs_base,
                                                        u64* __restrict__ cs_kbase) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= (size_t)AS * Ppad) return;
@@ -161,20 +163,23 @@ __global__ __launch_bounds__(256) void k_compact_seeds(const u32* __restrict__ e
     const u32 q = q_pseq[p];
     const u32 qpos = p - (qoff[q] + q);
     cs_hoff[k] = hoff[t];
-    cs_beg[k] = sbeg[t];
-    cs_kbase[k] = ((u64)q << kl.sh_q) | ((u64)((i64)qpos + kl.diag_off) << kl.sh_diag) | ((u64)qpos << kl.sh_qpos) | ((u64)as << kl.sh_as);
+    cs_base[k] = sbeg[t] - hoff[t];
+    cs_kbase[k] = ((u64)q << kl.sh_q) | ((u64)qpos << kl.sh_diag) | ((u64)qpos << kl.sh_qpos) | ((u64)as << kl.sh_as);
 }
 
 // ---- the seed-lookup kernel ------------------------------------------------------------------------
-// Hit h (0 <= h < H) is slot cs_beg[k] + (h - cs_hoff[k]) of the compacted seed k that owns it.
-// Work unit = one WAVE: LW_HITS consecutive hit ordinals, no block-level barrier anywhere.  The
-// wave stages the first LW_SEEDS seeds that cover its range in LDS (further ones -- tiny buckets --
-// are read from global), builds an owner map (start marks + wave prefix-max) and then walks 64
-// consecutive ordinals per step: lanes read consecutive index slots (coalesced 8-byte entries, all
-// LW_ITERS loads of a lane in flight before the first use) and write consecutive 8-byte keys.
+// Hit h (0 <= h < H) is index slot cs_base[k] + h of the compacted seed k that owns it.
+// Work unit = one WAVE: LW_HITS consecutive hit ordinals, no block-level barrier anywhere.  The wave
+// loads the seeds that cover its range (base / kbase into LDS, start marks into an owner map) and then
+// walks 64 consecutive ordinals per step: owner = wave prefix-max of the marks (DPP scan, carried
+// across steps in an SGPR), lanes read consecutive index slots (coalesced 8-byte key deltas, all
+// LW_ITERS loads in flight before the first use) and write consecutive 8-byte keys.  A full tile with
+// <= LW_SEEDS seeds takes the branch-free fast path; the last (partial) tile and tiles of many tiny
+// buckets take a generic loop.
 // Subject resolution follows the reference's strict `soas[j] < x` rule: an entry at offset 0 of chunk
 // sequence j belongs to the previous non-empty sequence at sst = its length; at the chunk start it
-// resolves to index -1, can never score, and is dropped (key = ~0).
+// resolves to index -1, can never score, and is dropped (key = ~0).  Such entries are flagged in
+// bit 63 of their delta and redone after the main loop.
 #define LW_ITERS 8
 #define LW_HITS (64 * LW_ITERS)
 #define LW_SEEDS 256
@@ -205,115 +210,113 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(64 * LW_WAVES, 4) void k_lookup(const u32* __restrict__ cs_hoff, const u32* __restrict__ cs_beg,
+// inclusive max-scan over the 64 lanes (values >= 0): 4 row shifts + 2 row broadcasts, all DPP
+__device__ __forceinline__ u32 wave_scan_max(u32 x) {
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));  // row_shr:1
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));  // row_shr:2
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));  // row_shr:4
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));  // row_shr:8
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false)); // row_bcast:15 -> rows 1, 3
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false)); // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+// the reference's resolution of an entry at offset 0 of its sequence (flagged delta)
+__device__ __forceinline__ u64 lookup_offset0_key(u64 d, u64 kb, const u32* __restrict__ roff, const KeyLayout& kl, u32 maxslen) {
+    u32 j = (u32)(d >> 8) & 0x7FFFFFFFu;
+    const u32 tag = (u32)d & 0xFFu;
+    // previous NON-EMPTY sequence at sst = its length; none -> index -1 -> dropped
+    while (j > 0 && roff[j] == roff[j - 1]) --j;
+    if (j == 0) return ~0ull;
+    j -= 1;
+    const u32 sst = roff[j + 1] - roff[j];
+    return kb + ((u64)j << kl.sh_subj) + ((u64)(maxslen - sst) << kl.sh_diag) + (u64)tag;
+}
+
+__global__ __launch_bounds__(64 * LW_WAVES, 8) void k_lookup(const u32* __restrict__ cs_hoff, const u32* __restrict__ cs_base,
                                                           const u64* __restrict__ cs_kbase, const u32* __restrict__ wave_first, u32 K,
-                                                          u32 H, u32 nw, const u64* __restrict__ entries,
-                                                          const u32* __restrict__ roff /*chunk off*/, KeyLayout kl,
-                                                          u64* __restrict__ keys, int variant /*diagnostic ablations; 0 = real*/) {
+                                                          u32 H, u32 nw, const u64* __restrict__ dkeys,
+                                                          const u32* __restrict__ roff /*chunk off*/, KeyLayout kl, u32 maxslen,
+                                                          u64* __restrict__ keys) {
     __shared__ u16 s_owner_all[LW_WAVES][LW_HITS];
-    __shared__ u32 s_off_all[LW_WAVES][LW_SEEDS];
-    __shared__ u32 s_beg_all[LW_WAVES][LW_SEEDS];
+    __shared__ u32 s_base_all[LW_WAVES][LW_SEEDS];
     __shared__ u64 s_kb_all[LW_WAVES][LW_SEEDS];
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 wid = blockIdx.x * LW_WAVES + w;
+    const u32 wid = __builtin_amdgcn_readfirstlane(blockIdx.x * LW_WAVES + w);
     if (wid >= nw) return;
     u16* s_owner = s_owner_all[w];
-    u32* s_off = s_off_all[w];
-    u32* s_beg = s_beg_all[w];
+    u32* s_base = s_base_all[w];
     u64* s_kb = s_kb_all[w];
-    const u32 k0 = wave_first[wid];
-    u32 k1 = wave_first[wid + 1];
+    const u32 k0 = __builtin_amdgcn_readfirstlane(wave_first[wid]);
+    u32 k1 = __builtin_amdgcn_readfirstlane(wave_first[wid + 1]);
     if (k1 >= K) k1 = K - 1;
     const u32 ns = k1 - k0 + 1;  // <= LW_HITS + 1
     const u32 lo = wid * LW_HITS;
-    const u32 nl = ns < LW_SEEDS ? ns : LW_SEEDS;
     {
-        uint4 z = make_uint4(0, 0, 0, 0);  // LW_HITS u16, 16 B per lane and store
-        for (u32 i = lane; i < LW_HITS / 8; i += 64) reinterpret_cast<uint4*>(s_owner)[i] = z;
-    }
-    for (u32 i = lane; i < nl; i += 64) {
-        s_off[i] = cs_hoff[k0 + i];
-        s_beg[i] = cs_beg[k0 + i];
-        s_kb[i] = cs_kbase[k0 + i];
+        uint4 z = make_uint4(0, 0, 0, 0);  // LW_HITS u16 marks, 16 B per lane and store
+#pragma unroll
+        for (u32 i = 0; i < LW_HITS / 8 / 64; ++i) reinterpret_cast<uint4*>(s_owner)[i * 64 + lane] = z;
     }
     wave_lds_sync();
-    for (u32 i = lane + 1; i < ns; i += 64) {
-        const u32 o = (i < LW_SEEDS ? s_off[i] : cs_hoff[k0 + i]) - lo;
-        if (o < LW_HITS) s_owner[o] = (u16)i;
+    // seed i (relative to k0) starts at ordinal cs_hoff[k0 + i]; seed 0 covers the tile start
+    for (u32 i = lane; i < ns; i += 64) {
+        if (i < LW_SEEDS) {
+            s_base[i] = cs_base[k0 + i];
+            s_kb[i] = cs_kbase[k0 + i];
+        }
+        if (i) {
+            const u32 o = cs_hoff[k0 + i] - lo;
+            if (o < LW_HITS) s_owner[o] = (u16)i;
+        }
     }
     wave_lds_sync();
-    {  // prefix-max over the wave's 1024 owner marks: 16 consecutive per lane + wave scan
-        const u32 b = lane * LW_ITERS;
-        u32 v[LW_ITERS], m = 0;
+    u64* const kp = keys + lo;  // wave-uniform base: the per-lane part is lane * 8 + constant
+    if (ns <= LW_SEEDS && lo + LW_HITS <= H) {
+        // ---- fast path: full tile, every seed staged in LDS ----
+        u64 e[LW_ITERS];
+        u32 own[LW_ITERS];
+        u32 carry = 0;
 #pragma unroll
-        for (int k = 0; k < LW_ITERS; ++k) {
-            m = max(m, (u32)s_owner[b + k]);
-            v[k] = m;
-        }
-        u32 inc = m;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const u32 t = __shfl_up(inc, o);
-            if ((int)lane >= o) inc = max(inc, t);
-        }
-        u32 pre = __shfl_up(inc, 1);
-        if (lane == 0) pre = 0;
-#pragma unroll
-        for (int k = 0; k < LW_ITERS; ++k) s_owner[b + k] = (u16)max(v[k], pre);
-    }
-    wave_lds_sync();
-    u64 e[LW_ITERS];
-    u32 own[LW_ITERS];
-#pragma unroll
-    for (int it = 0; it < LW_ITERS; ++it) {
-        const u32 hl = it * 64 + lane, h = lo + hl;
-        e[it] = 0;
-        own[it] = 0;
-        if (h < H) {
-            const u32 a = s_owner[hl];
-            own[it] = a;
-            const u32 beg = a < LW_SEEDS ? s_beg[a] : cs_beg[k0 + a], off = a < LW_SEEDS ? s_off[a] : cs_hoff[k0 + a];
-            if (variant == 1) e[it] = ((u64)(hl & 1023u) << 32) | 5u;  // ablation: no index-entry read
-            else e[it] = entries[beg + (h - off)];
-        }
-    }
-    u32 fix = 0;  // iterations whose entry sits at offset 0 of its sequence (rare): redone below
-#pragma unroll
-    for (int it = 0; it < LW_ITERS; ++it) {
-        const u32 hl = it * 64 + lane, h = lo + hl;
-        if (h >= H) continue;
-        const u32 a = own[it];
-        const u64 kb = a < LW_SEEDS ? s_kb[a] : cs_kbase[k0 + a];
-        const u32 j = (u32)(e[it] >> 32), pos = (u32)e[it] & 0xFFFFFFu, tag = (u32)(e[it] >> 24) & 0xFFu;
-        if (pos == 0) fix |= 1u << it;
-        const u64 key = kb + ((u64)j << kl.sh_subj) - ((u64)pos << kl.sh_diag) + (u64)tag;
-        if (variant == 2) {
-            if (key == 0x1234567ull) keys[h] = key;  // ablation: (practically) no key write
-        } else {
-            keys[h] = key;
-        }
-    }
-    if (fix) {
-#pragma unroll 1
         for (int it = 0; it < LW_ITERS; ++it) {
-            if (!((fix >> it) & 1u)) continue;
-            const u32 hl = it * 64 + lane, h = lo + hl;
-            const u32 a = s_owner[hl];
-            const u32 beg = a < LW_SEEDS ? s_beg[a] : cs_beg[k0 + a], off = a < LW_SEEDS ? s_off[a] : cs_hoff[k0 + a];
-            const u64 kb = a < LW_SEEDS ? s_kb[a] : cs_kbase[k0 + a];
-            const u64 en = entries[beg + (h - off)];
-            u32 j = (u32)(en >> 32);
-            const u32 tag = (u32)(en >> 24) & 0xFFu;
-            // previous NON-EMPTY sequence at sst = its length; none -> index -1 -> dropped
-            while (j > 0 && roff[j] == roff[j - 1]) --j;
-            u64 key = ~0ull;
-            if (j > 0) {
-                j -= 1;
-                const u32 sst = roff[j + 1] - roff[j];
-                key = kb + ((u64)j << kl.sh_subj) - ((u64)sst << kl.sh_diag) + (u64)tag;
-            }
-            if (variant != 2) keys[h] = key;
+            const u32 inc = wave_scan_max((u32)s_owner[it * 64 + lane]);
+            const u32 a = max(inc, carry);
+            carry = max(carry, (u32)__builtin_amdgcn_readlane((int)inc, 63));
+            own[it] = a;
+            const u32 byte_off = (s_base[a] + (lo + it * 64 + lane)) << 3;  // < 2^32: chunk entries < 2^29 (host check)
+            e[it] = *reinterpret_cast<const u64*>(reinterpret_cast<const char*>(dkeys) + byte_off);
         }
+        u32 fix = 0;
+#pragma unroll
+        for (int it = 0; it < LW_ITERS; ++it) {
+            kp[it * 64 + lane] = s_kb[own[it]] + e[it];
+            fix |= (u32)(e[it] >> 63) << it;
+        }
+        if (fix) {  // rare: entries at offset 0 of their sequence
+#pragma unroll 1
+            for (int it = 0; it < LW_ITERS; ++it) {
+                if (!((fix >> it) & 1u)) continue;
+                const u32 hl = it * 64 + lane;
+                u32 a = 0;
+                for (u32 i = 1; i < ns; ++i)
+                    if (cs_hoff[k0 + i] - lo <= hl) a = i;
+                kp[hl] = lookup_offset0_key(dkeys[s_base[a] + lo + hl], s_kb[a], roff, kl, maxslen);
+            }
+        }
+        return;
+    }
+    // ---- generic path: partial last tile, or more seeds than the LDS stage holds ----
+    u32 carry = 0;
+#pragma unroll 1
+    for (int it = 0; it < LW_ITERS; ++it) {
+        const u32 hl = it * 64 + lane, h = lo + hl;
+        const u32 inc = wave_scan_max((u32)s_owner[hl]);
+        const u32 a = max(inc, carry);
+        carry = max(carry, (u32)__builtin_amdgcn_readlane((int)inc, 63));
+        if (h >= H) continue;
+        const u32 base = a < LW_SEEDS ? s_base[a] : cs_base[k0 + a];
+        const u64 kb = a < LW_SEEDS ? s_kb[a] : cs_kbase[k0 + a];
+        const u64 d = dkeys[base + h];
+        keys[h] = (d >> 63) ? lookup_offset0_key(d, kb, roff, kl, maxslen) : kb + d;
     }
 }
 
@@ -349,11 +352,11 @@ void launch_effcnt(const u8* mark, const u32* scnt, u32 Ppad, int AS, u32 p_lo, 
 }
 
 void launch_compact_seeds(const u32* eff, const u32* hoff, const u32* cidx, const u32* sbeg, const u32* q_pseq, const u32* qoff,
-                          u32 Ppad, int AS, const KeyLayout& kl, u32* cs_hoff, u32* cs_beg, u64* cs_kbase, hipStream_t st) {
+                          u32 Ppad, int AS, const KeyLayout& kl, u32* cs_hoff, u32* cs_base, u64* cs_kbase, hipStream_t st) {
     size_t T = (size_t)AS * Ppad;
     if (!T) return;
     hipLaunchKernelGGL(k_compact_seeds, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, eff, hoff, cidx, sbeg, q_pseq, qoff,
-                       Ppad, AS, kl, cs_hoff, cs_beg, cs_kbase);
+                       Ppad, AS, kl, cs_hoff, cs_base, cs_kbase);
 }
 
 u32 lookup_num_blocks(u32 H) { return (H + LW_HITS - 1) / LW_HITS; }  // number of lookup WAVES
@@ -363,11 +366,10 @@ void launch_lookup_blockfirst(const u32* cs_hoff, u32 K, u32 H, u32* wave_first,
     hipLaunchKernelGGL(k_lookup_blockfirst, dim3((nw + 1 + 255) / 256), dim3(256), 0, st, cs_hoff, K, H, nw, wave_first);
 }
 
-void launch_lookup(const u32* cs_hoff, const u32* cs_beg, const u64* cs_kbase, const u32* wave_first, u32 K, u32 H,
-                   const u64* entries, const u32* roff, const KeyLayout& kl, u64* keys, hipStream_t st) {
+void launch_lookup(const u32* cs_hoff, const u32* cs_base, const u64* cs_kbase, const u32* wave_first, u32 K, u32 H,
+                   const u64* dkeys, const u32* roff, const KeyLayout& kl, u32 maxslen, u64* keys, hipStream_t st) {
     if (!H) return;
-    static const int variant = getenv("SOHIT_LK_VARIANT") ? atoi(getenv("SOHIT_LK_VARIANT")) : 0;
     const u32 nw = lookup_num_blocks(H);
-    hipLaunchKernelGGL(k_lookup, dim3((nw + LW_WAVES - 1) / LW_WAVES), dim3(64 * LW_WAVES), 0, st, cs_hoff, cs_beg, cs_kbase, wave_first,
-                       K, H, nw, entries, roff, kl, keys, variant);
+    hipLaunchKernelGGL(k_lookup, dim3((nw + LW_WAVES - 1) / LW_WAVES), dim3(64 * LW_WAVES), 0, st, cs_hoff, cs_base, cs_kbase, wave_first,
+                       K, H, nw, dkeys, roff, kl, maxslen, keys);
 }
