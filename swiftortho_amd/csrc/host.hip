@@ -195,7 +195,8 @@ struct ChunkIndex {
     DevBuf<u32> start;    // NC + 1
     DevBuf<u64> entries;  // E
     DevBuf<u64> dkeys;    // E: per-entry key addends for the layout (d_sh_subj, d_sh_diag) -- k_encode_delta
-    int d_sh_subj = -1, d_sh_diag = -1;
+    DevBuf<u32> dk32;     // E: compact addends for field widths (d_ba, d_bd) -- k_encode_delta32
+    int d_sh_subj = -1, d_sh_diag = -1, d_ba = -1, d_bd = -1;
 };
 
 }  // namespace
@@ -770,7 +771,16 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     b.cs_hoff.ensure((size_t)K + 2), b.cs_beg.ensure((size_t)K + 2), b.cs_kbase.ensure((size_t)K + 2);
     launch_compact_seeds(b.eff.p, b.hoff.p, b.cidx.p, b.sbeg.p, b.dev.d_pseq.p, b.dev.d_off.p, Ppad, AS, kl, b.cs_hoff.p, b.cs_beg.p,
                          b.cs_kbase.p, c->st);
-    if (ch.d_sh_subj != kl.sh_subj || ch.d_sh_diag != kl.sh_diag) {  // (re-)encode the chunk's key addends for this layout
+    // per-entry key addends for this layout: 4-byte compact form whenever the fields fit, else 8-byte
+    const bool force_wide = getenv("SOHIT_LK_WIDE") && atoi(getenv("SOHIT_LK_WIDE")) != 0;
+    const bool compact = !force_wide && (kl.bs + kl.bd + kl.ba <= 32);
+    if (compact) {
+        if (ch.d_ba != kl.ba || ch.d_bd != kl.bd) {
+            ch.dk32.ensure((size_t)ch.E + 4);
+            launch_encode_delta32(ch.entries.p, ch.E, kl.ba, kl.bd, ch.maxslen, ch.dk32.p, c->st);
+            ch.d_ba = kl.ba, ch.d_bd = kl.bd;
+        }
+    } else if (ch.d_sh_subj != kl.sh_subj || ch.d_sh_diag != kl.sh_diag) {
         ch.dkeys.ensure((size_t)ch.E + 2);
         launch_encode_delta(ch.entries.p, ch.E, kl.sh_subj, kl.sh_diag, ch.maxslen, ch.dkeys.p, c->st);
         ch.d_sh_subj = kl.sh_subj, ch.d_sh_diag = kl.sh_diag;
@@ -780,20 +790,21 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     b.keys.ensure((size_t)H + 2), b.keys2.ensure((size_t)H + 2);
     {
         ProfTimer pt(c, &c->cnt.lookup_ms, &c->cnt.lookup_launches);
-        launch_lookup(b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, b.blk_first.p, K, H, ch.dkeys.p, c->ref.d_off.p + ch.seq_lo, kl,
-                      ch.maxslen, b.keys.p, c->st);
+        launch_lookup(b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, b.blk_first.p, K, H, compact ? (const void*)ch.dk32.p : (const void*)ch.dkeys.p,
+                      compact, c->ref.d_off.p + ch.seq_lo, kl, ch.maxslen, b.keys.p, c->st);
         pt.stop();
         if (c->profile) c->cnt.lookup_bytes += (i64)8 * (i64)H;
     }
     const double t1 = wall();
     sc.lap("seed.compact_lookup");
+    if (getenv("SOHIT_LK_VARIANT") && (atoi(getenv("SOHIT_LK_VARIANT")) == 1 || atoi(getenv("SOHIT_LK_VARIANT")) == 2)) return;  // ablation runs time the lookup only: keys are not valid
     // diagonal binning: sort keys, find group heads
     // Hits are generated in (query, qpos, as) order (position-major seed ordinals) and the radix sorts are
     // stable, so only the (subject, diagonal) bits need sorting, inside each query's segment: 2 radix passes
     // fewer than a device-wide sort of the (query, subject, diagonal) bits.  One block sorts one segment, so
     // passes with few queries (huge per-query hit lists) use the device-wide sort instead.
     // (Dropped hits carry ~0 and sort last in their segment.)
-    static const int seg_mode = getenv("SOHIT_SEGSORT") ? atoi(getenv("SOHIT_SEGSORT")) : 1;
+    const int seg_mode = getenv("SOHIT_SEGSORT") ? atoi(getenv("SOHIT_SEGSORT")) : 1;
     const u32 nseg = qb - qa;
     if (seg_mode && nseg >= 256) {
         b.qseg.ensure((size_t)b.nq + 4);

@@ -180,13 +180,15 @@ __global__ __launch_bounds__(256) void k_compact_seeds(const u32* __restrict__ e
 // sequence j belongs to the previous non-empty sequence at sst = its length; at the chunk start it
 // resolves to index -1, can never score, and is dropped (key = ~0).  Such entries are flagged in
 // bit 63 of their delta and redone after the main loop.
-#define LW_ITERS 8
-#define LW_HITS (64 * LW_ITERS)
 #define LW_SEEDS 256
 #define LW_WAVES 4
+static int lw_iters() {  // 64-hit steps per wave tile (tuning knob; config 2: 4 -> 0.54 ms, 8 -> 0.48 ms, 16 -> 0.46 ms)
+    static const int v = getenv("SOHIT_LK_ITERS") ? atoi(getenv("SOHIT_LK_ITERS")) : 16;
+    return v == 4 || v == 8 ? v : 16;
+}
 
 // first compacted seed of every lookup wave: largest k with cs_hoff[k] <= wave * LW_HITS
-__global__ __launch_bounds__(256) void k_lookup_blockfirst(const u32* __restrict__ cs_hoff, u32 K, u32 H, u32 nw,
+__global__ __launch_bounds__(256) void k_lookup_blockfirst(const u32* __restrict__ cs_hoff, u32 K, u32 H, u32 nw, u32 LW_HITS,
                                                            u32* __restrict__ wave_first) {
     const u32 b = blockIdx.x * 256u + threadIdx.x;
     if (b > nw) return;
@@ -222,9 +224,7 @@ __device__ __forceinline__ u32 wave_scan_max(u32 x) {
 }
 
 // the reference's resolution of an entry at offset 0 of its sequence (flagged delta)
-__device__ __forceinline__ u64 lookup_offset0_key(u64 d, u64 kb, const u32* __restrict__ roff, const KeyLayout& kl, u32 maxslen) {
-    u32 j = (u32)(d >> 8) & 0x7FFFFFFFu;
-    const u32 tag = (u32)d & 0xFFu;
+__device__ __forceinline__ u64 lookup_offset0_key(u32 j, u32 tag, u64 kb, const u32* __restrict__ roff, const KeyLayout& kl, u32 maxslen) {
     // previous NON-EMPTY sequence at sst = its length; none -> index -1 -> dropped
     while (j > 0 && roff[j] == roff[j - 1]) --j;
     if (j == 0) return ~0ull;
@@ -233,11 +233,36 @@ __device__ __forceinline__ u64 lookup_offset0_key(u64 d, u64 kb, const u32* __re
     return kb + ((u64)j << kl.sh_subj) + ((u64)(maxslen - sst) << kl.sh_diag) + (u64)tag;
 }
 
+// ENT = u32: compact addends (k_encode_delta32), ENT = u64: full addends (k_encode_delta)
+template <class ENT>
+struct Addend;
+template <>
+struct Addend<u64> {
+    static __device__ __forceinline__ u64 expand(u64 d, const KeyLayout&) { return d; }
+    static __device__ __forceinline__ bool offset0(u64 d, const KeyLayout&) { return (d >> 63) != 0; }
+    static __device__ __forceinline__ u32 subj(u64 d, const KeyLayout&) { return (u32)(d >> 8) & 0x7FFFFFFFu; }
+    static __device__ __forceinline__ u32 tag(u64 d, const KeyLayout&) { return (u32)d & 0xFFu; }
+};
+template <>
+struct Addend<u32> {
+    static __device__ __forceinline__ u64 expand(u32 c, const KeyLayout& kl) {
+        return kl.ba ? (((u64)(c >> kl.ba) << kl.sh_diag) + (u64)(c & ((1u << kl.ba) - 1u))) : ((u64)c << kl.sh_diag);
+    }
+    static __device__ __forceinline__ bool offset0(u32 c, const KeyLayout& kl) {
+        const u32 m = ((1u << kl.bd) - 1u) << kl.ba;
+        return (c & m) == m;
+    }
+    static __device__ __forceinline__ u32 subj(u32 c, const KeyLayout& kl) { return c >> (kl.bd + kl.ba); }
+    static __device__ __forceinline__ u32 tag(u32 c, const KeyLayout& kl) { return c & ((1u << kl.ba) - 1u); }
+};
+
+template <int LW_ITERS, int VAR /*0 = real; diagnostic ablations: 1 = no index read, 2 = no key write, 3 = plain (temporal) key stores*/, class ENT>
 __global__ __launch_bounds__(64 * LW_WAVES, 8) void k_lookup(const u32* __restrict__ cs_hoff, const u32* __restrict__ cs_base,
                                                           const u64* __restrict__ cs_kbase, const u32* __restrict__ wave_first, u32 K,
-                                                          u32 H, u32 nw, const u64* __restrict__ dkeys,
+                                                          u32 H, u32 nw, const ENT* __restrict__ dkeys,
                                                           const u32* __restrict__ roff /*chunk off*/, KeyLayout kl, u32 maxslen,
                                                           u64* __restrict__ keys) {
+    constexpr u32 LW_HITS = 64 * LW_ITERS;
     __shared__ u16 s_owner_all[LW_WAVES][LW_HITS];
     __shared__ u32 s_base_all[LW_WAVES][LW_SEEDS];
     __shared__ u64 s_kb_all[LW_WAVES][LW_SEEDS];
@@ -253,9 +278,9 @@ __global__ __launch_bounds__(64 * LW_WAVES, 8) void k_lookup(const u32* __restri
     const u32 ns = k1 - k0 + 1;  // <= LW_HITS + 1
     const u32 lo = wid * LW_HITS;
     {
-        uint4 z = make_uint4(0, 0, 0, 0);  // LW_HITS u16 marks, 16 B per lane and store
+        // LW_HITS u16 marks = LW_ITERS * 128 B: 8 B per lane and store
 #pragma unroll
-        for (u32 i = 0; i < LW_HITS / 8 / 64; ++i) reinterpret_cast<uint4*>(s_owner)[i * 64 + lane] = z;
+        for (u32 i = 0; i < LW_ITERS / 4; ++i) reinterpret_cast<uint2*>(s_owner)[i * 64 + lane] = make_uint2(0, 0);
     }
     wave_lds_sync();
     // seed i (relative to k0) starts at ordinal cs_hoff[k0 + i]; seed 0 covers the tile start
@@ -273,7 +298,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 8) void k_lookup(const u32* __restri
     u64* const kp = keys + lo;  // wave-uniform base: the per-lane part is lane * 8 + constant
     if (ns <= LW_SEEDS && lo + LW_HITS <= H) {
         // ---- fast path: full tile, every seed staged in LDS ----
-        u64 e[LW_ITERS];
+        ENT e[LW_ITERS];
         u32 own[LW_ITERS];
         u32 carry = 0;
 #pragma unroll
@@ -282,14 +307,24 @@ __global__ __launch_bounds__(64 * LW_WAVES, 8) void k_lookup(const u32* __restri
             const u32 a = max(inc, carry);
             carry = max(carry, (u32)__builtin_amdgcn_readlane((int)inc, 63));
             own[it] = a;
-            const u32 byte_off = (s_base[a] + (lo + it * 64 + lane)) << 3;  // < 2^32: chunk entries < 2^29 (host check)
-            e[it] = *reinterpret_cast<const u64*>(reinterpret_cast<const char*>(dkeys) + byte_off);
+            const u32 byte_off = (s_base[a] + (lo + it * 64 + lane)) * (u32)sizeof(ENT);  // < 2^32: chunk entries < 2^29 (host check)
+            if (VAR == 1) e[it] = (ENT)(byte_off >> 4);
+            else e[it] = *reinterpret_cast<const ENT*>(reinterpret_cast<const char*>(dkeys) + byte_off);
         }
         u32 fix = 0;
 #pragma unroll
         for (int it = 0; it < LW_ITERS; ++it) {
-            kp[it * 64 + lane] = s_kb[own[it]] + e[it];
-            fix |= (u32)(e[it] >> 63) << it;
+            const u64 key = s_kb[own[it]] + Addend<ENT>::expand(e[it], kl);
+            if (VAR == 2) {
+                if (key == 0x1234567ull) kp[it * 64 + lane] = key;
+            } else if (VAR == 3) {
+                kp[it * 64 + lane] = key;
+            } else {
+                // streamed once, read back by the sort: non-temporal stores keep the 1.9 GB key stream from evicting
+                // the index addends out of L2 / Infinity Cache (0.64 -> 0.47 ms on config 2)
+                __builtin_nontemporal_store(key, kp + it * 64 + lane);
+            }
+            if (VAR == 0 || VAR == 3) fix |= (u32)Addend<ENT>::offset0(e[it], kl) << it;
         }
         if (fix) {  // rare: entries at offset 0 of their sequence
 #pragma unroll 1
@@ -299,7 +334,8 @@ __global__ __launch_bounds__(64 * LW_WAVES, 8) void k_lookup(const u32* __restri
                 u32 a = 0;
                 for (u32 i = 1; i < ns; ++i)
                     if (cs_hoff[k0 + i] - lo <= hl) a = i;
-                kp[hl] = lookup_offset0_key(dkeys[s_base[a] + lo + hl], s_kb[a], roff, kl, maxslen);
+                const ENT d = dkeys[s_base[a] + lo + hl];
+                kp[hl] = lookup_offset0_key(Addend<ENT>::subj(d, kl), Addend<ENT>::tag(d, kl), s_kb[a], roff, kl, maxslen);
             }
         }
         return;
@@ -315,8 +351,9 @@ __global__ __launch_bounds__(64 * LW_WAVES, 8) void k_lookup(const u32* __restri
         if (h >= H) continue;
         const u32 base = a < LW_SEEDS ? s_base[a] : cs_base[k0 + a];
         const u64 kb = a < LW_SEEDS ? s_kb[a] : cs_kbase[k0 + a];
-        const u64 d = dkeys[base + h];
-        keys[h] = (d >> 63) ? lookup_offset0_key(d, kb, roff, kl, maxslen) : kb + d;
+        const ENT d = dkeys[base + h];
+        keys[h] = Addend<ENT>::offset0(d, kl) ? lookup_offset0_key(Addend<ENT>::subj(d, kl), Addend<ENT>::tag(d, kl), kb, roff, kl, maxslen)
+                                              : kb + Addend<ENT>::expand(d, kl);
     }
 }
 
@@ -359,17 +396,34 @@ void launch_compact_seeds(const u32* eff, const u32* hoff, const u32* cidx, cons
                        Ppad, AS, kl, cs_hoff, cs_base, cs_kbase);
 }
 
-u32 lookup_num_blocks(u32 H) { return (H + LW_HITS - 1) / LW_HITS; }  // number of lookup WAVES
+u32 lookup_num_blocks(u32 H) { return (H + 64u * lw_iters() - 1) / (64u * lw_iters()); }  // number of lookup WAVES
 
 void launch_lookup_blockfirst(const u32* cs_hoff, u32 K, u32 H, u32* wave_first, hipStream_t st) {
     u32 nw = lookup_num_blocks(H);
-    hipLaunchKernelGGL(k_lookup_blockfirst, dim3((nw + 1 + 255) / 256), dim3(256), 0, st, cs_hoff, K, H, nw, wave_first);
+    hipLaunchKernelGGL(k_lookup_blockfirst, dim3((nw + 1 + 255) / 256), dim3(256), 0, st, cs_hoff, K, H, nw, 64u * lw_iters(), wave_first);
 }
 
 void launch_lookup(const u32* cs_hoff, const u32* cs_base, const u64* cs_kbase, const u32* wave_first, u32 K, u32 H,
-                   const u64* dkeys, const u32* roff, const KeyLayout& kl, u32 maxslen, u64* keys, hipStream_t st) {
+                   const void* dkeys, bool compact, const u32* roff, const KeyLayout& kl, u32 maxslen, u64* keys, hipStream_t st) {
     if (!H) return;
     const u32 nw = lookup_num_blocks(H);
-    hipLaunchKernelGGL(k_lookup, dim3((nw + LW_WAVES - 1) / LW_WAVES), dim3(64 * LW_WAVES), 0, st, cs_hoff, cs_base, cs_kbase, wave_first,
-                       K, H, nw, dkeys, roff, kl, maxslen, keys);
+    static const int var = getenv("SOHIT_LK_VARIANT") ? atoi(getenv("SOHIT_LK_VARIANT")) : 0;
+    const dim3 g((nw + LW_WAVES - 1) / LW_WAVES), bl(64 * LW_WAVES);
+#define LK_LAUNCH(I, V)                                                                                                              \
+    do {                                                                                                                             \
+        if (compact)                                                                                                                 \
+            hipLaunchKernelGGL((k_lookup<I, V, u32>), g, bl, 0, st, cs_hoff, cs_base, cs_kbase, wave_first, K, H, nw, (const u32*)dkeys, \
+                               roff, kl, maxslen, keys);                                                                            \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((k_lookup<I, V, u64>), g, bl, 0, st, cs_hoff, cs_base, cs_kbase, wave_first, K, H, nw, (const u64*)dkeys, \
+                               roff, kl, maxslen, keys);                                                                            \
+    } while (0)
+    const int it = lw_iters();
+    if (var == 1) LK_LAUNCH(8, 1);
+    else if (var == 2) LK_LAUNCH(8, 2);
+    else if (var == 3) LK_LAUNCH(8, 3);
+    else if (it == 4) LK_LAUNCH(4, 0);
+    else if (it == 16) LK_LAUNCH(16, 0);
+    else LK_LAUNCH(8, 0);
+#undef LK_LAUNCH
 }

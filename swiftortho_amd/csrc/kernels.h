@@ -34,6 +34,7 @@ void launch_index_count(const u32* words, const u32* pseq, const u32* off, u32 p
 void launch_index_fill(const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
                        const SeedCfg& cfg, const HashLut& lut, u32 step, u32* start, u64* entries, hipStream_t st);
 void launch_index_stats(const u32* counts, u32 NC, u64* stats4, hipStream_t st);
+void launch_encode_delta32(const u64* entries, u32 E, int ba, int bd, u32 maxslen, u32* dk32, hipStream_t st);
 void launch_encode_delta(const u64* entries, u32 E, int sh_subj, int sh_diag, u32 maxslen, u64* dkeys, hipStream_t st);
 void launch_index_fixlast(const u32* start, u64* entries, u32 bstar, u32 E, hipStream_t st);
 void launch_index_counts_from_start(const u32* start, u32 NC, u32* counts, hipStream_t st);
@@ -52,7 +53,8 @@ void launch_compact_seeds(const u32* eff, const u32* hoff, const u32* cidx, cons
 u32 lookup_num_blocks(u32 H);
 void launch_lookup_blockfirst(const u32* cs_hoff, u32 K, u32 H, u32* wave_first, hipStream_t st);
 void launch_lookup(const u32* cs_hoff, const u32* cs_base, const u64* cs_kbase, const u32* wave_first, u32 K, u32 H,
-                   const u64* dkeys, const u32* roff, const KeyLayout& kl, u32 maxslen, u64* keys, hipStream_t st);
+                   const void* dkeys /*u32 (compact) or u64 addends*/, bool compact, const u32* roff, const KeyLayout& kl, u32 maxslen,
+                   u64* keys, hipStream_t st);
 
 // k_group.hip
 void launch_group_flags(const u64* keys, u32 H, const KeyLayout& kl, u32* flags, u32* hvalid, hipStream_t st);

@@ -242,6 +242,16 @@ def test_huge_family_over_4096_candidates_per_query(fs, oracle, tmp_path):
     assert c["candidates"] > 6 * 4096
 
 
+def test_wide_addends_and_device_wide_sort_paths(fs, oracle, tmp_path, monkeypatch):
+    """the 8-byte key-addend lookup path (taken when subject + diagonal + tag fields exceed 32 bits) and the
+    device-wide key sort (taken for passes with few queries), forced on an ordinary input"""
+    from swiftortho_amd import synthprot
+    monkeypatch.setenv("SOHIT_LK_WIDE", "1")
+    monkeypatch.setenv("SOHIT_SEGSORT", "0")
+    kw = dict(ssd="111111,1101011", nr=oracle.AA9, ht=2000003, chk=900, step=1, v=500, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, synthprot.synthprot(1300, 200, 86), kw, tmp_path)
+
+
 def test_exact_threshold_replay(fs, oracle, monkeypatch):
     """the rare exact get_mu_sd replay path gives the same threshold as the integer-sum path"""
     from swiftortho_amd import synthprot
