@@ -114,7 +114,8 @@ struct SeqSet {
     std::vector<u8> res;         // concatenated residues (raw bytes)
     u32 maxlen = 0;
     // device
-    DevBuf<u8> d_res, d_scls;
+    DevBuf<u8> d_res, d_scls_store;
+    struct { u8* p = nullptr; } d_scls;  // score classes; 16 readable bytes in front (k_ungap's left-pass windows start up to 8 bytes early)
     DevBuf<u32> d_off, d_words, d_pseq;
     u32 P = 0, Ppad = 0;
     HashLut lut;
@@ -316,7 +317,8 @@ void upload_constants(so_ctx* c) {
 void layout_set(so_ctx* c, SeqSet& s, const bool present[256], size_t nres, u32 nseq) {
     u8 hmap[256];
     build_hash_classes(present, c->codes, hmap, s.lut);
-    s.d_scls.ensure(nres + 64);
+    s.d_scls_store.ensure(nres + 64 + 16);
+    s.d_scls.p = s.d_scls_store.p + 16;
     HIP_CHECK(hipMemcpyAsync(c->d_hmap.p, hmap, 256, hipMemcpyHostToDevice, c->st));
     launch_scls(s.d_res.p, nres, c->d_smap.p, s.d_scls.p, c->st);
     if ((u64)nres + nseq + 64 > 0xFFFFFFF0ull) throw SoError("sequence set too large for 32-bit packed positions");

@@ -8,25 +8,7 @@
 #include "common.h"
 #include "kernels.h"
 
-// ---- group heads ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_group_flags(const u64* __restrict__ keys, u32 H, KeyLayout kl, u32* __restrict__ flags,
-                                                     u32* __restrict__ hvalid) {
-    const u32 h = blockIdx.x * 256u + threadIdx.x;
-    if (h >= H) return;
-    const u64 mask = (kl.total >= 64) ? ~0ull : ((1ull << kl.total) - 1ull);
-    const u64 qall = (1ull << kl.bq) - 1ull;
-    const u64 k = keys[h] & mask;
-    const bool valid = (k >> kl.sh_q) != qall;
-    bool head = false;
-    if (valid) {
-        if (h == 0) head = true;
-        else head = ((keys[h - 1] & mask) >> kl.sh_diag) != (k >> kl.sh_diag);
-        bool last = (h + 1 == H) || (((keys[h + 1] & mask) >> kl.sh_q) == qall);
-        if (last) *hvalid = h + 1;
-    }
-    flags[h] = head ? 1u : 0u;
-}
-
+// ---- segment heads of a flagged list ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_group_list(const u32* __restrict__ flags, const u32* __restrict__ gidx, u32 H,
                                                     u32* __restrict__ ghead) {
     const u32 h = blockIdx.x * 256u + threadIdx.x;
@@ -35,81 +17,12 @@ __global__ __launch_bounds__(256) void k_group_list(const u32* __restrict__ flag
 }
 
 // ---- chained ungapped extension -----------------------------------------------------------------
-struct UG {
-    int max_score, max_qst, max_qed, max_sst, max_sed;
-};
-
 #define B62_LD 36  // LDS score table: 32 rows of 36 bytes (9 dwords: rows rotate through all 32 banks); any 5-bit class pair indexes inside it
 
 __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global load
     u64 w;
     __builtin_memcpy(&w, p, 8);
     return w;
-}
-
-// Fasta.ungap (fsearch.py:2454-2494); qlo/slo already resolved to >= 0.
-// The reference's per-residue loops are evaluated in chunks of 8 residues: two unaligned 8-byte
-// loads, eight LDS score lookups issued back to back, and predicated (branch-free) max / X-drop
-// updates.  Scores, maxima and end points are exactly those of the sequential loops: an element
-// is applied only while `k < remaining && !stopped`.  qabs/sabs = absolute offsets of the two
-// sequences inside their (padded) class arrays, used to keep the left-pass loads in bounds.
-__device__ __forceinline__ UG ungap_dev(const u8* __restrict__ q, int ql, i64 qabs, const u8* __restrict__ s, int sl, i64 sabs, int Qst,
-                                        int Sst, int qlo, int slo, const signed char* b62c) {
-    const int off = max(max(qlo - Qst, slo - Sst), 0);
-    Qst += off;
-    Sst += off;
-    int max_score = 0, score = 0, best = -1;
-    bool stop = false;
-    // right pass: t-th step scores (Qst + t, Sst + t) while qlo < qst < ql and slo < sst < sl
-    int n = (qlo < Qst && slo < Sst) ? min(ql - Qst, sl - Sst) : 0;
-    for (int i = 0; i < n && !stop; i += 8) {
-        const u64 qw = load8u(q + Qst + i), sw = load8u(s + Sst + i);
-        const int m = n - i;
-        int sc[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sc[k] = b62c[(((u32)(qw >> (8 * k)) & 31u) * B62_LD) + ((u32)(sw >> (8 * k)) & 31u)];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const bool act = (k < m) && !stop;
-            const int ns = score + sc[k];
-            const bool better = act && (ns > max_score);
-            stop = stop || (act && !better && (ns + DROPX < max_score));
-            score = act ? ns : score;
-            max_score = better ? ns : max_score;
-            best = better ? i + k : best;
-        }
-    }
-    const int max_qed = best >= 0 ? Qst + best : Qst, max_sed = best >= 0 ? Sst + best : Sst;
-    // left pass from (Qst - 1, Sst - 1), score continues from the maximum
-    score = max_score;
-    stop = false;
-    best = -1;
-    n = (Qst - 1 < ql && Sst - 1 < sl) ? min(Qst - 1 - qlo, Sst - 1 - slo) : 0;
-    for (int i = 0; i < n && !stop; i += 8) {
-        // bytes [p - 7, p] with p = Qst - 1 - i; element k lives in byte 7 - k
-        i64 qa = (i64)Qst - 8 - i, sa = (i64)Sst - 8 - i;
-        u64 qw, sw;
-        if (qabs + qa >= 0) qw = load8u(q + qa);
-        else qw = load8u(q - qabs) << (8 * (int)(-(qabs + qa)));  // array start: missing low bytes are never active
-        if (sabs + sa >= 0) sw = load8u(s + sa);
-        else sw = load8u(s - sabs) << (8 * (int)(-(sabs + sa)));
-        const int m = n - i;
-        int sc[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sc[k] = b62c[(((u32)(qw >> (8 * (7 - k))) & 31u) * B62_LD) + ((u32)(sw >> (8 * (7 - k))) & 31u)];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const bool act = (k < m) && !stop;
-            const int ns = score + sc[k];
-            const bool better = act && (ns > max_score);
-            stop = stop || (act && !better && (ns + DROPX < max_score));
-            score = act ? ns : score;
-            max_score = better ? ns : max_score;
-            best = better ? i + k : best;
-        }
-    }
-    const int max_qst = best >= 0 ? Qst - 1 - best : Qst - 1, max_sst = best >= 0 ? Sst - 1 - best : Sst - 1;
-    return {max_score, max_qst, max_qed, max_sst, max_sed};
 }
 
 // ---- group walk + chained ungapped extension --------------------------------------------------------
@@ -129,6 +42,7 @@ __device__ __forceinline__ UG ungap_dev(const u8* __restrict__ q, int ql, i64 qa
 #define UW_QCAP 256     // group-head ring (u32 hit indices)
 #define UW_PCAP 192     // buffered pass records per wave
 #define UW_WAIT 20      // run the bookkeeping part when this many lanes wait for it
+#define UG_PIN (-(1 << 22))  // running score after an X-drop: below anything reachable, (UG_PIN - 8 * 128) << 8 fits int32
 
 enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN = 5 };
 
@@ -184,7 +98,7 @@ __global__ __launch_bounds__(64 * UW_WAVES) void k_ungap(const u64* __restrict__
     u64 ft = ~0ull, hkey = 0;
     u32 cq = 0xFFFFFFFFu, cqb = 0;  // last query looked up (groups arrive sorted by query)
     int cql = 0;
-    int Qst = 0, Sst = 0, qlo = 0, slo = 0, ci = 0, cn = 0, score = 0, max_score = 0, best = -1, r_qed = 0, r_sed = 0;
+    int Qst = 0, Sst = 0, qlo = 0, slo = 0, ci = 0, cn = 0, score = 0, mp = 255 /*packed running maximum*/, best = -1, r_qed = 0, r_sed = 0;
     bool stop = false;
 
     for (;;) {
@@ -286,7 +200,7 @@ __global__ __launch_bounds__(64 * UW_WAVES) void k_ungap(const u64* __restrict__
                         Qst = qpos + off;
                         Sst = sst + off;
                         cn = (qlo < Qst && slo < Sst) ? min(ql - Qst, sl - Sst) : 0;
-                        ci = 0, score = 0, max_score = 0, best = -1, stop = false;
+                        ci = 0, score = 0, mp = 255, best = -1, stop = false;
                         phase = PH_RIGHT;
                     }
                 }
@@ -301,12 +215,12 @@ __global__ __launch_bounds__(64 * UW_WAVES) void k_ungap(const u64* __restrict__
         if (phase == PH_RIGHT || phase == PH_LEFT) {
             if (ci < cn && !stop) {
                 const bool left = phase == PH_LEFT;
-                // right: bytes [Qst + ci, +8), element k in byte k;  left: bytes [Qst - 8 - ci, +8), element k in byte 7 - k
-                const i64 qa = (i64)qb + (left ? (i64)Qst - 8 - ci : (i64)Qst + ci);
-                const i64 sa = (i64)sb + (left ? (i64)Sst - 8 - ci : (i64)Sst + ci);
-                u64 qw = load8u(q_scls + (qa < 0 ? 0 : qa)), sw = load8u(r_scls + (sa < 0 ? 0 : sa));
-                if (qa < 0) qw <<= 8 * (int)(-qa);  // array start (left pass only): the missing low bytes are never active
-                if (sa < 0) sw <<= 8 * (int)(-sa);
+                // right: bytes [Qst + ci, +8), element k in byte k;  left: bytes [Qst - 8 - ci, +8), element k in byte 7 - k.
+                // A left window may start up to 8 bytes before its sequence (the arrays have 16 readable bytes in
+                // front): those elements lie past the pass limit and are never active.
+                const int qa = (int)qb + (left ? Qst - 8 - ci : Qst + ci);
+                const int sa = (int)sb + (left ? Sst - 8 - ci : Sst + ci);
+                u64 qw = load8u(q_scls + qa), sw = load8u(r_scls + sa);
                 const u64 qr = __builtin_bswap64(qw), sr = __builtin_bswap64(sw);
                 qw = left ? qr : qw;
                 sw = left ? sr : sw;
@@ -315,31 +229,34 @@ __global__ __launch_bounds__(64 * UW_WAVES) void k_ungap(const u64* __restrict__
                 int sc[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) sc[k] = s_b62[(((u32)(qw >> (8 * k)) & 31u) * B62_LD) + ((u32)(sw >> (8 * k)) & 31u)];
-                bool dropped = false;
+                // running maximum and its FIRST position in one packed word: (score << 8) | (255 - k).  A later equal
+                // score has a smaller low byte and loses; the incoming maximum carries 255 and wins every tie.
+                // drop:  ns + 30 < max  <=>  ((ns + 31) << 8) <= packed max.
+                const int mp_in = mp;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int ns = score + sc[k];
-                    const bool better = ns > max_score;
-                    const bool drop = ns + DROPX < max_score;  // (never together with `better`)
-                    best = better ? ci + k : best;
-                    max_score = max(max_score, ns);
-                    score = drop ? -(1 << 28) : ns;
-                    dropped = dropped || drop;
+                    const bool drop = ((ns << 8) + ((DROPX + 1) << 8)) <= mp;
+                    mp = max(mp, (ns << 8) + (255 - k));
+                    score = drop ? UG_PIN : ns;
                 }
-                stop = dropped;
+                if (mp != mp_in) best = ci + (255 - (mp & 255));
+                mp |= 255;
+                stop = score < (UG_PIN >> 1);
                 ci += 8;
             }
             if (phase == PH_RIGHT && (ci >= cn || stop)) {
                 r_qed = best >= 0 ? Qst + best : Qst;
                 r_sed = best >= 0 ? Sst + best : Sst;
                 // left pass from (Qst - 1, Sst - 1); the score continues from the maximum (2479-2492)
-                score = max_score;
+                score = mp >> 8;
                 stop = false, best = -1, ci = 0;
                 cn = (Qst - 1 < ql && Sst - 1 < sl) ? min(Qst - 1 - qlo, Sst - 1 - slo) : 0;
                 phase = PH_LEFT;
             }
             if (phase == PH_LEFT && (ci >= cn || stop)) {
                 const int l_qst = best >= 0 ? Qst - 1 - best : Qst - 1, l_sst = best >= 0 ? Sst - 1 - best : Sst - 1;
+                const int max_score = mp >> 8;
                 if (first) {  // get_ungap_scores (2497-2509)
                     scores = max_score, x0 = l_qst, y0 = l_sst;
                     first = false;
@@ -500,12 +417,6 @@ __global__ __launch_bounds__(256) void k_seg_counts(const u32* __restrict__ out_
 }
 
 // ---- launch wrappers -------------------------------------------------------------------------------
-void launch_group_flags(const u64* keys, u32 H, const KeyLayout& kl, u32* flags, u32* hvalid, hipStream_t st) {
-    HIP_CHECK(hipMemsetAsync(hvalid, 0, sizeof(u32), st));
-    if (!H) return;
-    hipLaunchKernelGGL(k_group_flags, dim3((H + 255) / 256), dim3(256), 0, st, keys, H, kl, flags, hvalid);
-}
-
 void launch_group_list(const u32* flags, const u32* gidx, u32 H, u32* ghead, hipStream_t st) {
     if (!H) return;
     hipLaunchKernelGGL(k_group_list, dim3((H + 255) / 256), dim3(256), 0, st, flags, gidx, H, ghead);

@@ -57,7 +57,6 @@ void launch_lookup(const u32* cs_hoff, const u32* cs_base, const u64* cs_kbase, 
                    u64* keys, hipStream_t st);
 
 // k_group.hip
-void launch_group_flags(const u64* keys, u32 H, const KeyLayout& kl, u32* flags, u32* hvalid, hipStream_t st);
 void launch_group_list(const u32* flags, const u32* gidx, u32 H, u32* ghead, hipStream_t st);
 u32 ungap_shard_cap(u32 H);
 void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, int ft_bits_entry, int bsp, const u8* q_scls, const u32* qoff,
