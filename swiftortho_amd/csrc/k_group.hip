@@ -39,14 +39,14 @@ __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global
 // p_ft = first-touch key.
 #define UW_WAVES 4
 #define UW_RANGE 4096   // head positions owned by one wave
-#define UW_QCAP 256     // group-head ring (u32 hit indices)
-#define UW_PCAP 192     // buffered pass records per wave
+#define UW_QCAP 128     // group-head ring (u32 hit indices)
+#define UW_PCAP 96     // buffered pass records per wave
 #define UW_WAIT 20      // run the bookkeeping part when this many lanes wait for it
 #define UG_PIN (-(1 << 22))  // running score after an X-drop: below anything reachable, (UG_PIN - 8 * 128) << 8 fits int32
 
 enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN = 5 };
 
-__global__ __launch_bounds__(64 * UW_WAVES) void k_ungap(const u64* __restrict__ keys, u32 H, KeyLayout kl, int ft_bits_entry, int bsp,
+__global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restrict__ keys, u32 H, KeyLayout kl, int ft_bits_entry, int bsp,
                                                          const u8* __restrict__ q_scls, const u32* __restrict__ qoff,
                                                          const u8* __restrict__ r_scls,
                                                          const u32* __restrict__ roff /*chunk-local offsets (absolute values)*/,
@@ -218,9 +218,8 @@ __global__ __launch_bounds__(64 * UW_WAVES) void k_ungap(const u64* __restrict__
                 // right: bytes [Qst + ci, +8), element k in byte k;  left: bytes [Qst - 8 - ci, +8), element k in byte 7 - k.
                 // A left window may start up to 8 bytes before its sequence (the arrays have 16 readable bytes in
                 // front): those elements lie past the pass limit and are never active.
-                const int qa = (int)qb + (left ? Qst - 8 - ci : Qst + ci);
-                const int sa = (int)sb + (left ? Sst - 8 - ci : Sst + ci);
-                u64 qw = load8u(q_scls + qa), sw = load8u(r_scls + sa);
+                u64 qw = load8u(q_scls + ((int)qb + (left ? Qst - 8 - ci : Qst + ci)));
+                u64 sw = load8u(r_scls + ((int)sb + (left ? Sst - 8 - ci : Sst + ci)));
                 const u64 qr = __builtin_bswap64(qw), sr = __builtin_bswap64(sw);
                 qw = left ? qr : qw;
                 sw = left ? sr : sw;
