@@ -49,25 +49,37 @@ __global__ __launch_bounds__(TILE_POS) void k_index_pass(const u32* __restrict__
 
 // sum c, sum c^2, #non-empty, largest non-empty bucket id over counts[0..NC)
 __global__ __launch_bounds__(256) void k_index_stats(const u32* __restrict__ counts, u32 NC, u64* __restrict__ stats /*[4]*/) {
-    u64 s1 = 0, s2 = 0, nn = 0;
+    u64 s1 = 0, s2 = 0;
+    u32 nn = 0;
     u32 mbp1 = 0;  // (largest non-empty bucket id) + 1, 0 = none
-    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < NC; i += (size_t)gridDim.x * 256 * 4) {
-        u32 c[4] = {0, 0, 0, 0};
-        if (i + 3 < NC) {
-            uint4 v = *reinterpret_cast<const uint4*>(counts + i);
-            c[0] = v.x, c[1] = v.y, c[2] = v.z, c[3] = v.w;
-        } else {
-            for (int k = 0; k < 4; ++k)
-                if (i + k < NC) c[k] = counts[i + k];
+    // branch-free, four independent 16-byte loads per thread and trip (the array is 4 x NC bytes, mostly zeros)
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < NC; i0 += 4 * stride) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = i0 + u * stride;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (i + 3 < NC) {
+                v[u] = *reinterpret_cast<const uint4*>(counts + i);
+            } else if (i < NC) {
+                v[u].x = counts[i];
+                if (i + 1 < NC) v[u].y = counts[i + 1];
+                if (i + 2 < NC) v[u].z = counts[i + 2];
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (c[k]) {
+        for (int u = 0; u < 4; ++u) {
+            const u32 i = (u32)(i0 + u * stride);
+            const u32 c[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
                 s1 += c[k];
                 s2 += (u64)c[k] * c[k];
-                nn += 1;
-                mbp1 = (u32)(i + k) + 1u;
+                nn += c[k] != 0;
+                mbp1 = max(mbp1, c[k] ? i + k + 1u : 0u);
             }
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         s1 += __shfl_down(s1, o);

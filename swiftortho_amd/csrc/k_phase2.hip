@@ -38,16 +38,19 @@ __device__ __forceinline__ u32 cand_tiles(u32 lq, u32 ls, u32 qi) {
     return qi < lq ? (lq - qi + LONG_SEQ - 1) / LONG_SEQ : 0u;
 }
 
+// CAP = LDS capacity of this instance; it serves the queries with LO < n <= CAP (a small instance keeps
+// 4x more waves resident for the typical few-hundred-candidate lists).
+template <int CAP, int LO>
 __global__ __launch_bounds__(64) void k_csort_lds(const u32* __restrict__ rec, const u32* __restrict__ qcoff, u32 nq, u32 vmax,
                                                   const u32* __restrict__ qoff, const u32* __restrict__ roff, u32* __restrict__ perm,
                                                   u32* __restrict__ ntask, u32* __restrict__ ntile) {
-    __shared__ u32 s_x[LDS_SORT_MAX];
-    __shared__ u16 s_L[LDS_SORT_MAX], s_R[LDS_SORT_MAX];
+    __shared__ u32 s_x[CAP];
+    __shared__ u16 s_L[CAP], s_R[CAP];
     __shared__ int s_leaf[2 * WQS_LEAF];
     const u32 q = blockIdx.x;
     const u32 c0 = qcoff[q];
     const int n = (int)(qcoff[q + 1] - c0);
-    if (n > LDS_SORT_MAX) return;  // k_csort handles it
+    if (n > CAP || (n <= LO && LO > 0)) return;  // another instance (or k_csort) handles it
     const u32* r = rec + 4 * (size_t)c0;
     for (int i = threadIdx.x; i < n; i += 64) {
         u32 sc = r[4 * (size_t)i + 1];
@@ -320,7 +323,9 @@ void launch_add_u32(u32* acc, const u32* x, u32 n, hipStream_t st) {
 void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, const u32* qoff, const u32* roff, u32* perm, u32* ntask,
                   u32* ntile, u64* gx, u32* gL, u32* gR, hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_csort_lds, dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile);
+    hipLaunchKernelGGL((k_csort_lds<1024, 0>), dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile);
+    hipLaunchKernelGGL((k_csort_lds<2048, 1024>), dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile);
+    hipLaunchKernelGGL((k_csort_lds<LDS_SORT_MAX, 2048>), dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile);
     if (gx) hipLaunchKernelGGL(k_csort, dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile, gx, gL, gR);
 }
 

@@ -60,11 +60,12 @@ __global__ __launch_bounds__(256) void k_bounds(const u32* __restrict__ qbucket,
 #define LDS_SORT_MAX 4096
 #define KSC_BIAS (1 << 18)
 
+template <int CAP, int LO>  // serves queries with LO < windows <= CAP
 __global__ __launch_bounds__(64) void k_ksc_order_lds(const u8* __restrict__ q_scls, const u32* __restrict__ qoff, u32 nq, int mink,
                                                       const signed char* __restrict__ b62c, u32* __restrict__ korder) {
     __shared__ signed char s_self[SCLS_N];
-    __shared__ u32 s_x[LDS_SORT_MAX];
-    __shared__ u16 s_L[LDS_SORT_MAX], s_R[LDS_SORT_MAX];
+    __shared__ u32 s_x[CAP];
+    __shared__ u16 s_L[CAP], s_R[CAP];
     __shared__ int s_leaf[2 * WQS_LEAF];
     if (threadIdx.x < SCLS_N) s_self[threadIdx.x] = b62c[threadIdx.x * SCLS_N + threadIdx.x];
     __syncthreads();
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(64) void k_ksc_order_lds(const u8* __restrict__ q_s
     const u32 base = qoff[q];
     const int ql = (int)(qoff[q + 1] - base);
     const int nk = ql - mink + 1;
-    if (nk <= 0 || nk > LDS_SORT_MAX) return;
+    if (nk <= LO || nk > CAP) return;
     const u8* c = q_scls + base;
     for (int i = threadIdx.x; i < nk; i += 64) {
         int sc = 0;
@@ -372,7 +373,8 @@ void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* start, u32 N
 void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, int mink, const signed char* b62c, int* ksc, u32* korder,
                       hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_ksc_order_lds, dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
+    hipLaunchKernelGGL((k_ksc_order_lds<1024, 0>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
+    hipLaunchKernelGGL((k_ksc_order_lds<LDS_SORT_MAX, 1024>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
     hipLaunchKernelGGL(k_ksc_order, dim3((nq + 63) / 64), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, ksc, korder);
 }
 
