@@ -35,7 +35,7 @@ __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global
 // One loop iteration = one 8-residue chunk for every lane that is inside a pass; the bookkeeping part
 // (group fetch, hit walk) runs only when enough lanes wait for it.  Passing groups (score >= 25) are
 // buffered in LDS and flushed to one of UG_SHARDS regions with ONE atomic per flush (wave-ballot
-// compaction inside the wave).   p_qs = (q << 32) | subject_local, p_sd = (score << 32) | (u32)dist,
+// compaction inside the wave).   p_qs = (q << bs) | subject_local, p_sd = (score << 32) | (u32)dist,
 // p_ft = first-touch key.
 #define UW_WAVES 4
 #define UW_RANGE 4096   // head positions owned by one wave
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                     const int d2 = (y0 - x0) + (y - x);
                     const int dist = (d2 >= 0) ? d2 / 2 : -((-d2 + 1) / 2);
                     const u32 i = npb + (u32)__popcll(pb & lt);
-                    s_pqs[i] = ((u64)gq << 32) | gsubj;
+                    s_pqs[i] = ((u64)gq << kl.bs) | gsubj;
                     s_psd[i] = ((u64)(u32)scores << 32) | (u64)(u32)dist;
                     s_pft[i] = ft;
                 }
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_seg_flags(const u64* __restrict__ sorte
 
 __global__ __launch_bounds__(256) void k_best(const u64* __restrict__ sorted_qs, const u32* __restrict__ idx, const u32* __restrict__ shead,
                                               u32 nseg, u32 n, const u64* __restrict__ p_sd, const u64* __restrict__ p_ft, u32 seq_lo,
-                                              u64* __restrict__ c_ft, u32* __restrict__ c_q, u32* __restrict__ c_rec /*4 per cand*/) {
+                                              int bs, u64* __restrict__ c_ft, u32* __restrict__ c_q, u32* __restrict__ c_rec /*4 per cand*/) {
     const u32 s = blockIdx.x * 256u + threadIdx.x;
     if (s >= nseg) return;
     const u32 i0 = shead[s], i1 = (s + 1 < nseg) ? shead[s + 1] : n;
@@ -364,11 +364,11 @@ __global__ __launch_bounds__(256) void k_best(const u64* __restrict__ sorted_qs,
     }
     const u64 qs = sorted_qs[i0];
     c_ft[s] = minft;
-    c_q[s] = (u32)(qs >> 32);
+    c_q[s] = (u32)(qs >> bs);
     u32 qi, qj;
     if (bdist > 0) qi = 0, qj = (u32)bdist;
     else qi = (u32)(-bdist), qj = 0;
-    c_rec[4 * s + 0] = (u32)qs + seq_lo;  // global subject id
+    c_rec[4 * s + 0] = ((u32)qs & ((1u << bs) - 1u)) + seq_lo;  // global subject id
     c_rec[4 * s + 1] = bscore;
     c_rec[4 * s + 2] = qi;
     c_rec[4 * s + 3] = qj;
@@ -451,9 +451,9 @@ void launch_seg_flags(const u64* sorted_qs, u32 n, u32* flags, hipStream_t st) {
 }
 
 void launch_best(const u64* sorted_qs, const u32* idx, const u32* shead, u32 nseg, u32 n, const u64* p_sd, const u64* p_ft,
-                 u32 seq_lo, u64* c_ft, u32* c_q, u32* c_rec, hipStream_t st) {
+                 u32 seq_lo, int bs, u64* c_ft, u32* c_q, u32* c_rec, hipStream_t st) {
     if (!nseg) return;
-    hipLaunchKernelGGL(k_best, dim3((nseg + 255) / 256), dim3(256), 0, st, sorted_qs, idx, shead, nseg, n, p_sd, p_ft, seq_lo, c_ft,
+    hipLaunchKernelGGL(k_best, dim3((nseg + 255) / 256), dim3(256), 0, st, sorted_qs, idx, shead, nseg, n, p_sd, p_ft, seq_lo, bs, c_ft,
                        c_q, c_rec);
 }
 

@@ -67,7 +67,7 @@ void launch_compact_shards(const u32* shard_cnt, u32* shard_off, u32 shard_cap, 
                            u64* b1, u64* b2, hipStream_t st);
 void launch_seg_flags(const u64* sorted_qs, u32 n, u32* flags, hipStream_t st);
 void launch_best(const u64* sorted_qs, const u32* idx, const u32* shead, u32 nseg, u32 n, const u64* p_sd, const u64* p_ft,
-                 u32 seq_lo, u64* c_ft, u32* c_q, u32* c_rec, hipStream_t st);
+                 u32 seq_lo, int bs, u64* c_ft, u32* c_q, u32* c_rec, hipStream_t st);
 void launch_gather_u32_as_u64(const u32* src, const u32* idx, u32 n, u64* dst, hipStream_t st);
 void launch_iota(u32* p, u32 n, hipStream_t st);
 void launch_combine_q_ft(const u32* c_q, const u64* c_ft, u32 n, int ftbits, u64* dst, hipStream_t st);
