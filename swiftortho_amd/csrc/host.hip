@@ -878,6 +878,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     }
     // append to the candidate store
     const u32 base = b.chunk_base.back();
+    if ((u64)base + NS >= 0xFFFFFFF0ull) throw SoError("a query batch collected >= 2^32 candidates: lower SOHIT_BATCH");
     b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
     b.cand_rec.ensure(4 * ((size_t)base + NS) + 16, true, c->st);
     b.segfirst.ensure((size_t)b.nq + 4);

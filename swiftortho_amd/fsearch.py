@@ -151,8 +151,9 @@ class Hits:
                                           ("ungapped", "<i4"))])
         if self.n == 0:
             return np.zeros(0, dtype=dt)
-        raw = C.string_at(self.ptr, self.n * C.sizeof(_lib.SoHit))
-        return np.frombuffer(raw, dtype=dt).copy()
+        nbytes = self.n * C.sizeof(_lib.SoHit)  # can exceed 2 GiB (1M x 1M: 24 GB): no string_at
+        view = (C.c_char * nbytes).from_address(C.addressof(self.ptr.contents))
+        return np.frombuffer(view, dtype=dt).copy()
 
     def write(self, path, mode="w"):
         self.s._chk(self.s.L.so_write_sc(self.s.h, self.ptr, self.n, os.fsencode(path), mode.encode()))
@@ -166,7 +167,10 @@ class Hits:
         return out
 
     def raw_bytes(self):
-        return C.string_at(self.ptr, self.n * C.sizeof(_lib.SoHit)) if self.n else b""
+        if not self.n:
+            return b""
+        nbytes = self.n * C.sizeof(_lib.SoHit)
+        return bytes((C.c_char * nbytes).from_address(C.addressof(self.ptr.contents)))
 
     def close(self):
         if self.ptr:
