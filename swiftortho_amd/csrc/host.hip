@@ -114,8 +114,9 @@ struct SeqSet {
     std::vector<u8> res;         // concatenated residues (raw bytes)
     u32 maxlen = 0;
     // device
-    DevBuf<u8> d_res, d_scls_store;
-    struct { u8* p = nullptr; } d_scls;  // score classes; 16 readable bytes in front (k_ungap's left-pass windows start up to 8 bytes early)
+    DevBuf<u8> d_res, d_scls_store, d_scls4_store;
+    struct { u8* p = nullptr; } d_scls;   // score classes; 16 readable bytes in front (k_ungap's left-pass windows start up to 8 bytes early)
+    struct { u8* p = nullptr; } d_scls4;  // score class * 4 (k_ungap's subject side: column offset in its LDS table), same padding
     DevBuf<u32> d_off, d_words, d_pseq;
     u32 P = 0, Ppad = 0;
     HashLut lut;
@@ -319,8 +320,10 @@ void layout_set(so_ctx* c, SeqSet& s, const bool present[256], size_t nres, u32 
     build_hash_classes(present, c->codes, hmap, s.lut);
     s.d_scls_store.ensure(nres + 64 + 16);
     s.d_scls.p = s.d_scls_store.p + 16;
+    s.d_scls4_store.ensure(nres + 64 + 16);
+    s.d_scls4.p = s.d_scls4_store.p + 16;
     HIP_CHECK(hipMemcpyAsync(c->d_hmap.p, hmap, 256, hipMemcpyHostToDevice, c->st));
-    launch_scls(s.d_res.p, nres, c->d_smap.p, s.d_scls.p, c->st);
+    launch_scls(s.d_res.p, nres, c->d_smap.p, s.d_scls.p, s.d_scls4.p, c->st);
     if ((u64)nres + nseq + 64 > 0xFFFFFFF0ull) throw SoError("sequence set too large for 32-bit packed positions");
     s.P = (u32)(nres + nseq);
     s.Ppad = (s.P + 31u) & ~31u;
@@ -826,7 +829,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     b.stepshard.ensure(UG_SHARDS);
     HIP_CHECK(hipMemsetAsync(b.shard.p, 0, (2 * UG_SHARDS + 8) * sizeof(u32), c->st));
     HIP_CHECK(hipMemsetAsync(b.stepshard.p, 0, UG_SHARDS * sizeof(unsigned long long), c->st));
-    launch_ungap(b.keys2.p, H, kl, ft_bits_entry, bsp, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_off.p + ch.seq_lo,
+    launch_ungap(b.keys2.p, H, kl, ft_bits_entry, bsp, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo,
                  c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
     {
         unsigned long long gc[UG_SHARDS];

@@ -17,7 +17,6 @@ __global__ __launch_bounds__(256) void k_group_list(const u32* __restrict__ flag
 }
 
 // ---- chained ungapped extension -----------------------------------------------------------------
-#define B62_LD 36  // LDS score table: 32 rows of 36 bytes (9 dwords: rows rotate through all 32 banks); any 5-bit class pair indexes inside it
 
 __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global load
     u64 w;
@@ -40,9 +39,9 @@ __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global
 #define UW_WAVES 4
 #define UW_RANGE 4096   // head positions owned by one wave
 #define UW_QCAP 128     // group-head ring (u32 hit indices)
-#define UW_PCAP 96     // buffered pass records per wave
+#define UW_PCAP 64     // buffered pass records per wave
 #define UW_WAIT 20      // run the bookkeeping part when this many lanes wait for it
-#define UG_PIN (-(1 << 22))  // running score after an X-drop: below anything reachable, (UG_PIN - 8 * 128) << 8 fits int32
+#define UG_PIN8 (-(1 << 30))  // running (x 256) score after an X-drop: below anything reachable, 8 more sentinel steps (-128 << 8 each) still fit int32
 
 enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN = 5 };
 
@@ -53,12 +52,15 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                                                          const signed char* __restrict__ b62g, u32* __restrict__ shard_cnt /*[UG_SHARDS]*/,
                                                          u32 shard_cap, u64* __restrict__ p_qs, u64* __restrict__ p_sd,
                                                          u64* __restrict__ p_ft, unsigned long long* __restrict__ group_count) {
-    __shared__ signed char s_b62[32 * B62_LD];
+    // score table addressed by ONE v_perm per element: (query class << 8) | (subject class * 4).  Row stride 256 B; the
+    // * 4 spreads the 24 subject classes over 24 LDS banks (a row stride of 64 dwords keeps the bank = column / 4).
+    __shared__ signed char s_b62[32 * 256];
     __shared__ u32 s_queue_all[UW_WAVES][UW_QCAP];   // head position | (1 << 31) when the group is a singleton
     __shared__ u64 s_qkey_all[UW_WAVES][UW_QCAP];    // the head's (masked) key
     __shared__ u64 s_pb_all[UW_WAVES][3][UW_PCAP];
-    for (int i = threadIdx.x; i < 32 * B62_LD; i += 64 * UW_WAVES) {
-        const int a = i / B62_LD, b = i % B62_LD;
+    for (int i = threadIdx.x; i < 32 * 256; i += 64 * UW_WAVES) {
+        const int a = i >> 8, b = (i & 255) >> 2;  // b: subject class of column i & 255 (columns between the * 4 slots are never read
+                                                   // by in-sequence bytes; stray pad bytes only meet query class 31)
         // class 31 never occurs in data: it marks elements past a pass limit and scores -128
         s_b62[i] = (a < SCLS_N && b < SCLS_N) ? b62g[a * SCLS_N + b] : ((a == 31 || b == 31) ? (signed char)-128 : (signed char)-4);
     }
@@ -98,7 +100,8 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
     u64 ft = ~0ull, hkey = 0;
     u32 cq = 0xFFFFFFFFu, cqb = 0;  // last query looked up (groups arrive sorted by query)
     int cql = 0;
-    int Qst = 0, Sst = 0, qlo = 0, slo = 0, ci = 0, cn = 0, score = 0, mp = 255 /*packed running maximum*/, best = -1, r_qed = 0, r_sed = 0;
+    int Qst = 0, Sst = 0, qlo = 0, slo = 0, ci = 0, cn = 0, score8 = 0 /*running score x 256*/, mp = 255 /*packed running maximum*/, best = -1, r_qed = 0, r_sed = 0;
+    int qcur = 0, scur = 0;  // byte offsets of the next chunk in the two class arrays
     bool stop = false;
 
     for (;;) {
@@ -200,7 +203,8 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                         Qst = qpos + off;
                         Sst = sst + off;
                         cn = (qlo < Qst && slo < Sst) ? min(ql - Qst, sl - Sst) : 0;
-                        ci = 0, score = 0, mp = 255, best = -1, stop = false;
+                        ci = 0, score8 = 0, mp = 255, best = -1, stop = false;
+                        qcur = (int)qb + Qst, scur = (int)sb + Sst;
                         phase = PH_RIGHT;
                     }
                 }
@@ -215,41 +219,49 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
         if (phase == PH_RIGHT || phase == PH_LEFT) {
             if (ci < cn && !stop) {
                 const bool left = phase == PH_LEFT;
-                // right: bytes [Qst + ci, +8), element k in byte k;  left: bytes [Qst - 8 - ci, +8), element k in byte 7 - k.
-                // A left window may start up to 8 bytes before its sequence (the arrays have 16 readable bytes in
-                // front): those elements lie past the pass limit and are never active.
-                u64 qw = load8u(q_scls + ((int)qb + (left ? Qst - 8 - ci : Qst + ci)));
-                u64 sw = load8u(r_scls + ((int)sb + (left ? Sst - 8 - ci : Sst + ci)));
+                // right: bytes [Qst + ci, +8), element k in byte k;  left: bytes [Qst - 8 - ci, +8), element k in byte 7 - k
+                // (qcur / scur walk by +-8 per chunk).  A left window may start up to 8 bytes before its sequence (the arrays
+                // have 16 readable bytes in front): those elements lie past the pass limit and are never active.
+                u64 qw = load8u(q_scls + qcur), sw = load8u(r_scls + scur);
+                qcur += left ? -8 : 8;
+                scur += left ? -8 : 8;
                 const u64 qr = __builtin_bswap64(qw), sr = __builtin_bswap64(sw);
                 qw = left ? qr : qw;
                 sw = left ? sr : sw;
                 const int m = cn - ci;
-                if (m < 8) qw |= 0x1F1F1F1F1F1F1F1Full << (8 * m);  // elements >= m: class 31
+                if (m < 8) qw = (qw & ~(~0ull << (8 * m))) | (0x1F1F1F1F1F1F1F1Full << (8 * m));  // elements >= m: exactly class 31 (row 31 = -128)
                 int sc[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) sc[k] = s_b62[(((u32)(qw >> (8 * k)) & 31u) * B62_LD) + ((u32)(sw >> (8 * k)) & 31u)];
-                // running maximum and its FIRST position in one packed word: (score << 8) | (255 - k).  A later equal
-                // score has a smaller low byte and loses; the incoming maximum carries 255 and wins every tie.
-                // drop:  ns + 30 < max  <=>  ((ns + 31) << 8) <= packed max.
+                for (int k = 0; k < 8; ++k) {
+                    const u32 qh = (u32)(k < 4 ? qw : qw >> 32), sh = (u32)(k < 4 ? sw : sw >> 32);
+                    // byte0 = subject byte k, byte1 = query byte k, bytes 2-3 = 0   (selector 0x0c = constant 0x00)
+                    sc[k] = s_b62[__builtin_amdgcn_perm(qh, sh, 0x0c0c0400u + (u32)(k & 3) * 0x0101u)];
+                }
+                // Scores are carried scaled by 256 (`score8`), so that the running maximum and its FIRST position share one
+                // word: mp = (max << 8) | (255 - k).  A later equal score has a smaller low byte and loses; the incoming
+                // maximum carries 255 and wins every tie.  With d = mp - P = ((max - ns) << 8) + (low-byte difference in
+                // [-7, 7]) the X-drop test  ns + 30 < max  is  d >= (31 << 8) - 7.  Six VALU per element.
                 const int mp_in = mp;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int ns = score + sc[k];
-                    const bool drop = ((ns << 8) + ((DROPX + 1) << 8)) <= mp;
-                    mp = max(mp, (ns << 8) + (255 - k));
-                    score = drop ? UG_PIN : ns;
+                    const int ns8 = (sc[k] << 8) + score8;
+                    const int P = ns8 | (255 - k);
+                    const bool drop = mp - P >= ((DROPX + 1) << 8) - 7;
+                    mp = max(mp, P);
+                    score8 = drop ? UG_PIN8 : ns8;
                 }
                 if (mp != mp_in) best = ci + (255 - (mp & 255));
                 mp |= 255;
-                stop = score < (UG_PIN >> 1);
+                stop = score8 < (UG_PIN8 >> 1);
                 ci += 8;
             }
             if (phase == PH_RIGHT && (ci >= cn || stop)) {
                 r_qed = best >= 0 ? Qst + best : Qst;
                 r_sed = best >= 0 ? Sst + best : Sst;
                 // left pass from (Qst - 1, Sst - 1); the score continues from the maximum (2479-2492)
-                score = mp >> 8;
+                score8 = mp & ~255;
                 stop = false, best = -1, ci = 0;
+                qcur = (int)qb + Qst - 8, scur = (int)sb + Sst - 8;
                 cn = (Qst - 1 < ql && Sst - 1 < sl) ? min(Qst - 1 - qlo, Sst - 1 - slo) : 0;
                 phase = PH_LEFT;
             }

@@ -56,8 +56,9 @@ __global__ __launch_bounds__(256) void k_pack5(const u8* __restrict__ pcls, u32 
     for (int k = 0; k < 5; ++k) words[(size_t)g * 5 + k] = out[k];
 }
 
-// raw byte -> BLOSUM62 score class
-__global__ __launch_bounds__(256) void k_scls(const u8* __restrict__ res, size_t n, const u8* __restrict__ smap, u8* __restrict__ scls) {
+// raw byte -> BLOSUM62 score class; scls4 (optional) = class * 4, the column index of k_ungap's LDS score table
+__global__ __launch_bounds__(256) void k_scls(const u8* __restrict__ res, size_t n, const u8* __restrict__ smap, u8* __restrict__ scls,
+                                              u8* __restrict__ scls4) {
     __shared__ u8 s_map[256];
     s_map[threadIdx.x] = smap[threadIdx.x];
     __syncthreads();
@@ -66,9 +67,13 @@ __global__ __launch_bounds__(256) void k_scls(const u8* __restrict__ res, size_t
         uchar4 v = *reinterpret_cast<const uchar4*>(res + i);
         uchar4 o = make_uchar4(s_map[v.x], s_map[v.y], s_map[v.z], s_map[v.w]);
         *reinterpret_cast<uchar4*>(scls + i) = o;
+        if (scls4) *reinterpret_cast<uchar4*>(scls4 + i) = make_uchar4(o.x << 2, o.y << 2, o.z << 2, o.w << 2);
     } else {
         for (int k = 0; k < 4; ++k)
-            if (i + k < n) scls[i + k] = s_map[res[i + k]];
+            if (i + k < n) {
+                scls[i + k] = s_map[res[i + k]];
+                if (scls4) scls4[i + k] = (u8)(s_map[res[i + k]] << 2);
+            }
     }
 }
 
@@ -195,8 +200,8 @@ void launch_layout(const u8* res, const u32* off, u32 nseq, u32 P, u32 Ppad, con
     hipLaunchKernelGGL(k_pack5, dim3((groups + 255) / 256), dim3(256), 0, st, pcls, Ppad, words);
 }
 
-void launch_scls(const u8* res, size_t n, const u8* smap, u8* scls, hipStream_t st) {
+void launch_scls(const u8* res, size_t n, const u8* smap, u8* scls, u8* scls4, hipStream_t st) {
     if (n == 0) return;
     size_t thr = (n + 3) / 4;
-    hipLaunchKernelGGL(k_scls, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, st, res, n, smap, scls);
+    hipLaunchKernelGGL(k_scls, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, st, res, n, smap, scls, scls4);
 }
