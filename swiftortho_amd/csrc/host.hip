@@ -309,7 +309,7 @@ void upload_constants(so_ctx* c) {
     for (int s = 0; s < so_ctx::BITTAB_N; ++s) bt[s] = (int)((.267 * (double)s + 3.1941832122778293) / 0.69314718055994529);
     c->d_bittab.ensure(so_ctx::BITTAB_N);
     HIP_CHECK(hipMemcpy(c->d_bittab.p, bt.data(), bt.size() * sizeof(int), hipMemcpyHostToDevice));
-    c->d_stats.ensure(8);
+    c->d_stats.ensure(4 + 4 * INDEX_STATS_BLOCKS + 8);
 }
 
 // device-resident arrays of a sequence set given its (possibly masked) residues

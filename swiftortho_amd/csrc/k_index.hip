@@ -48,7 +48,7 @@ __global__ __launch_bounds__(TILE_POS) void k_index_pass(const u32* __restrict__
 }
 
 // sum c, sum c^2, #non-empty, largest non-empty bucket id over counts[0..NC)
-__global__ __launch_bounds__(256) void k_index_stats(const u32* __restrict__ counts, u32 NC, u64* __restrict__ stats /*[4]*/) {
+__global__ __launch_bounds__(256) void k_index_stats(const u32* __restrict__ counts, u32 NC, u64* __restrict__ stats /*[gridDim.x][4] partials*/) {
     u64 s1 = 0, s2 = 0;
     u32 nn = 0;
     u32 mbp1 = 0;  // (largest non-empty bucket id) + 1, 0 = none
@@ -88,12 +88,40 @@ __global__ __launch_bounds__(256) void k_index_stats(const u32* __restrict__ cou
         u32 om = __shfl_down(mbp1, o);
         mbp1 = om > mbp1 ? om : mbp1;
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd((unsigned long long*)&stats[0], (unsigned long long)s1);
-        atomicAdd((unsigned long long*)&stats[1], (unsigned long long)s2);
-        atomicAdd((unsigned long long*)&stats[2], (unsigned long long)nn);
-        atomicMax((unsigned long long*)&stats[3], (unsigned long long)mbp1);
+    // per-block partials, no atomics: same-address atomics serialise at ~90 per microsecond chip-wide,
+    // which made 8 k wave-level atomics cost more than the 480 MB sweep itself
+    __shared__ u64 s_part[4][4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) s_part[w][0] = s1, s_part[w][1] = s2, s_part[w][2] = nn, s_part[w][3] = mbp1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 a = 0, b = 0, c = 0, d = 0;
+        for (int k = 0; k < 4; ++k) a += s_part[k][0], b += s_part[k][1], c += s_part[k][2], d = s_part[k][3] > d ? s_part[k][3] : d;
+        u64* o = stats + 4 * (size_t)blockIdx.x;
+        o[0] = a, o[1] = b, o[2] = c, o[3] = d;
     }
+}
+
+// second stage: reduce the per-block partials (nb x 4) into stats[0..4)
+__global__ __launch_bounds__(256) void k_index_stats_final(const u64* __restrict__ part, u32 nb, u64* __restrict__ stats) {
+    __shared__ u64 s_red[256][4];
+    u64 a = 0, b = 0, c = 0, d = 0;
+    for (u32 i = threadIdx.x; i < nb; i += 256) {
+        a += part[4 * (size_t)i], b += part[4 * (size_t)i + 1], c += part[4 * (size_t)i + 2];
+        d = part[4 * (size_t)i + 3] > d ? part[4 * (size_t)i + 3] : d;
+    }
+    s_red[threadIdx.x][0] = a, s_red[threadIdx.x][1] = b, s_red[threadIdx.x][2] = c, s_red[threadIdx.x][3] = d;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            s_red[threadIdx.x][0] += s_red[threadIdx.x + o][0];
+            s_red[threadIdx.x][1] += s_red[threadIdx.x + o][1];
+            s_red[threadIdx.x][2] += s_red[threadIdx.x + o][2];
+            if (s_red[threadIdx.x + o][3] > s_red[threadIdx.x][3]) s_red[threadIdx.x][3] = s_red[threadIdx.x + o][3];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) stats[threadIdx.x] = s_red[0][threadIdx.x];
 }
 
 // Keep the reference's "slot len(locus)-1 is never read": that slot belongs to the last non-empty
@@ -193,10 +221,11 @@ void launch_index_fill(const u32* words, const u32* pseq, const u32* off, u32 p_
                        step, start, entries);
 }
 
-void launch_index_stats(const u32* counts, u32 NC, u64* stats4, hipStream_t st) {
-    HIP_CHECK(hipMemsetAsync(stats4, 0, 4 * sizeof(u64), st));
-    u32 nb = (u32)std::min<size_t>(2048, ((size_t)NC / 4 + 255) / 256 + 1);
-    hipLaunchKernelGGL(k_index_stats, dim3(nb), dim3(256), 0, st, counts, NC, stats4);
+// stats_buf: 4 results followed by INDEX_STATS_BLOCKS x 4 per-block partials
+void launch_index_stats(const u32* counts, u32 NC, u64* stats_buf, hipStream_t st) {
+    u32 nb = (u32)std::min<size_t>(INDEX_STATS_BLOCKS, ((size_t)NC / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_index_stats, dim3(nb), dim3(256), 0, st, counts, NC, stats_buf + 4);
+    hipLaunchKernelGGL(k_index_stats_final, dim3(1), dim3(256), 0, st, stats_buf + 4, nb, stats_buf);
 }
 
 void launch_index_fixlast(const u32* start, u64* entries, u32 bstar, u32 E, hipStream_t st) {

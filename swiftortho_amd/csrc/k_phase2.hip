@@ -371,5 +371,5 @@ void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, 
 
 void launch_sum_cells(const AlnRes* res, u32 n, unsigned long long* total, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_sum_cells, dim3(std::min<u32>(1024u, (n + 255) / 256)), dim3(256), 0, st, res, n, total);
+    hipLaunchKernelGGL(k_sum_cells, dim3(std::min<u32>(128u, (n + 255) / 256)), dim3(256), 0, st, res, n, total);
 }

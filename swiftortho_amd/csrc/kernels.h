@@ -33,7 +33,8 @@ void launch_index_count(const u32* words, const u32* pseq, const u32* off, u32 p
                         const SeedCfg& cfg, const HashLut& lut, u32 step, u32* start, hipStream_t st);
 void launch_index_fill(const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
                        const SeedCfg& cfg, const HashLut& lut, u32 step, u32* start, u64* entries, hipStream_t st);
-void launch_index_stats(const u32* counts, u32 NC, u64* stats4, hipStream_t st);
+#define INDEX_STATS_BLOCKS 2048
+void launch_index_stats(const u32* counts, u32 NC, u64* stats_buf /*4 + 4 * INDEX_STATS_BLOCKS*/, hipStream_t st);
 void launch_encode_delta32(const u64* entries, u32 E, int ba, int bd, u32 maxslen, u32* dk32, hipStream_t st);
 void launch_encode_delta(const u64* entries, u32 E, int sh_subj, int sh_diag, u32 maxslen, u64* dkeys, hipStream_t st);
 void launch_index_fixlast(const u32* start, u64* entries, u32 bstar, u32 E, hipStream_t st);
