@@ -84,7 +84,8 @@ __device__ inline void ref_qsort_dev(T* x, int n, KeyFn key, int limit = 0x7ffff
 // element equal to the pivot: a self-swap, one more scan step).  Ranks come from ballots.
 // Block = exactly one wave (64 threads); x, Lpos, Rpos (n u16 each) and leaf (2 * WQS_LEAF ints) in LDS.
 // ---------------------------------------------------------------------------------------------
-#define WQS_PAR 64
+#define WQS_PAR 32   // ranges below this go to the per-lane sequential leaves (>= 8: the gap == 7 pivot rule lives there);
+                     // config 2 candidate sort: 64 -> 1.27 ms, 32 -> 1.04, 24 -> 1.05, 10 -> 1.40
 #define WQS_LEAF 512
 
 // T = element type (u32 words in LDS, or u64 words in global memory for segments that do not fit),
