@@ -235,6 +235,7 @@ struct so_ctx {
     // scratch
     DevBuf<u32> d_scan_tmp, d_tmp32a, d_tmp32b;
     DevBuf<u64> d_stats;
+    DevBuf<u32> d_small;  // parked scan totals (stash_u32)
     DevBuf<u8> d_pcls;
     DevBuf<u8> d_sort_tmp;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -246,6 +247,7 @@ struct so_ctx {
     bool q_present[256];               // bytes that can occur in (masked) query residues
     void* pinned = nullptr;            // pinned host staging for result rows
     size_t pinned_cap = 0;
+    unsigned long long* h_small = nullptr;  // pinned scratch for the small device -> host reads (counts, totals): 1 KB
     std::map<std::string, double> tm;  // per-stage wall ms (only with params.profile)
     std::shared_ptr<void> batch;       // persistent per-batch scratch (struct Batch)
 };
@@ -653,11 +655,31 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
     c->cnt.seed_windows += (i64)AS * (i64)nres;
 }
 
+// pinned destination: a pageable 4-byte read costs ~30 us per sync through the staging path, a pinned one ~10
+void* small_host(so_ctx* c) {
+    if (!c->h_small) HIP_CHECK(hipHostMalloc((void**)&c->h_small, 1024, hipHostMallocDefault));
+    return c->h_small;
+}
+
 u32 d2h_u32(so_ctx* c, const u32* p) {
-    u32 v;
-    HIP_CHECK(hipMemcpyAsync(&v, p, sizeof v, hipMemcpyDeviceToHost, c->st));
+    u32* v = (u32*)small_host(c);
+    HIP_CHECK(hipMemcpyAsync(v, p, sizeof(u32), hipMemcpyDeviceToHost, c->st));
     HIP_CHECK(hipStreamSynchronize(c->st));
-    return v;
+    return *v;
+}
+
+// Totals of two scans that share d_scan_tmp, fetched with ONE synchronisation: the first total is parked in a
+// device word while the second scan runs.
+void stash_u32(so_ctx* c, const u32* p, int slot) {
+    c->d_small.ensure(16);
+    HIP_CHECK(hipMemcpyAsync(c->d_small.p + slot, p, sizeof(u32), hipMemcpyDeviceToDevice, c->st));
+}
+void d2h_pair(so_ctx* c, const u32* second, u32& a, u32& b) {
+    stash_u32(c, second, 1);
+    u32* v = (u32*)small_host(c);
+    HIP_CHECK(hipMemcpyAsync(v, c->d_small.p, 2 * sizeof(u32), hipMemcpyDeviceToHost, c->st));
+    HIP_CHECK(hipStreamSynchronize(c->st));
+    a = v[0], b = v[1];
 }
 
 void ensure_sort_tmp(so_ctx* c, size_t bytes) { c->d_sort_tmp.ensure(bytes + 256); }
@@ -751,9 +773,10 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     u32* qcnt = b.ccnt.p + (size_t)ci * b.nq;
     launch_effcnt(b.mark.p, b.scnt.p, Ppad, AS, p_lo, p_hi, b.eff.p, b.nz.p, c->st);
     const u32* dH = scan_u32(b.eff.p, b.hoff.p, T, false, c->d_scan_tmp.p, c->st);
-    const u32 H = d2h_u32(c, dH);  // the scan's total lives in d_scan_tmp: fetch before the next scan
+    stash_u32(c, dH, 0);  // the scan's total lives in d_scan_tmp: park it before the next scan
     const u32* dK = scan_u32(b.nz.p, b.cidx.p, T, false, c->d_scan_tmp.p, c->st);
-    const u32 K = d2h_u32(c, dK);
+    u32 H, K;
+    d2h_pair(c, dK, H, K);
     sc.lap("seed.bounds_cap_scan");
     c->cnt.seed_hits += H;
     if (H == 0 || K == 0) {
@@ -831,16 +854,20 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     HIP_CHECK(hipMemsetAsync(b.stepshard.p, 0, UG_SHARDS * sizeof(unsigned long long), c->st));
     launch_ungap(b.keys2.p, H, kl, ft_bits_entry, bsp, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo,
                  c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
-    {
-        unsigned long long gc[UG_SHARDS];
-        HIP_CHECK(hipMemcpyAsync(gc, b.stepshard.p, sizeof gc, hipMemcpyDeviceToHost, c->st));
-        HIP_CHECK(hipStreamSynchronize(c->st));
-        for (int k = 0; k < UG_SHARDS; ++k) c->cnt.groups += (i64)gc[k];
-    }
-    // contiguous pass list
+    // contiguous pass list; the group counters and the pass total come back in one synchronisation
     u32* shard_off = b.shard.p + UG_SHARDS;
     launch_shard_scan(b.shard.p, shard_off, c->st);
-    const u32 NP = d2h_u32(c, shard_off + UG_SHARDS);
+    u32 NP;
+    {
+        static_assert(UG_SHARDS * sizeof(unsigned long long) + sizeof(u32) <= 1024, "h_small too small");
+        unsigned long long* gc = (unsigned long long*)small_host(c);
+        u32* np = (u32*)(gc + UG_SHARDS);
+        HIP_CHECK(hipMemcpyAsync(gc, b.stepshard.p, UG_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
+        HIP_CHECK(hipMemcpyAsync(np, shard_off + UG_SHARDS, sizeof(u32), hipMemcpyDeviceToHost, c->st));
+        HIP_CHECK(hipStreamSynchronize(c->st));
+        for (int k = 0; k < UG_SHARDS; ++k) c->cnt.groups += (i64)gc[k];
+        NP = *np;
+    }
     sc.lap("group.ungap");
     if (NP) {
         b.q_qs.ensure((size_t)NP + 2), b.q_sd.ensure((size_t)NP + 2), b.q_ft.ensure((size_t)NP + 2);
@@ -982,9 +1009,10 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         launch_csort(b.fin_rec.p, b.qcoff.p, nq, vmax, b.dev.d_off.p, c->ref.d_off.p, b.perm.p, b.ntask.p, b.ntile.p, gx, gL, gR, c->st);
     }
     const u32* dNRk = scan_u32(b.ntask.p, b.roffc.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
-    const u32 NRK = d2h_u32(c, dNRk);
+    stash_u32(c, dNRk, 0);
     const u32* dNT = scan_u32(b.ntile.p, b.toff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
-    const u32 NT = d2h_u32(c, dNT);
+    u32 NRK, NT;
+    d2h_pair(c, dNT, NRK, NT);
     sc.lap("phase2.csort");
     b.tasks.ensure((size_t)NT + 4), b.ares.ensure((size_t)NT + 4), b.bits.ensure((size_t)NT + 4), b.sel.ensure((size_t)NT + 4);
     b.rk_slot.ensure((size_t)NRK + 4);
@@ -1007,10 +1035,11 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         launch_round_counts(b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.qcoff.p, b.st_state.p, nq, c->max_miss, minr, b.rcnt.p,
                             b.tcnt.p, c->st);
         const u32* dNR = scan_u32(b.tcnt.p, b.roff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
-        const u32 NR = d2h_u32(c, dNR);
+        stash_u32(c, dNR, 0);
         // ranks left this round (a round may hold ranks with zero tiles only)
         const u32* dRR = scan_u32(b.rcnt.p, b.order_tmp.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
-        const u32 RR = d2h_u32(c, dRR);
+        u32 NR, RR;
+        d2h_pair(c, dRR, NR, RR);
         if (RR == 0) break;
         if (NR) {
             launch_round_idx(b.tcnt.p, b.roff.p, b.toff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.st_state.p, nq, b.ridx.p, c->st);
@@ -1292,6 +1321,7 @@ void so_destroy(so_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->st) (void)hipStreamSynchronize(c->st);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->st) (void)hipStreamDestroy(c->st);
