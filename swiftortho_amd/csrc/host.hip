@@ -226,6 +226,7 @@ struct so_ctx {
     bool ref_loaded = false, qry_loaded = false, index_built = false;
     i64 r_lo = -1, r_hi = -1;
     std::vector<std::unique_ptr<ChunkIndex>> chunks;
+    std::vector<std::unique_ptr<ChunkIndex>> spare_chunks;  // dropped chunk objects: their device buffers are reused by the next build
     // masked query cache of the last batch / search (for so_masked_query)
     std::vector<std::string> masked;     // indexed by qidx - masked_lo
     i64 masked_lo = 0;
@@ -526,7 +527,14 @@ void build_index(so_ctx* c) {
     c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)NC + 1) + 8);
     c->cnt.index_entries = 0;
     for (i64 s = Start; s < End; s += c->chunk) {
-        auto ch = std::make_unique<ChunkIndex>();
+        std::unique_ptr<ChunkIndex> ch;
+        if (!c->spare_chunks.empty()) {
+            ch = std::move(c->spare_chunks.back());
+            c->spare_chunks.pop_back();
+            ch->d_sh_subj = ch->d_sh_diag = ch->d_ba = ch->d_bd = -1;  // key addends belong to the old entries
+        } else {
+            ch = std::make_unique<ChunkIndex>();
+        }
         i64 e = std::min(s + c->chunk, End);
         ch->seq_lo = std::min<i64>(std::max<i64>(0, s), N);  // build_msav clamps, 2233-2234
         ch->seq_hi = std::min<i64>(e, N);
@@ -558,6 +566,7 @@ void build_index(so_ctx* c) {
         c->cnt.index_entries += ch->E;
         c->chunks.push_back(std::move(ch));
     }
+    c->spare_chunks.clear();
     c->cnt.n_chunks = (i64)c->chunks.size();
     c->index_built = true;
     c->cnt.index_ms += (wall() - t0) * 1e3;
@@ -1350,6 +1359,7 @@ int so_build_index(so_ctx* c) {
 
 int so_drop_index(so_ctx* c) {
     return guarded(c, [&] {
+        for (auto& ch : c->chunks) c->spare_chunks.push_back(std::move(ch));  // keep the allocations (480 MB `start` per chunk)
         c->chunks.clear();
         c->index_built = false;
     });
