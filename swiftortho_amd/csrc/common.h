@@ -69,7 +69,8 @@ struct DevBuf {
 #define MAX_SEEDLEN 32   // longest spaced-seed pattern
 #define MIN_UNGAP 25     // self.min, fsearch.py:2224
 #define DROPX 30
-#define UG_SHARDS 64   // pass-list shards of k_ungap (power of two)
+#define UG_SHARDS 1    // pass-list regions of k_ungap (power of two).  One region: a wave appends ~64 records per atomic, a few
+                       // hundred thousand appends per launch -- far below the same-address atomic rate -- and the list needs no compaction
 
 struct SeedCfg {
     int S, A;                       // #patterns, #alphabets

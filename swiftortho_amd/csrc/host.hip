@@ -878,9 +878,11 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         NP = *np;
     }
     sc.lap("group.ungap");
-    if (NP) {
+    const u64 *q_qs = b.p_qs.p, *q_sd = b.p_sd.p, *q_ft = b.p_ft.p;  // one region: already contiguous
+    if (NP && UG_SHARDS > 1) {
         b.q_qs.ensure((size_t)NP + 2), b.q_sd.ensure((size_t)NP + 2), b.q_ft.ensure((size_t)NP + 2);
         launch_compact_shards(b.shard.p, shard_off, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.q_qs.p, b.q_sd.p, b.q_ft.p, c->st);
+        q_qs = b.q_qs.p, q_sd = b.q_sd.p, q_ft = b.q_ft.p;
     }
     if (NP == 0) {
         c->cnt.seed_ms += (t1 - t0) * 1e3;
@@ -891,7 +893,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     b.pidx.ensure((size_t)NP + 2), b.pidx2.ensure((size_t)NP + 2), b.p_qs2.ensure((size_t)NP + 2);
     launch_iota(b.pidx.p, NP, c->st);
     ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(NP, 64));
-    sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.q_qs.p, b.p_qs2.p, b.pidx.p, b.pidx2.p, NP, kl.bs + kl.bq, c->st);
+    sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, q_qs, b.p_qs2.p, b.pidx.p, b.pidx2.p, NP, kl.bs + kl.bq, c->st);
     b.flags.ensure((size_t)NP + 4), b.gidx.ensure((size_t)NP + 4);
     launch_seg_flags(b.p_qs2.p, NP, b.flags.p, c->st);
     const u32* dS = scan_u32(b.flags.p, b.gidx.p, NP, false, c->d_scan_tmp.p, c->st);
@@ -899,7 +901,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     b.shead.ensure((size_t)NS + 2);
     launch_group_list(b.flags.p, b.gidx.p, NP, b.shead.p, c->st);
     b.c_ft.ensure((size_t)NS + 2), b.c_ft2.ensure((size_t)NS + 2), b.c_q.ensure((size_t)NS + 2), b.c_rec.ensure(4 * (size_t)NS + 8);
-    launch_best(b.p_qs2.p, b.pidx2.p, b.shead.p, NS, NP, b.q_sd.p, b.q_ft.p, (u32)ch.seq_lo, kl.bs, b.c_ft.p, b.c_q.p, b.c_rec.p, c->st);
+    launch_best(b.p_qs2.p, b.pidx2.p, b.shead.p, NS, NP, q_sd, q_ft, (u32)ch.seq_lo, kl.bs, b.c_ft.p, b.c_q.p, b.c_rec.p, c->st);
     // order candidates by (query, first-touch): one sort on (q << ftbits | ft) when that fits 64 bits,
     // else sort by first-touch and then stable-sort by query; only the populated bits are sorted
     const int ftbits = kl.ba + kl.bp + ft_bits_entry;
