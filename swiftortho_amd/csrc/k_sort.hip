@@ -46,15 +46,43 @@ void launch_query_segments(const u32* hoff, size_t T, const u32* qoff, u32 nq, i
     hipLaunchKernelGGL(k_query_segments, dim3((nq + 1 + 255) / 256), dim3(256), 0, st, hoff, T, qoff, nq, AS, H, seg);
 }
 
+// rocPRIM ships no tuned segmented-sort configuration for gfx950 and falls back to its generic one (6-bit digits,
+// 128 x 17 keys per block: four passes over our 24 bits).  Measured on config 2 (247 M keys, 10 k segments;
+// tools/diag/sort_sweep.sh): generic 5.09 ms; 8-bit digits with 256 x 8 keys 4.16, 256 x 16 keys 3.97-4.06 (default
+// here), 256 x 32 6.0, 512 x 16 4.64, 1024 x 8 4.35.  SOHIT_SEG_CFG selects (0 = library default).
+template <int IPT, int BLOCK = 256, int BITS = 8>
+using SegCfg = rocprim::segmented_radix_sort_config<BITS, rocprim::kernel_config<BLOCK, IPT>, rocprim::WarpSortConfig<8, 4, 256, 64, 16, 8, 256>, true>;
+
+static int seg_variant() {
+    static const int v = getenv("SOHIT_SEG_CFG") ? atoi(getenv("SOHIT_SEG_CFG")) : 2;
+    return v;
+}
+
+template <class Cfg>
+static hipError_t seg_sort(void* temp, size_t& bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* sb, const u32* se, int b0,
+                           int b1, hipStream_t st) {
+    return rocprim::segmented_radix_sort_keys<Cfg>(temp, bytes, in, out, (unsigned)n, nseg, sb, se, (unsigned)b0, (unsigned)b1, st, false);
+}
+
+static hipError_t seg_sort_dispatch(void* temp, size_t& bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* sb, const u32* se,
+                                    int b0, int b1, hipStream_t st) {
+    switch (seg_variant()) {
+        case 0: return seg_sort<rocprim::default_config>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
+        case 1: return seg_sort<SegCfg<8>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
+        case 4: return seg_sort<SegCfg<16, 512>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
+        case 5: return seg_sort<SegCfg<8, 1024>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
+        default: return seg_sort<SegCfg<16>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
+    }
+}
+
 size_t sort_keys_u64_seg_temp_bytes(size_t n, u32 nseg, int begin_bit, int end_bit) {
     size_t bytes = 0;
-    (void)hipcub::DeviceSegmentedRadixSort::SortKeys((void*)nullptr, bytes, (const u64*)nullptr, (u64*)nullptr, (int)n, (int)nseg,
-                                                      (const u32*)nullptr, (const u32*)nullptr, begin_bit, end_bit, (hipStream_t)0);
+    (void)seg_sort_dispatch(nullptr, bytes, nullptr, nullptr, n, nseg, nullptr, nullptr, begin_bit, end_bit, (hipStream_t)0);
     return bytes;
 }
 
 void sort_keys_u64_seg(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* seg, int begin_bit,
                        int end_bit, hipStream_t st) {
     if (n == 0) return;
-    HIP_CHECK(hipcub::DeviceSegmentedRadixSort::SortKeys(temp, temp_bytes, in, out, (int)n, (int)nseg, seg, seg + 1, begin_bit, end_bit, st));
+    HIP_CHECK(seg_sort_dispatch(temp, temp_bytes, in, out, n, nseg, seg, seg + 1, begin_bit, end_bit, st));
 }
