@@ -113,26 +113,46 @@ __global__ __launch_bounds__(64) void k_ksc_order(const u8* __restrict__ q_scls,
 }
 
 // ---- high-frequency cap (fsearch.py:2667-2677) ---------------------------------------------------
-__global__ __launch_bounds__(64) void k_cap(const u32* __restrict__ korder, const u32* __restrict__ qoff, u32 nq, int mink,
-                                            const u32* __restrict__ pcnt, i64 threshold, u8* __restrict__ mark,
-                                            unsigned long long* __restrict__ qhits) {
-    const u32 q = blockIdx.x * 64u + threadIdx.x;
+// Positions are taken in korder until the running bucket total exceeds threshold * len; the test precedes the
+// add, so position r is taken iff the total of the positions before it is <= the limit: a prefix of the order.
+// One wave per query: 64 counts per step, wave prefix sum (u64), carried total; also returns the query's hits.
+__global__ __launch_bounds__(256) void k_cap(const u32* __restrict__ korder, const u32* __restrict__ qoff, u32 nq, int mink,
+                                             const u32* __restrict__ pcnt, i64 threshold, u8* __restrict__ mark,
+                                             unsigned long long* __restrict__ qhits) {
+    const u32 q = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (q >= nq) return;
-    qhits[q] = 0;
     const u32 base = qoff[q];
     const int ql = (int)(qoff[q + 1] - base);
     const int nk = ql - mink + 1;
-    if (nk <= 0) return;
-    const u32 pbase = base + q;  // packed position of residue 0
-    const i64 thr = threshold * (i64)ql;
-    i64 cum = 0;
-    for (int r = 0; r < nk; ++r) {
-        if (cum > thr) break;
-        u32 pos = korder[base + r];
-        cum += pcnt[pbase + pos];
-        mark[pbase + pos] = 1;
+    unsigned long long cum = 0;  // total of the positions taken so far (wave-uniform)
+    if (nk > 0) {
+        const u32 pbase = base + q;  // packed position of residue 0
+        const i64 thr = threshold * (i64)ql;
+        for (int r0 = 0; r0 < nk; r0 += 64) {
+            const int r = r0 + lane;
+            u32 pos = 0;
+            unsigned long long v = 0;
+            if (r < nk) {
+                pos = korder[base + r];
+                v = pcnt[pbase + pos];
+            }
+            unsigned long long inc = v;  // inclusive prefix over the wave
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned long long t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            const bool take = (r < nk) && ((i64)(cum + inc - v) <= thr);
+            if (take) mark[pbase + pos] = 1;
+            const unsigned long long tb = __ballot(take);
+            // taken lanes form a prefix of the wave: the new total is the inclusive prefix of the last taken lane
+            const int ntake = __popcll(tb);
+            if (ntake) cum += __shfl(inc, ntake - 1);
+            if (ntake < 64 && ntake < nk - r0) break;  // a position was refused: everything after it is refused too
+        }
     }
-    qhits[q] = (unsigned long long)cum;  // seed hits this query will visit in this chunk
+    if (lane == 0) qhits[q] = cum;  // seed hits this query will visit in this chunk
 }
 
 // ---- effective per-seed hit counts + compaction of non-empty seeds --------------------------------
@@ -381,7 +401,7 @@ void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, int mink, const
 void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark,
                 unsigned long long* qhits, hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_cap, dim3((nq + 63) / 64), dim3(64), 0, st, korder, qoff, nq, mink, pcnt, threshold, mark, qhits);
+    hipLaunchKernelGGL(k_cap, dim3((nq + 3) / 4), dim3(256), 0, st, korder, qoff, nq, mink, pcnt, threshold, mark, qhits);
 }
 
 void launch_effcnt(const u8* mark, const u32* scnt, u32 Ppad, int AS, u32 p_lo, u32 p_hi, u32* eff, u32* nz, hipStream_t st) {

@@ -53,9 +53,13 @@ void launch_query_segments(const u32* hoff, size_t T, const u32* qoff, u32 nq, i
 template <int IPT, int BLOCK = 256, int BITS = 8>
 using SegCfg = rocprim::segmented_radix_sort_config<BITS, rocprim::kernel_config<BLOCK, IPT>, rocprim::WarpSortConfig<8, 4, 256, 64, 16, 8, 256>, true>;
 
-static int seg_variant() {
-    static const int v = getenv("SOHIT_SEG_CFG") ? atoi(getenv("SOHIT_SEG_CFG")) : 2;
-    return v;
+// Long segments (weight-6 seeds: tens of thousands of keys per query) want the 8-bit / 256 x 16 instance; short ones
+// (weight-10 seeds: hundreds per query) are served better by the library default with its warp-sort size classes
+// (config 3: 2.7 ms vs 3.7 ms).
+static int seg_variant(size_t n, u32 nseg) {
+    static const int v = getenv("SOHIT_SEG_CFG") ? atoi(getenv("SOHIT_SEG_CFG")) : -1;
+    if (v >= 0) return v;
+    return (nseg && n / nseg >= 4096) ? 2 : 0;
 }
 
 template <class Cfg>
@@ -66,7 +70,7 @@ static hipError_t seg_sort(void* temp, size_t& bytes, const u64* in, u64* out, s
 
 static hipError_t seg_sort_dispatch(void* temp, size_t& bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* sb, const u32* se,
                                     int b0, int b1, hipStream_t st) {
-    switch (seg_variant()) {
+    switch (seg_variant(n, nseg)) {
         case 0: return seg_sort<rocprim::default_config>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
         case 1: return seg_sort<SegCfg<8>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
         case 4: return seg_sort<SegCfg<16, 512>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
