@@ -248,6 +248,14 @@ struct so_ctx {
     bool q_present[256];               // bytes that can occur in (masked) query residues
     void* pinned = nullptr;            // pinned host staging for result rows
     size_t pinned_cap = 0;
+    // host-side row emission of batch k runs on a worker thread while the GPU processes batch k + 1
+    struct EmitJob {
+        std::thread th;
+        bool active = false;
+        size_t base = 0, n = 0;
+        std::atomic<i64> dropped{0};
+        std::exception_ptr err;
+    } emit;
     unsigned long long* h_small = nullptr;  // pinned scratch for the small device -> host reads (counts, totals): 1 KB
     std::map<std::string, double> tm;  // per-stage wall ms (only with params.profile)
     std::shared_ptr<void> batch;       // persistent per-batch scratch (struct Batch)
@@ -957,6 +965,27 @@ struct HostRow {
     int v[12];
 };
 
+// wait for the row-emission job of the previous batch (if any) and apply its rare post-filter
+void emit_join(so_ctx* c, HitBuf& out) {
+    if (!c->emit.active) return;
+    c->emit.th.join();
+    c->emit.active = false;
+    if (c->emit.err) {
+        std::exception_ptr e = c->emit.err;
+        c->emit.err = nullptr;
+        std::rethrow_exception(e);
+    }
+    if (c->emit.dropped.load()) {
+        // entry_point re-checks e <= expect (3234).  k_stop_round applied the same test to the same
+        // doubles, so this never fires; kept as the reference has it.
+        const double expect = c->expect;
+        size_t wpos = c->emit.base;
+        for (size_t k = c->emit.base; k < c->emit.base + c->emit.n; ++k)
+            if (out.p[k].evalue <= expect) out.p[wpos++] = out.p[k];
+        out.n = wpos;
+    }
+}
+
 void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     const double t0 = wall();
     StageClock sc(c);
@@ -1080,6 +1109,8 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     if (NO) {
         b.outrec.ensure(12 * (size_t)NO + 16);
         launch_emit_hits(b.tasks.p, b.ares.p, b.toff.p, b.sel.p, b.nout.p, b.ooff.p, b.bits.p, nq, b.outrec.p, c->st);
+        emit_join(c, out);  // the previous batch's job reads the staging buffer and writes into `out`
+        sc.lap("phase2.emit_host");
         // pinned staging buffer: pageable D2H runs at ~1 GB/s, pinned at PCIe speed
         if (c->pinned_cap < (size_t)NO * sizeof(HostRow)) {
             if (c->pinned) (void)hipHostFree(c->pinned);
@@ -1101,34 +1132,36 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         const size_t base = out.n;
         out.grow(NO);
         so_hit* dst = out.p + base;
-        const double expect = c->expect;
-        std::atomic<i64> dropped(0);
-        parallel_for((i64)NO, [&](i64 i) {
-            const int* v = rows[i].v;
-            so_hit h;
-            h.qidx = b.q_lo + v[0];
-            h.sidx = v[1];
-            h.aln = v[2], h.mis = v[3], h.gap = v[4], h.qst = v[5], h.qed = v[6], h.sst = v[7], h.sed = v[8], h.bit = v[9];
-            h.ungapped = v[10], h.matches = v[11];
-            h.qlen = (int32_t)c->qry.len(h.qidx);
-            h.slen = (int32_t)c->ref.len(h.sidx);
-            // idy: one += 1. per identical column, then idy *= (100. / AL) (fsearch.py:1458-1459, 1471)
-            h.identity = (double)h.matches * (100. / (double)h.aln);
-            // bit2e (1086): D * len(sqi) * len(sqj) * pow(2, -bit)
-            const double pw = (h.bit >= 0 && h.bit < 1200) ? p2[h.bit] : p_pow(2, (double)(-h.bit));
-            h.evalue = (double)(D * (i64)h.qlen * (i64)h.slen) * pw;
-            if (!(h.evalue <= expect)) dropped.fetch_add(1);
-            dst[i] = h;
-        });
         out.n = base + NO;
-        if (dropped.load()) {
-            // entry_point re-checks e <= expect (3234).  k_stop_round applied the same test to the same
-            // doubles, so this never fires; kept as the reference has it.
-            size_t wpos = base;
-            for (size_t k = base; k < base + NO; ++k)
-                if (out.p[k].evalue <= expect) out.p[wpos++] = out.p[k];
-            out.n = wpos;
-        }
+        const double expect = c->expect;
+        const i64 q_lo = b.q_lo;
+        const double* p2p = p2.data();
+        c->emit.base = base, c->emit.n = NO;
+        c->emit.dropped.store(0);
+        c->emit.active = true;
+        c->emit.th = std::thread([c, rows, dst, NO, D, expect, q_lo, p2p] {
+            try {
+                parallel_for((i64)NO, [&](i64 i) {
+                    const int* v = rows[i].v;
+                    so_hit h;
+                    h.qidx = q_lo + v[0];
+                    h.sidx = v[1];
+                    h.aln = v[2], h.mis = v[3], h.gap = v[4], h.qst = v[5], h.qed = v[6], h.sst = v[7], h.sed = v[8], h.bit = v[9];
+                    h.ungapped = v[10], h.matches = v[11];
+                    h.qlen = (int32_t)c->qry.len(h.qidx);
+                    h.slen = (int32_t)c->ref.len(h.sidx);
+                    // idy: one += 1. per identical column, then idy *= (100. / AL) (fsearch.py:1458-1459, 1471)
+                    h.identity = (double)h.matches * (100. / (double)h.aln);
+                    // bit2e (1086): D * len(sqi) * len(sqj) * pow(2, -bit)
+                    const double pw = (h.bit >= 0 && h.bit < 1200) ? p2p[h.bit] : p_pow(2, (double)(-h.bit));
+                    h.evalue = (double)(D * (i64)h.qlen * (i64)h.slen) * pw;
+                    if (!(h.evalue <= expect)) c->emit.dropped.fetch_add(1);
+                    dst[i] = h;
+                });
+            } catch (...) {
+                c->emit.err = std::current_exception();
+            }
+        });
     }
     sc.lap("phase2.emit_host");
     c->cnt.phase2_ms += (wall() - t0) * 1e3;
@@ -1138,6 +1171,16 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
     if (!c->ref_loaded) throw SoError("so_search: no reference loaded");
     if (!c->qry_loaded) throw SoError("so_search: no queries loaded");
     build_index(c);
+    struct EmitGuard {  // an exception must not leave a worker writing into a result buffer that is being freed
+        so_ctx* c;
+        ~EmitGuard() {
+            if (c->emit.active) {
+                c->emit.th.join();
+                c->emit.active = false;
+                c->emit.err = nullptr;
+            }
+        }
+    } emit_guard{c};
     const double t0 = wall();
     const i64 N = c->qry.N, D = c->ref.N;
     i64 st = std::min<i64>(std::max<i64>(0, q_lo), N);       // fsearch.py:2980
@@ -1177,6 +1220,7 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
                 c->masked.emplace_back((const char*)b.h_res.data() + b.h_off[i], (size_t)(b.h_off[i + 1] - b.h_off[i]));
         }
     }
+    emit_join(c, out);  // the last batch's rows
     c->cnt.rows += (i64)out.n;
     c->cnt.total_ms += (wall() - t0) * 1e3;
 }
