@@ -194,8 +194,13 @@ struct ChunkIndex {
     u32 E = 0;
     i64 threshold = 0;
     u32 maxslen = 0;
-    DevBuf<u32> start;    // NC + 1
-    DevBuf<u64> entries;  // E
+    DevBuf<u64> entries;  // E, grouped by ascending bucket id (the reference's CSR slot layout)
+    DevBuf<u32> ub, ubeg, ucnt;  // occupied bucket ids (ascending), their first slots (+ E), their sizes
+    u32 U = 0;            // occupied buckets
+    DevBuf<u32> hkey;     // open-addressed map bucket id -> hval = first slot | count << 32
+    DevBuf<u64> hval;
+    int hshift = 31;
+    u32 hmask = 0;
     DevBuf<u64> dkeys;    // E: per-entry key addends for the layout (d_sh_subj, d_sh_diag) -- k_encode_delta
     DevBuf<u32> dk32;     // E: compact addends for field widths (d_ba, d_bd) -- k_encode_delta32
     int d_sh_subj = -1, d_sh_diag = -1, d_ba = -1, d_bd = -1;
@@ -237,6 +242,8 @@ struct so_ctx {
     DevBuf<u32> d_scan_tmp, d_tmp32a, d_tmp32b;
     DevBuf<u64> d_stats;
     DevBuf<u32> d_small;  // parked scan totals (stash_u32)
+    DevBuf<u32> ix_pcount, ix_bkt, ix_bkt2, ix_flags, ix_ridx;  // index build scratch
+    DevBuf<u64> ix_ent;
     DevBuf<u8> d_pcls;
     DevBuf<u8> d_sort_tmp;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -496,7 +503,7 @@ void load_ref_common(so_ctx* c, i64 r_lo, i64 r_hi) {
 // threshold = int(mu + 2 sd) (fsearch.py:2248-2250, 746-761) from exact integer sums; when the
 // value is too close to an integer for that to be safe, replay the reference's sequential
 // floating-point loops over the counts in bucket order.
-i64 chunk_threshold(so_ctx* c, const u32* d_counts, u64 s1, u64 s2, u64 nn) {
+i64 chunk_threshold(so_ctx* c, const u32* d_counts /*sizes of the occupied buckets, ascending bucket order*/, u64 s1, u64 s2, u64 nn) {
     const double N = (double)(nn + 1);
     const double mu = (double)s1 / N;
     long double lm = (long double)mu;
@@ -508,8 +515,8 @@ i64 chunk_threshold(so_ctx* c, const u32* d_counts, u64 s1, u64 s2, u64 nn) {
     const bool forced = getenv("SOHIT_EXACT_THRESHOLD") != nullptr;
     if (!forced && T - fl > margin && (fl + 1.0L) - T > margin) return (i64)fl;
     // exact replay
-    std::vector<u32> counts((size_t)c->nc);
-    HIP_CHECK(hipMemcpyAsync(counts.data(), d_counts, (size_t)c->nc * sizeof(u32), hipMemcpyDeviceToHost, c->st));
+    std::vector<u32> counts((size_t)nn);  // the reference walks all NC counts and skips the zeros: same sequence
+    if (nn) HIP_CHECK(hipMemcpyAsync(counts.data(), d_counts, (size_t)nn * sizeof(u32), hipMemcpyDeviceToHost, c->st));
     HIP_CHECK(hipStreamSynchronize(c->st));
     i64 Nn = 1;
     double m = 0.;
@@ -523,6 +530,10 @@ i64 chunk_threshold(so_ctx* c, const u32* d_counts, u64 s1, u64 s2, u64 nn) {
     return (i64)(m + 2 * sd);
 }
 
+void* small_host(so_ctx* c);
+u32 d2h_u32(so_ctx* c, const u32* p);
+void ensure_sort_tmp(so_ctx* c, size_t bytes);
+
 void build_index(so_ctx* c) {
     if (!c->ref_loaded) throw SoError("so_build_index: no reference loaded");
     if (c->index_built) return;
@@ -532,7 +543,6 @@ void build_index(so_ctx* c) {
     i64 Start = c->r_lo == -1 ? 0 : std::max<i64>(0, c->r_lo);   // makedb, fsearch.py:2286-2288
     i64 End = c->r_hi == -1 ? N : c->r_hi;
     const u32 NC = (u32)c->nc;
-    c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)NC + 1) + 8);
     c->cnt.index_entries = 0;
     for (i64 s = Start; s < End; s += c->chunk) {
         std::unique_ptr<ChunkIndex> ch;
@@ -551,25 +561,60 @@ void build_index(so_ctx* c) {
         ch->p_hi = c->ref.off[ch->seq_hi] + (u32)ch->seq_hi;
         ch->maxslen = 0;
         for (i64 j = ch->seq_lo; j < ch->seq_hi; ++j) ch->maxslen = std::max(ch->maxslen, c->ref.len(j));
-        ch->start.ensure((size_t)NC + 4);
-        HIP_CHECK(hipMemsetAsync(ch->start.p, 0, ((size_t)NC + 4) * sizeof(u32), c->st));
-        launch_index_count(c->ref.d_words.p, c->ref.d_pseq.p, c->ref.d_off.p, ch->p_lo, ch->p_hi, c->ref.Ppad, (u32)ch->seq_lo, c->cfg,
-                           c->ref.lut, (u32)c->step, ch->start.p, c->st);
-        launch_index_stats(ch->start.p, NC, c->d_stats.p, c->st);
-        u64 stats[4];
-        HIP_CHECK(hipMemcpyAsync(stats, c->d_stats.p, sizeof stats, hipMemcpyDeviceToHost, c->st));
-        HIP_CHECK(hipStreamSynchronize(c->st));
-        const u64 E64 = stats[0];
-        if (E64 >= (1ull << 29)) throw SoError("chunk index exceeds 2^29 entries (the lookup kernel addresses 8-byte slots with 32-bit byte offsets); lower -c");
-        ch->E = (u32)E64;
-        ch->threshold = chunk_threshold(c, ch->start.p, stats[0], stats[1], stats[2]);
-        // inclusive scan in place: start[b] = end of bucket b; the fill pass walks it back to the begin
-        scan_u32(ch->start.p, ch->start.p, NC, true, c->d_scan_tmp.p, c->st);
-        HIP_CHECK(hipMemcpyAsync(ch->start.p + NC, &ch->E, sizeof(u32), hipMemcpyHostToDevice, c->st));
-        ch->entries.ensure((size_t)ch->E + 4);
-        launch_index_fill(c->ref.d_words.p, c->ref.d_pseq.p, c->ref.d_off.p, ch->p_lo, ch->p_hi, c->ref.Ppad, (u32)ch->seq_lo, c->cfg,
-                          c->ref.lut, (u32)c->step, ch->start.p, ch->entries.p, c->st);
-        if (ch->E > 0 && stats[3] > 0) launch_index_fixlast(ch->start.p, ch->entries.p, (u32)(stats[3] - 1), ch->E, c->st);
+        // 1. windows per position -> exclusive scan -> (bucket, entry) pairs in position order
+        const u32 npos = ch->p_hi - ch->p_lo;
+        c->ix_pcount.ensure((size_t)npos + 4);
+        c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)npos + 1) + 8);
+        launch_index_windows(false, c->ref.d_words.p, c->ref.d_pseq.p, c->ref.d_off.p, ch->p_lo, ch->p_hi, c->ref.Ppad, (u32)ch->seq_lo, c->cfg,
+                             c->ref.lut, (u32)c->step, c->ix_pcount.p, nullptr, nullptr, c->st);
+        u32 E = 0;
+        if (npos) E = d2h_u32(c, scan_u32(c->ix_pcount.p, c->ix_pcount.p, npos, false, c->d_scan_tmp.p, c->st));
+        if ((u64)E >= (1ull << 29)) throw SoError("chunk index exceeds 2^29 entries (the lookup kernel addresses 8-byte slots with 32-bit byte offsets); lower -c");
+        ch->E = E;
+        ch->U = 0;
+        ch->entries.ensure((size_t)E + 4);
+        u64 s2 = 0;
+        if (E) {
+            c->ix_bkt.ensure((size_t)E + 4), c->ix_bkt2.ensure((size_t)E + 4), c->ix_ent.ensure((size_t)E + 4);
+            launch_index_windows(true, c->ref.d_words.p, c->ref.d_pseq.p, c->ref.d_off.p, ch->p_lo, ch->p_hi, c->ref.Ppad, (u32)ch->seq_lo, c->cfg,
+                                 c->ref.lut, (u32)c->step, c->ix_pcount.p, c->ix_bkt.p, c->ix_ent.p, c->st);
+            // 2. group by bucket id (ascending): the slot layout of the reference's CSR
+            const int bbits = ceil_log2((u64)NC);
+            ensure_sort_tmp(c, sort_pairs_u32_u64_temp_bytes(E, bbits));
+            sort_pairs_u32_u64(c->d_sort_tmp.p, c->d_sort_tmp.cap, c->ix_bkt.p, c->ix_bkt2.p, c->ix_ent.p, ch->entries.p, E, bbits, c->st);
+            // 3. runs -> occupied bucket list, first slots, sizes
+            c->ix_flags.ensure((size_t)E + 4), c->ix_ridx.ensure((size_t)E + 4);
+            c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)E + 1) + 8);
+            launch_run_heads(c->ix_bkt2.p, E, c->ix_flags.p, c->st);
+            const u32 U = d2h_u32(c, scan_u32(c->ix_flags.p, c->ix_ridx.p, E, false, c->d_scan_tmp.p, c->st));
+            ch->U = U;
+            ch->ub.ensure((size_t)U + 4), ch->ubeg.ensure((size_t)U + 4), ch->ucnt.ensure((size_t)U + 4);
+            launch_run_list(c->ix_bkt2.p, c->ix_flags.p, c->ix_ridx.p, E, U, ch->ub.p, ch->ubeg.p, ch->ucnt.p, c->st);
+            // 4. threshold statistics over the occupied buckets (sum c = E, sum c^2, count = U)
+            launch_index_stats(ch->ucnt.p, U, c->d_stats.p, c->st);
+            u64* stats = (u64*)small_host(c);
+            u32* last_lo_h = (u32*)(stats + 4);
+            HIP_CHECK(hipMemcpyAsync(stats, c->d_stats.p, 4 * sizeof(u64), hipMemcpyDeviceToHost, c->st));
+            HIP_CHECK(hipMemcpyAsync(last_lo_h, ch->ubeg.p + (U - 1), sizeof(u32), hipMemcpyDeviceToHost, c->st));
+            HIP_CHECK(hipStreamSynchronize(c->st));
+            s2 = stats[1];
+            const u32 last_lo = *last_lo_h;
+            // 5. open-addressed directory, load factor <= 1/2
+            u32 cap = 1024;
+            int lg = 10;
+            while (cap < 2 * U) cap <<= 1, ++lg;
+            ch->hkey.ensure(cap), ch->hval.ensure(cap);
+            ch->hshift = 32 - lg, ch->hmask = cap - 1;
+            HIP_CHECK(hipMemsetAsync(ch->hkey.p, 0xFF, (size_t)cap * sizeof(u32), c->st));
+            launch_htab_insert(ch->ub.p, ch->ubeg.p, U, ch->hkey.p, ch->hval.p, ch->hshift, ch->hmask, c->st);
+            // 6. the reference never reads the last locus slot: park the last bucket's smallest entry there
+            launch_index_fixlast(ch->entries.p, last_lo, E, c->st);
+        } else {
+            ch->hkey.ensure(1024), ch->hval.ensure(1024);
+            ch->hshift = 22, ch->hmask = 1023;
+            HIP_CHECK(hipMemsetAsync(ch->hkey.p, 0xFF, 1024 * sizeof(u32), c->st));
+        }
+        ch->threshold = chunk_threshold(c, ch->ucnt.p, (u64)E, s2, (u64)ch->U);
         HIP_CHECK(hipStreamSynchronize(c->st));
         c->cnt.index_entries += ch->E;
         c->chunks.push_back(std::move(ch));
@@ -753,7 +798,7 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     StageClock sc(c);
     {
         ProfTimer pt(c, &c->cnt.bounds_ms, &c->cnt.bounds_launches);
-        launch_bounds(b.qbucket.p, Ppad, AS, ch.start.p, NC, ch.E, b.sbeg.p, b.scnt.p, b.pcnt.p, c->st);
+        launch_bounds(b.qbucket.p, Ppad, AS, ch.hkey.p, ch.hval.p, ch.hshift, ch.hmask, NC, ch.E, b.sbeg.p, b.scnt.p, b.pcnt.p, c->st);
         pt.stop();
         if (c->profile) c->cnt.bounds_bytes += (i64)8 * AS * (i64)b.h_off[b.nq];
     }
@@ -1519,7 +1564,18 @@ int so_chunk_download(so_ctx* c, int64_t k, uint32_t* start, uint64_t* entries) 
     return guarded(c, [&] {
         if (k < 0 || k >= (int64_t)c->chunks.size()) throw SoError("so_chunk_download: no such chunk");
         ChunkIndex& ch = *c->chunks[k];
-        if (start) HIP_CHECK(hipMemcpy(start, ch.start.p, ((size_t)c->nc + 1) * sizeof(u32), hipMemcpyDeviceToHost));
+        if (start) {  // the reference's direct-addressed start[NC + 1], rebuilt from the occupied-bucket list
+            std::vector<u32> ub(ch.U), ubeg((size_t)ch.U + 1);
+            if (ch.U) {
+                HIP_CHECK(hipMemcpy(ub.data(), ch.ub.p, (size_t)ch.U * sizeof(u32), hipMemcpyDeviceToHost));
+                HIP_CHECK(hipMemcpy(ubeg.data(), ch.ubeg.p, ((size_t)ch.U + 1) * sizeof(u32), hipMemcpyDeviceToHost));
+            }
+            size_t k = 0;
+            for (size_t bk = 0; bk <= (size_t)c->nc; ++bk) {
+                while (k < ch.U && ub[k] < bk) ++k;  // start[b] = first slot of the first occupied bucket >= b
+                start[bk] = k < ch.U ? ubeg[k] : ch.E;
+            }
+        }
         if (entries && ch.E) HIP_CHECK(hipMemcpy(entries, ch.entries.p, (size_t)ch.E * sizeof(u64), hipMemcpyDeviceToHost));
     });
 }

@@ -1,50 +1,106 @@
 // k_index.hip -- per-chunk seed index build on the device (Fasta.build_msav, fsearch.py:2208-2280).
 //
-//   start[0..NC]  u32   after the build: start[b] = first slot of bucket b, start[NC] = E
-//   entries[0..E) u64   (subject_local << 32) | (tag << 24) | pos,   tag = alphabet * S + pattern
+// The reference keeps a direct-addressed CSR: start[NC + 1] (480 MB at -M 120000000) + locus[E].  Only a few
+// hundred thousand of the 120 M buckets are occupied, so here the bucket directory is an OPEN-ADDRESSED HASH MAP
+// of the occupied bucket ids, a few MB that stay in L2 / Infinity Cache:
 //
-// The reference stores bucket members in descending insertion order and later visits them in
-// slot order; here the slot order inside a bucket is arbitrary (atomic fill) because every
-// downstream consumer re-derives the visiting order from the entry value itself (descending
-// (subject, tag, pos) == descending insertion order) -- see DESIGN.md "ordering without sorting
-// the index".  The one order-dependent rule, "the very last locus slot is never read"
-// (fsearch.py:2277, 2539), is kept by k_index_fixlast.
+//   entries[0..E) u64   (subject_local << 32) | (tag << 24) | pos, grouped by ascending bucket id -- the very slot
+//                       layout of the reference's CSR (tag = alphabet * S + pattern)
+//   ub[0..U)      u32   occupied bucket ids, ascending;   ubeg[0..U] u32   first slot of each (ubeg[U] = E)
+//   hkey / hval         hash map bucket id -> (first slot | count << 32), linear probing, load <= 1/2
+//
+// Build: count windows per position -> exclusive scan -> emit (bucket, entry) pairs in position order (no atomics)
+// -> radix sort by bucket -> run heads -> unique list, run lengths (threshold statistics) -> hash map.
+// "bucket = hash % NC, no key check" -- collisions included -- is unchanged: the map is keyed by the bucket id.
+//
+// The reference stores bucket members in descending insertion order and later visits them in slot order; here
+// the slot order inside a bucket is whatever the sort leaves, because every downstream consumer re-derives the
+// visiting order from the entry value itself (descending (subject, tag, pos) == descending insertion order) --
+// see DESIGN.md "ordering without sorting the index".  The one order-dependent rule, "the very last locus slot
+// is never read" (fsearch.py:2277, 2539), is kept by k_index_fixlast.
 #include "common.h"
 #include "kernels.h"
 #include "seedhash.h"
 
-template <bool FILL>
-__global__ __launch_bounds__(TILE_POS) void k_index_pass(const u32* __restrict__ words, const u32* __restrict__ pseq,
-                                                         const u32* __restrict__ off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
-                                                         SeedCfg cfg, HashLut lut, u32 step, u32* __restrict__ start,
-                                                         u64* __restrict__ entries) {
+// EMIT = false: pcount[p - p_lo] = seed windows starting at packed position p (0 .. A * S).
+// EMIT = true : pcount holds the exclusive scan of those counts; the position writes its (bucket, entry) pairs there.
+template <bool EMIT>
+__global__ __launch_bounds__(TILE_POS) void k_index_windows(const u32* __restrict__ words, const u32* __restrict__ pseq,
+                                                            const u32* __restrict__ off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
+                                                            SeedCfg cfg, HashLut lut, u32 step, u32* __restrict__ pcount,
+                                                            u32* __restrict__ bkt, u64* __restrict__ ent) {
     __shared__ u8 s_cls[TILE_POS + MAX_SEEDLEN];
     const u32 p0 = p_lo + blockIdx.x * TILE_POS;
     stage_classes(words, p0, Ppad, s_cls);
     __syncthreads();
     const u32 p = p0 + threadIdx.x;
     if (p >= p_hi) return;
-    if (s_cls[threadIdx.x] >= HCLS_SEP) return;  // separator or x: no window starts here
+    u32 n = 0;
+    bool live = s_cls[threadIdx.x] < HCLS_SEP;  // separator or x: no window starts here
     u32 j = 0, pos = 0;
-    if (FILL || step > 1) {
+    if (live && (EMIT || step > 1)) {
         j = pseq[p];
         pos = p - (off[j] + j);
-        if (step > 1 && (pos % step) != 0) return;  // xrange(0, L - k + 1, step), fsearch.py:534
+        if (step > 1 && (pos % step) != 0) live = false;  // xrange(0, L - k + 1, step), fsearch.py:534
     }
-    u32 bucket[MAX_PATTERNS];
-    for (int a = 0; a < cfg.A; ++a) {
-        u32 mask = hash_position(s_cls + threadIdx.x, cfg, lut.v[a], bucket);
-        for (int s = 0; s < cfg.S; ++s) {
-            if (!((mask >> s) & 1u)) continue;
-            if (!FILL) {
-                atomicAdd(&start[bucket[s]], 1u);
+    if (live) {
+        u32 slot = EMIT ? pcount[p - p_lo] : 0u;
+        u32 bucket[MAX_PATTERNS];
+        for (int a = 0; a < cfg.A; ++a) {
+            const u32 mask = hash_position(s_cls + threadIdx.x, cfg, lut.v[a], bucket);
+            if (!EMIT) {
+                n += (u32)__popc(mask);
             } else {
-                u32 slot = atomicSub(&start[bucket[s]], 1u) - 1u;
-                u32 tag = (u32)(a * cfg.S + s);
-                entries[slot] = ((u64)(j - seq_lo) << 32) | ((u64)tag << 24) | (u64)pos;
+                for (int s = 0; s < cfg.S; ++s) {
+                    if (!((mask >> s) & 1u)) continue;
+                    const u32 tag = (u32)(a * cfg.S + s);
+                    bkt[slot] = bucket[s];
+                    ent[slot] = ((u64)(j - seq_lo) << 32) | ((u64)tag << 24) | (u64)pos;
+                    ++slot;
+                }
             }
         }
     }
+    if (!EMIT) pcount[p - p_lo] = n;
+}
+
+// ---- runs of equal bucket ids in the sorted pair list ---------------------------------------------------
+__global__ __launch_bounds__(256) void k_run_heads(const u32* __restrict__ bkt, u32 E, u32* __restrict__ flags) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i < E) flags[i] = (i == 0 || bkt[i] != bkt[i - 1]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_run_list(const u32* __restrict__ bkt, const u32* __restrict__ flags, const u32* __restrict__ ridx,
+                                                  u32 E, u32 U, u32* __restrict__ ub, u32* __restrict__ ubeg) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0) ubeg[U] = E;
+    if (i < E && flags[i]) {
+        const u32 k = ridx[i];
+        ub[k] = bkt[i];
+        ubeg[k] = i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_run_counts(const u32* __restrict__ ubeg, u32 U, u32* __restrict__ cnt) {
+    const u32 k = blockIdx.x * 256u + threadIdx.x;
+    if (k < U) cnt[k] = ubeg[k + 1] - ubeg[k];
+}
+
+// ---- open-addressed map: bucket id -> (first slot | count << 32) -----------------------------------------
+__device__ __forceinline__ u32 htab_hash(u32 b, int hshift) { return (b * 2654435761u) >> hshift; }
+
+__global__ __launch_bounds__(256) void k_htab_insert(const u32* __restrict__ ub, const u32* __restrict__ ubeg, u32 U, u32* __restrict__ hkey,
+                                                     u64* __restrict__ hval, int hshift, u32 hmask) {
+    const u32 k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= U) return;
+    const u32 b = ub[k];
+    u32 h = htab_hash(b, hshift);
+    for (;;) {
+        const u32 old = atomicCAS(&hkey[h], HTAB_EMPTY, b);
+        if (old == HTAB_EMPTY) break;  // ids are unique: nobody else inserts b
+        h = (h + 1u) & hmask;
+    }
+    hval[h] = (u64)ubeg[k] | ((u64)(ubeg[k + 1] - ubeg[k]) << 32);
 }
 
 // sum c, sum c^2, #non-empty, largest non-empty bucket id over counts[0..NC)
@@ -127,10 +183,9 @@ __global__ __launch_bounds__(256) void k_index_stats_final(const u64* __restrict
 // Keep the reference's "slot len(locus)-1 is never read": that slot belongs to the last non-empty
 // bucket b* and, in the reference's descending order, holds b*'s smallest entry.  Move b*'s
 // smallest entry to slot E-1; the lookup clamps every bucket end to E-1 exactly like get_bin_mem.
-__global__ __launch_bounds__(256) void k_index_fixlast(const u32* __restrict__ start, u64* __restrict__ entries, u32 bstar, u32 E) {
+__global__ __launch_bounds__(256) void k_index_fixlast(u64* __restrict__ entries, u32 lo /*first slot of the last occupied bucket*/, u32 E) {
     __shared__ u64 s_min[256];
     __shared__ u32 s_idx[256];
-    u32 lo = start[bstar];
     u64 mn = ~0ull;
     u32 mi = E - 1;
     for (u32 i = lo + threadIdx.x; i < E; i += 256) {
@@ -154,12 +209,6 @@ __global__ __launch_bounds__(256) void k_index_fixlast(const u32* __restrict__ s
             entries[E - 1] = a;
         }
     }
-}
-
-// counts of non-empty buckets in bucket order (exact host replay of get_mu_sd, rare path)
-__global__ __launch_bounds__(256) void k_index_counts_from_start(const u32* __restrict__ start, u32 NC, u32* __restrict__ counts) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < NC) counts[i] = start[i + 1] - start[i];
 }
 
 
@@ -205,20 +254,28 @@ void launch_encode_delta(const u64* entries, u32 E, int sh_subj, int sh_diag, u3
     hipLaunchKernelGGL(k_encode_delta, dim3((E + 255) / 256), dim3(256), 0, st, entries, E, sh_subj, sh_diag, maxslen, dkeys);
 }
 
-void launch_index_count(const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
-                        const SeedCfg& cfg, const HashLut& lut, u32 step, u32* start, hipStream_t st) {
+void launch_index_windows(bool emit, const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
+                          const SeedCfg& cfg, const HashLut& lut, u32 step, u32* pcount, u32* bkt, u64* ent, hipStream_t st) {
     if (p_hi <= p_lo) return;
-    u32 nb = (p_hi - p_lo + TILE_POS - 1) / TILE_POS;
-    hipLaunchKernelGGL((k_index_pass<false>), dim3(nb), dim3(TILE_POS), 0, st, words, pseq, off, p_lo, p_hi, Ppad, seq_lo, cfg, lut,
-                       step, start, (u64*)nullptr);
+    const u32 nb = (p_hi - p_lo + TILE_POS - 1) / TILE_POS;
+    if (emit)
+        hipLaunchKernelGGL((k_index_windows<true>), dim3(nb), dim3(TILE_POS), 0, st, words, pseq, off, p_lo, p_hi, Ppad, seq_lo, cfg, lut, step,
+                           pcount, bkt, ent);
+    else
+        hipLaunchKernelGGL((k_index_windows<false>), dim3(nb), dim3(TILE_POS), 0, st, words, pseq, off, p_lo, p_hi, Ppad, seq_lo, cfg, lut, step,
+                           pcount, bkt, ent);
 }
 
-void launch_index_fill(const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
-                       const SeedCfg& cfg, const HashLut& lut, u32 step, u32* start, u64* entries, hipStream_t st) {
-    if (p_hi <= p_lo) return;
-    u32 nb = (p_hi - p_lo + TILE_POS - 1) / TILE_POS;
-    hipLaunchKernelGGL((k_index_pass<true>), dim3(nb), dim3(TILE_POS), 0, st, words, pseq, off, p_lo, p_hi, Ppad, seq_lo, cfg, lut,
-                       step, start, entries);
+void launch_run_heads(const u32* bkt, u32 E, u32* flags, hipStream_t st) {
+    if (E) hipLaunchKernelGGL(k_run_heads, dim3((E + 255) / 256), dim3(256), 0, st, bkt, E, flags);
+}
+void launch_run_list(const u32* bkt, const u32* flags, const u32* ridx, u32 E, u32 U, u32* ub, u32* ubeg, u32* cnt, hipStream_t st) {
+    if (!E) return;
+    hipLaunchKernelGGL(k_run_list, dim3((E + 255) / 256), dim3(256), 0, st, bkt, flags, ridx, E, U, ub, ubeg);
+    hipLaunchKernelGGL(k_run_counts, dim3((U + 255) / 256), dim3(256), 0, st, ubeg, U, cnt);
+}
+void launch_htab_insert(const u32* ub, const u32* ubeg, u32 U, u32* hkey, u64* hval, int hshift, u32 hmask, hipStream_t st) {
+    if (U) hipLaunchKernelGGL(k_htab_insert, dim3((U + 255) / 256), dim3(256), 0, st, ub, ubeg, U, hkey, hval, hshift, hmask);
 }
 
 // stats_buf: 4 results followed by INDEX_STATS_BLOCKS x 4 per-block partials
@@ -228,11 +285,7 @@ void launch_index_stats(const u32* counts, u32 NC, u64* stats_buf, hipStream_t s
     hipLaunchKernelGGL(k_index_stats_final, dim3(1), dim3(256), 0, st, stats_buf + 4, nb, stats_buf);
 }
 
-void launch_index_fixlast(const u32* start, u64* entries, u32 bstar, u32 E, hipStream_t st) {
+void launch_index_fixlast(u64* entries, u32 lo, u32 E, hipStream_t st) {
     if (E == 0) return;
-    hipLaunchKernelGGL(k_index_fixlast, dim3(1), dim3(256), 0, st, start, entries, bstar, E);
-}
-
-void launch_index_counts_from_start(const u32* start, u32 NC, u32* counts, hipStream_t st) {
-    hipLaunchKernelGGL(k_index_counts_from_start, dim3((NC + 255) / 256), dim3(256), 0, st, start, NC, counts);
+    hipLaunchKernelGGL(k_index_fixlast, dim3(1), dim3(256), 0, st, entries, lo, E);
 }

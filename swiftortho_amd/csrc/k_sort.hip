@@ -90,3 +90,16 @@ void sort_keys_u64_seg(void* temp, size_t temp_bytes, const u64* in, u64* out, s
     if (n == 0) return;
     HIP_CHECK(seg_sort_dispatch(temp, temp_bytes, in, out, n, nseg, seg, seg + 1, begin_bit, end_bit, st));
 }
+
+// (bucket id, index entry) pairs of the index build
+size_t sort_pairs_u32_u64_temp_bytes(size_t n, int bits) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs((void*)nullptr, bytes, (const u32*)nullptr, (u32*)nullptr, (const u64*)nullptr, (u64*)nullptr,
+                                             (int)n, 0, bits, (hipStream_t)0);
+    return bytes;
+}
+
+void sort_pairs_u32_u64(void* temp, size_t temp_bytes, const u32* kin, u32* kout, const u64* vin, u64* vout, size_t n, int bits, hipStream_t st) {
+    if (n == 0) return;
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, kin, kout, vin, vout, (int)n, 0, bits, st));
+}

@@ -29,21 +29,24 @@ void launch_seg(const u8* raw, const u32* src_off, u32 q_lo, u32 nq, const u32* 
 void launch_copy_range(const u8* src, u8* dst, size_t n, hipStream_t st);
 
 // k_index.hip
-void launch_index_count(const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
-                        const SeedCfg& cfg, const HashLut& lut, u32 step, u32* start, hipStream_t st);
-void launch_index_fill(const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
-                       const SeedCfg& cfg, const HashLut& lut, u32 step, u32* start, u64* entries, hipStream_t st);
+#define HTAB_EMPTY 0xFFFFFFFFu
+void launch_index_windows(bool emit, const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
+                          const SeedCfg& cfg, const HashLut& lut, u32 step, u32* pcount, u32* bkt, u64* ent, hipStream_t st);
+void launch_run_heads(const u32* bkt, u32 E, u32* flags, hipStream_t st);
+void launch_run_list(const u32* bkt, const u32* flags, const u32* ridx, u32 E, u32 U, u32* ub, u32* ubeg, u32* cnt, hipStream_t st);
+void launch_htab_insert(const u32* ub, const u32* ubeg, u32 U, u32* hkey, u64* hval, int hshift, u32 hmask, hipStream_t st);
+void sort_pairs_u32_u64(void* temp, size_t temp_bytes, const u32* kin, u32* kout, const u64* vin, u64* vout, size_t n, int bits, hipStream_t st);
+size_t sort_pairs_u32_u64_temp_bytes(size_t n, int bits);
 #define INDEX_STATS_BLOCKS 2048
 void launch_index_stats(const u32* counts, u32 NC, u64* stats_buf /*4 + 4 * INDEX_STATS_BLOCKS*/, hipStream_t st);
 void launch_encode_delta32(const u64* entries, u32 E, int ba, int bd, u32 maxslen, u32* dk32, hipStream_t st);
 void launch_encode_delta(const u64* entries, u32 E, int sh_subj, int sh_diag, u32 maxslen, u64* dkeys, hipStream_t st);
-void launch_index_fixlast(const u32* start, u64* entries, u32 bstar, u32 E, hipStream_t st);
-void launch_index_counts_from_start(const u32* start, u32 NC, u32* counts, hipStream_t st);
+void launch_index_fixlast(u64* entries, u32 lo, u32 E, hipStream_t st);
 
 // k_seed.hip
 void launch_qhash(const u32* words, u32 Ppad, const SeedCfg& cfg, const HashLut& lut, u32* qbucket, hipStream_t st);
-void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* start, u32 NC, u32 E, u32* sbeg, u32* scnt, u32* pcnt,
-                   hipStream_t st);
+void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* hkey, const u64* hval, int hshift, u32 hmask, u32 NC, u32 E, u32* sbeg,
+                   u32* scnt, u32* pcnt, hipStream_t st);
 void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, int mink, const signed char* b62c, int* ksc, u32* korder,
                       hipStream_t st);
 void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark,
