@@ -39,22 +39,54 @@ __device__ __forceinline__ u32 win4(const u8* __restrict__ base, int idx, int le
 #define GO (-11)
 #define GE (-1)
 
+// ---- lane predicates as 64-bit wave masks ------------------------------------------------------------
+// Every predicate of a band cell is an integer compare, so it is kept as the SGPR-pair mask the compare
+// produces; the boolean algebra (validity, trace priority) then runs on the scalar unit, and the few
+// per-lane selections read the mask directly (v_cndmask / v_addc with an SGPR-pair operand).  The
+// compiler cannot be made to keep an `i1` in this form across `&&` / `||`, hence the three helpers.
+typedef unsigned long long m64;
+#define ICMP_EQ 32
+#define ICMP_ULT 36
+__device__ __forceinline__ int sel0(int x, m64 m) {  // m ? x : 0
+    int r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
+    return r;
+}
+__device__ __forceinline__ int gapcost(m64 ext) {  // ext ? GE (-1) : GO (-11)
+    int r;
+    asm("v_cndmask_b32_e64 %0, -11, -1, %1" : "=v"(r) : "s"(ext));
+    return r;
+}
+__device__ __forceinline__ u32 shl1_in(u32 x, m64 bit) {  // 2 * x + bit
+    u32 r;
+    m64 cout;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(cout) : "v"(x), "s"(bit));
+    return r;
+}
+__device__ __forceinline__ int inc_if(int x, m64 bit) {  // x + bit
+    int r;
+    m64 cout;
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(cout) : "v"(x), "s"(bit));
+    return r;
+}
+
 // One band cell.  I / D arrive ready-made from the producing cells (their score plus the gap cost
 // that applies when stepping out of them: extend iff their own trace is that gap direction, else
 // open); Bd = diagonal neighbour's score.  Publishes B, Iout (for the cell to the right),
-// Dout (for the cell below) and the 2-bit trace code: 0 '*', 1 '\\', 2 '-', 3 '|'
-// (priority diag > left > up, fsearch.py:1404-1411).
-__device__ __forceinline__ void dp_cell(bool valid, int I, int D, int Bd, int s, int& B, int& Iout, int& Dout, u32& trc) {
+// Dout (for the cell below) and the two bits of the trace code  0 '*', 1 '\\', 2 '-', 3 '|'
+// (priority diag > left > up, fsearch.py:1404-1411) as masks t0 (bit 0) and t1 (bit 1).
+__device__ __forceinline__ void dp_cell(m64 valid, int I, int D, int Bd, int s, int& B, int& Iout, int& Dout, m64& t0, m64& t1) {
     const int M = Bd + s;
     const int b0 = max(max(I, D), max(M, 0));
-    const bool isM = valid && (b0 == M);
-    const bool eI = valid && !isM && (b0 == I);
-    const bool eD = valid && !isM && !eI && (b0 == D);
-    const int b = valid ? b0 : 0;
+    const m64 isM = __builtin_amdgcn_sicmp(b0, M, ICMP_EQ) & valid;
+    const m64 eI = __builtin_amdgcn_sicmp(b0, I, ICMP_EQ) & valid & ~isM;
+    const m64 eD = __builtin_amdgcn_sicmp(b0, D, ICMP_EQ) & valid & ~isM & ~eI;
+    const int b = sel0(b0, valid);
     B = b;
-    trc = isM ? 1u : (eI ? 2u : (eD ? 3u : 0u));
-    Iout = b + (eI ? GE : GO);
-    Dout = b + (eD ? GE : GO);
+    t0 = isM | eD;
+    t1 = eI | eD;
+    Iout = b + gapcost(eI);
+    Dout = b + gapcost(eD);
 }
 
 // trace codes: 0 '*' (stop), 1 '\\' (diag), 2 '-' (left), 3 '|' (up)
@@ -110,27 +142,27 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
             const u32 rc = rw & 31u, cc1 = cw & 31u;
             rw >>= 8;
             cw >>= 8;
-            const bool row_ok = (u32)(i - 1) < (u32)R;
-            const bool ve = row_ok && ((u32)(j0 - 1) < (u32)ncols);
-            const bool vo = row_ok && ((u32)j0 < (u32)ncols);
+            const m64 row_ok = __builtin_amdgcn_uicmp((u32)(i - 1), (u32)R, ICMP_ULT);
+            const m64 ve = row_ok & __builtin_amdgcn_uicmp((u32)(j0 - 1), (u32)ncols, ICMP_ULT);
+            const m64 vo = row_ok & __builtin_amdgcn_uicmp((u32)j0, (u32)ncols, ICMP_ULT);
             const int s0 = s_b62[rc * 36u + cc0], s1 = s_b62[rc * 36u + cc1];
             cc0 = cc1;
             int nBe, Ie_out, De_out, nBo, nIo, nDo;
-            u32 te, to;
-            dp_cell(ve, dpp_row_shr1(GO, Io_out), Do_out, Be, s0, nBe, Ie_out, De_out, te);
-            dp_cell(vo, Ie_out, dpp_row_shl1(GO, De_out), Bo, s1, nBo, nIo, nDo, to);
+            m64 te0, te1, to0, to1;
+            dp_cell(ve, dpp_row_shr1(GO, Io_out), Do_out, Be, s0, nBe, Ie_out, De_out, te0, te1);
+            dp_cell(vo, Ie_out, dpp_row_shl1(GO, De_out), Bo, s1, nBo, nIo, nDo, to0, to1);
             Be = nBe, Bo = nBo, Io_out = nIo, Do_out = nDo;
-            ncell += (ve ? 1 : 0) + (vo ? 1 : 0);
+            ncell = inc_if(inc_if(ncell, ve), vo);
             // first strict maximum in row-major order == largest (score, 8191 - i) key; keys of invalid cells are < any valid one
             const u32 rk = (u32)(8191 - i) & 8191u;
             keyE = max(keyE, ((u32)nBe << 13) | rk);
             keyO = max(keyO, ((u32)nBo << 13) | rk);
-            if (row_ok) {
-                tw |= (te | (to << 2)) << (((u32)(i - 1) & 7u) << 2);
-                if ((((u32)(i - 1)) & 7u) == 7u || i == R) {
-                    tr[((u32)(i - 1) >> 3) * 16u + (u32)l] = tw;
-                    tw = 0;
-                }
+            // the row's 4 trace bits (odd cell: bits 3-2, even cell: bits 1-0) are shifted into the trace word, one v_addc
+            // per bit; rows outside [1, R] shift in zeros.  Row r of an 8-row word ends up in nibble 7 - (r & 7).
+            tw = shl1_in(shl1_in(shl1_in(shl1_in(tw, to1), to0), te1), te0);
+            if ((u32)(i - 1) < (u32)R && ((((u32)(i - 1)) & 7u) == 7u || i == R)) {
+                tr[((u32)(i - 1) >> 3) * 16u + (u32)l] = tw << ((7u - ((u32)(i - 1) & 7u)) << 2);  // left-align a partial last word
+                tw = 0;
             }
         }
     }
@@ -195,7 +227,7 @@ __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ ta
             else {
                 const int key = ((i - 1) >> 3) * 16 + (d >> 1);
                 if (key != wkey) wkey = key, wv = tr[key];
-                tc = (int)((wv >> ((((i - 1) & 7) << 2) + ((d & 1) << 1))) & 3u);
+                tc = (int)((wv >> (((7 - ((i - 1) & 7)) << 2) + ((d & 1) << 1))) & 3u);
             }
         }
         if (tc == 0) break;
