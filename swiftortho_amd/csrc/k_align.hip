@@ -16,6 +16,7 @@
 // score table.  2-bit traces go to a per-task scratch slab; the traceback caches its trace word.
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 #define KB 16  // kbound
 
@@ -75,13 +76,16 @@ __device__ __forceinline__ int inc_if(int x, m64 bit) {  // x + bit
 // open); Bd = diagonal neighbour's score.  Publishes B, Iout (for the cell to the right),
 // Dout (for the cell below) and the two bits of the trace code  0 '*', 1 '\\', 2 '-', 3 '|'
 // (priority diag > left > up, fsearch.py:1404-1411) as masks t0 (bit 0) and t1 (bit 1).
+// EDGE = false: the caller knows the cell is valid in every active lane (band interior), `valid` is ignored.
+template <bool EDGE>
 __device__ __forceinline__ void dp_cell(m64 valid, int I, int D, int Bd, int s, int& B, int& Iout, int& Dout, m64& t0, m64& t1) {
     const int M = Bd + s;
     const int b0 = max(max(I, D), max(M, 0));
-    const m64 isM = __builtin_amdgcn_sicmp(b0, M, ICMP_EQ) & valid;
-    const m64 eI = __builtin_amdgcn_sicmp(b0, I, ICMP_EQ) & valid & ~isM;
-    const m64 eD = __builtin_amdgcn_sicmp(b0, D, ICMP_EQ) & valid & ~isM & ~eI;
-    const int b = sel0(b0, valid);
+    m64 isM = __builtin_amdgcn_sicmp(b0, M, ICMP_EQ), eI = __builtin_amdgcn_sicmp(b0, I, ICMP_EQ), eD = __builtin_amdgcn_sicmp(b0, D, ICMP_EQ);
+    if (EDGE) isM &= valid, eI &= valid, eD &= valid;
+    eI &= ~isM;
+    eD &= ~(isM | eI);
+    const int b = EDGE ? sel0(b0, valid) : b0;
     B = b;
     t0 = isM | eD;
     t1 = eI | eD;
@@ -131,9 +135,9 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     u32 tw = 0;
     u32 cc0 = 0;
     const int m_end = R + 15;
-    for (int m0 = 8; m0 <= m_end; m0 += 4) {
-        u32 rw = win4(rcls, m0 - l - 1, nrows);
-        u32 cw = win4(ccls, m0 + l - KB, ncols);
+    // four iterations; EDGE = false when every cell of every active lane is inside its band and matrix
+    auto four = [&](int m0, u32 rw, u32 cw, auto edge) {
+        constexpr bool EDGE = decltype(edge)::value;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int m = m0 + k;
@@ -142,17 +146,20 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
             const u32 rc = rw & 31u, cc1 = cw & 31u;
             rw >>= 8;
             cw >>= 8;
-            const m64 row_ok = __builtin_amdgcn_uicmp((u32)(i - 1), (u32)R, ICMP_ULT);
-            const m64 ve = row_ok & __builtin_amdgcn_uicmp((u32)(j0 - 1), (u32)ncols, ICMP_ULT);
-            const m64 vo = row_ok & __builtin_amdgcn_uicmp((u32)j0, (u32)ncols, ICMP_ULT);
+            m64 row_ok = ~0ull, ve = ~0ull, vo = ~0ull;
+            if (EDGE) {
+                row_ok = __builtin_amdgcn_uicmp((u32)(i - 1), (u32)R, ICMP_ULT);
+                ve = row_ok & __builtin_amdgcn_uicmp((u32)(j0 - 1), (u32)ncols, ICMP_ULT);
+                vo = row_ok & __builtin_amdgcn_uicmp((u32)j0, (u32)ncols, ICMP_ULT);
+            }
             const int s0 = s_b62[rc * 36u + cc0], s1 = s_b62[rc * 36u + cc1];
             cc0 = cc1;
             int nBe, Ie_out, De_out, nBo, nIo, nDo;
             m64 te0, te1, to0, to1;
-            dp_cell(ve, dpp_row_shr1(GO, Io_out), Do_out, Be, s0, nBe, Ie_out, De_out, te0, te1);
-            dp_cell(vo, Ie_out, dpp_row_shl1(GO, De_out), Bo, s1, nBo, nIo, nDo, to0, to1);
+            dp_cell<EDGE>(ve, dpp_row_shr1(GO, Io_out), Do_out, Be, s0, nBe, Ie_out, De_out, te0, te1);
+            dp_cell<EDGE>(vo, Ie_out, dpp_row_shl1(GO, De_out), Bo, s1, nBo, nIo, nDo, to0, to1);
             Be = nBe, Bo = nBo, Io_out = nIo, Do_out = nDo;
-            ncell = inc_if(inc_if(ncell, ve), vo);
+            if (EDGE) ncell = inc_if(inc_if(ncell, ve), vo);
             // first strict maximum in row-major order == largest (score, 8191 - i) key; keys of invalid cells are < any valid one
             const u32 rk = (u32)(8191 - i) & 8191u;
             keyE = max(keyE, ((u32)nBe << 13) | rk);
@@ -160,11 +167,19 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
             // the row's 4 trace bits (odd cell: bits 3-2, even cell: bits 1-0) are shifted into the trace word, one v_addc
             // per bit; rows outside [1, R] shift in zeros.  Row r of an 8-row word ends up in nibble 7 - (r & 7).
             tw = shl1_in(shl1_in(shl1_in(shl1_in(tw, to1), to0), te1), te0);
-            if ((u32)(i - 1) < (u32)R && ((((u32)(i - 1)) & 7u) == 7u || i == R)) {
+            if ((!EDGE || (u32)(i - 1) < (u32)R) && ((((u32)(i - 1)) & 7u) == 7u || i == R)) {
                 tr[((u32)(i - 1) >> 3) * 16u + (u32)l] = tw << ((7u - ((u32)(i - 1) & 7u)) << 2);  // left-align a partial last word
                 tw = 0;
             }
         }
+        if (!EDGE) ncell += 8;
+    };
+    const int int_hi = min(R, ncols) - 3;  // groups m0 in [17, int_hi] are interior for this alignment (all 16 lanes, all 4 steps)
+    for (int m0 = 8; m0 <= m_end; m0 += 4) {
+        const u32 rw = win4(rcls, m0 - l - 1, nrows);
+        const u32 cw = win4(ccls, m0 + l - KB, ncols);
+        if (__all(m0 >= 17 && m0 <= int_hi)) four(m0, rw, cw, std::false_type{});
+        else four(m0, rw, cw, std::true_type{});
     }
     // lane best: max score, then smallest i, then the even cell (smaller j)
     int best, bi, bj;
