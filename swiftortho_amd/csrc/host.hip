@@ -263,6 +263,8 @@ struct so_ctx {
         std::atomic<i64> dropped{0};
         std::exception_ptr err;
     } emit;
+    unsigned long long* h_qhits = nullptr;  // pinned: per-query hit counts of one (batch, chunk)
+    size_t h_qhits_cap = 0;
     unsigned long long* h_small = nullptr;  // pinned scratch for the small device -> host reads (counts, totals): 1 KB
     std::map<std::string, double> tm;  // per-stage wall ms (only with params.profile)
     std::shared_ptr<void> batch;       // persistent per-batch scratch (struct Batch)
@@ -809,8 +811,13 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     launch_cap(b.korder.p, b.dev.d_off.p, b.nq, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, c->st);
     // Split the batch into query sub-ranges whose seed hits fit the per-pass budget (keys, sort
     // scratch and group arrays are sized by it; 32-bit hit ordinals need < 2^32 per pass).
-    std::vector<unsigned long long> qh(b.nq);
-    HIP_CHECK(hipMemcpyAsync(qh.data(), b.qhits.p, (size_t)b.nq * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
+    if (c->h_qhits_cap < b.nq) {  // pinned: a pageable read of this array costs more than the kernels around it
+        if (c->h_qhits) (void)hipHostFree(c->h_qhits);
+        c->h_qhits_cap = (size_t)b.nq + 1024;
+        HIP_CHECK(hipHostMalloc((void**)&c->h_qhits, c->h_qhits_cap * sizeof(unsigned long long), hipHostMallocDefault));
+    }
+    unsigned long long* qh = c->h_qhits;
+    HIP_CHECK(hipMemcpyAsync(qh, b.qhits.p, (size_t)b.nq * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
     HIP_CHECK(hipStreamSynchronize(c->st));
     const unsigned long long budget = c->max_hits_per_pass;
     u32 qa = 0;
@@ -1422,6 +1429,7 @@ void so_destroy(so_ctx* c) {
     if (c->st) (void)hipStreamSynchronize(c->st);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->h_qhits) (void)hipHostFree(c->h_qhits);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->st) (void)hipStreamDestroy(c->st);

@@ -78,28 +78,35 @@ __global__ __launch_bounds__(256) void k_scls(const u8* __restrict__ res, size_t
 }
 
 // ---- SEG-like query masking (fsearch.py:2872-2928; entropy 2854-2868; Counter 157-177) ------------
-// One thread per query, sequential like the reference (the entropy is updated incrementally and
-// its rounding is order dependent).  All logarithms come from host tables of libm values
-// (lg12[k] = log(k / 12.), lgn[w][j] = log(j / w), log2v = log(2)), so the device only performs
-// IEEE fp64 multiply / subtract / divide / compare (the library is built with -ffp-contract=off)
-// and reproduces the reference's doubles bit for bit.  symmap folds the upper-cased byte to one
-// of <= 64 symbols; per-thread counters live in LDS.  Only output[:n] is produced (2996, 3034).
+// The reference slides a 12-residue window and updates the entropy incrementally,  ent += t(leaving) ; ent +=
+// t(entering),  so its rounding depends on the order of those additions -- but each addend depends only on the
+// window: the reference's per-symbol counter always equals (occurrences in the current window) + a per-symbol
+// constant (its Counter starts the first window at 2 * occ - 1 instead of occ).  One wave per query: the lanes
+// compute the two addends of up to SEG_TILE positions in parallel (counts by direct comparison over the 12
+// residues), then lane 0 replays the additions in order from LDS, then walks the mask into the output.
+// All logarithms come from host tables of libm values (lg12[k] = log(k / 12.), lgn[w][j] = log(j / w),
+// log2v = log(2)), so the device only performs IEEE fp64 multiply / subtract / divide / add / compare (the
+// library is built with -ffp-contract=off) and reproduces the reference's doubles bit for bit.  symmap folds
+// the upper-cased byte to one of <= 64 symbols.  Only output[:n] is produced (2996, 3034).
 struct SegTab {
     double lg12[64];
     double lgn[13][32];
     double log2v;
 };
+#define SEG_TILE 512
 
 __global__ __launch_bounds__(64) void k_seg(const u8* __restrict__ raw, const u32* __restrict__ src_off, u32 q_lo, u32 nq,
                                             const u32* __restrict__ dst_off, const u8* __restrict__ symmap /*256: upper-cased byte*/,
                                             const u8* __restrict__ upmap /*256*/, const SegTab* __restrict__ tab, u8* __restrict__ mk,
                                             u8* __restrict__ out) {
-    __shared__ u8 s_cnt[64][64];  // [symbol][thread]: conflict-free per-thread counters
     __shared__ u8 s_sym[256], s_up[256];
-    for (int i = threadIdx.x; i < 256; i += 64) s_sym[i] = symmap[i], s_up[i] = upmap[i];
-    for (int k = 0; k < 64; ++k) s_cnt[k][threadIdx.x] = 0;
+    __shared__ int s_off[64];  // reference counter - occurrences in the window, per symbol
+    __shared__ double s_t1[SEG_TILE], s_t2[SEG_TILE];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) s_sym[i] = symmap[i], s_up[i] = upmap[i];
+    s_off[lane] = 0;
     __syncthreads();
-    const u32 q = blockIdx.x * 64u + threadIdx.x;
+    const u32 q = blockIdx.x;
     if (q >= nq) return;
     const u8* S = raw + src_off[q_lo + q];
     const int n = (int)(src_off[q_lo + q + 1] - src_off[q_lo + q]);
@@ -107,58 +114,79 @@ __global__ __launch_bounds__(64) void k_seg(const u8* __restrict__ raw, const u3
     u8* m = mk + dst_off[q];
     if (n <= 0) return;
     const double minent = 2.2, window = 12.;
-    const int tx = threadIdx.x;
-#define CNT(c) s_cnt[c][tx]
+    const double log2v = tab->log2v;
     const int w = n < 12 ? n : 12;
-    for (int i = 0; i < w; ++i) {  // Counter(seq) + one more per char: 2 * occ - 1
-        const int c = s_sym[S[i]];
-        CNT(c) = CNT(c) == 0 ? 1 : CNT(c) + 2;
-    }
-    double ent = 0;
-    for (int i = 0; i < w; ++i) {  // values() in first-seen order
-        const int c = s_sym[S[i]];
-        bool first = true;
-        for (int k = 0; k < i; ++k) first = first && (s_sym[S[k]] != c);
-        if (!first) continue;
-        const int j = CNT(c);
-        const double freq = (double)j / ((double)w * 1.);
-        ent -= freq * tab->lgn[w][j];
-    }
-    ent /= tab->log2v;
-    int prev = ent < minent ? 1 : 0;
-    m[0] = (u8)prev;
-    for (int i = 1; i < n - 12 + 1; ++i) {
-        const int pre = s_sym[S[i - 1]], cur = s_sym[S[i + 11]];
-        if (pre == cur) {
-            m[i] = (u8)prev;
-            continue;
+    double ent = 0;  // lane 0 only
+    int prev = 0;
+    if (lane == 0) {
+        // first window: Counter(seq) then one more per char -> 2 * occ - 1 (157-177, 2876-2880); entropy over the
+        // distinct symbols in first-seen order (2854-2868)
+        int cnt[12], symv[12], nd = 0;
+        for (int i = 0; i < w; ++i) {
+            const int c = s_sym[S[i]];
+            int k = 0;
+            while (k < nd && symv[k] != c) ++k;
+            if (k == nd) symv[nd] = c, cnt[nd] = 1, ++nd;
+            else cnt[k] += 2;
         }
-        const int pre_count = CNT(pre);
-        CNT(pre) = pre_count - 1;
-        const int cur_count = CNT(cur);
-        CNT(cur) = cur_count + 1;
-        const int pre_after = pre_count - 1, cur_after = cur_count + 1;
-        double a = (double)pre_count / window, b = (double)pre_after / window, t;
-        if (pre_after != 0) {
-            t = (a * tab->lg12[pre_count] - b * tab->lg12[pre_after]) / tab->log2v;
-            if (t == 0) t = a * tab->lg12[pre_count] / tab->log2v;
-        } else {
-            t = a * tab->lg12[pre_count] / tab->log2v;
+        for (int k = 0; k < nd; ++k) {
+            const int j = cnt[k];
+            const double freq = (double)j / ((double)w * 1.);
+            ent -= freq * tab->lgn[w][j];
+            s_off[symv[k]] = j - (j + 1) / 2;  // occ = (j + 1) / 2
         }
-        ent += t;
-        a = (double)cur_count / window;
-        b = (double)cur_after / window;
-        if (cur_count != 0) {
-            t = (a * tab->lg12[cur_count] - b * tab->lg12[cur_after]) / tab->log2v;
-            if (t == 0) t = -b * tab->lg12[cur_after] / tab->log2v;
-        } else {
-            t = -b * tab->lg12[cur_after] / tab->log2v;
-        }
-        ent += t;
+        ent /= log2v;
         prev = ent < minent ? 1 : 0;
-        m[i] = (u8)prev;
+        m[0] = (u8)prev;
     }
-#undef CNT
+    __syncthreads();
+    const int last = n - 12;  // sliding steps i = 1 .. last
+    for (int i0 = 1; i0 <= last; i0 += SEG_TILE) {
+        const int cntp = min(SEG_TILE, last - i0 + 1);
+        // ---- the two addends of every step of the tile, all lanes ----
+        for (int r = lane; r < cntp; r += 64) {
+            const int i = i0 + r;
+            const int pre = s_sym[S[i - 1]], cur = s_sym[S[i + 11]];
+            double t1 = 0., t2 = 0.;  // pre == cur: the reference leaves ent alone; adding +0. twice does the same
+            if (pre != cur) {
+                int tp = 0, tc = 0;  // occurrences in the window before the step, S[i - 1 .. i + 10]
+                for (int k = -1; k < 11; ++k) {
+                    const int c = s_sym[S[i + k]];
+                    tp += (c == pre), tc += (c == cur);
+                }
+                const int pre_count = tp + s_off[pre], cur_count = tc + s_off[cur];
+                const int pre_after = pre_count - 1, cur_after = cur_count + 1;
+                double a = (double)pre_count / window, b = (double)pre_after / window;
+                if (pre_after != 0) {
+                    t1 = (a * tab->lg12[pre_count] - b * tab->lg12[pre_after]) / log2v;
+                    if (t1 == 0) t1 = a * tab->lg12[pre_count] / log2v;
+                } else {
+                    t1 = a * tab->lg12[pre_count] / log2v;
+                }
+                a = (double)cur_count / window;
+                b = (double)cur_after / window;
+                if (cur_count != 0) {
+                    t2 = (a * tab->lg12[cur_count] - b * tab->lg12[cur_after]) / log2v;
+                    if (t2 == 0) t2 = -b * tab->lg12[cur_after] / log2v;
+                } else {
+                    t2 = -b * tab->lg12[cur_after] / log2v;
+                }
+            }
+            s_t1[r] = t1, s_t2[r] = t2;
+        }
+        __syncthreads();
+        // ---- the additions, in the reference's order ----
+        if (lane == 0) {
+            for (int r = 0; r < cntp; ++r) {
+                ent += s_t1[r];
+                ent += s_t2[r];
+                prev = ent < minent ? 1 : 0;
+                m[i0 + r] = (u8)prev;
+            }
+        }
+        __syncthreads();
+    }
+    if (lane != 0) return;
     const int Nws = n - 12 > 0 ? n - 12 : 0;
     const int tail = m[Nws];  // if mask[Nws]: mask[Nws:] = 1 ; positions past n - 12 are otherwise 0
     int st = 0, oo = 0;
@@ -183,8 +211,7 @@ __global__ __launch_bounds__(256) void k_copy_range(const u8* __restrict__ src, 
 void launch_seg(const u8* raw, const u32* src_off, u32 q_lo, u32 nq, const u32* dst_off, const u8* symmap, const u8* upmap,
                 const void* tab, u8* mk, u8* out, hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_seg, dim3((nq + 63) / 64), dim3(64), 0, st, raw, src_off, q_lo, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk,
-                       out);
+    hipLaunchKernelGGL(k_seg, dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk, out);
 }
 
 void launch_copy_range(const u8* src, u8* dst, size_t n, hipStream_t st) {
