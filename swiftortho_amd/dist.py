@@ -26,27 +26,56 @@ def shard_queries(lengths, world, lo=0, hi=None):
     return [(bounds[r], bounds[r + 1]) for r in range(world)]
 
 
-def gather_bytes(payload, device=None, dst=0):
-    """Gather one bytes object per rank to rank `dst` (others get None).
+_pinned = {}  # reusable pinned staging tensors, keyed by role
 
-    all_gather of the sizes, then a padded gather of the payload (gatherv).  Hit records are tens
-    of bytes per reported row, so this is latency- not bandwidth-bound."""
+
+def _staging(role, nbytes, pin):
+    import torch
+    buf = _pinned.get(role)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 16) * 5 // 4, dtype=torch.uint8, pin_memory=pin)
+        _pinned[role] = buf
+    return buf
+
+
+def gather_records(view, device=None, dst=0):
+    """Gather one uint8 numpy array (the packed hit records of this rank) per rank to rank `dst`.
+
+    Returns a list of uint8 numpy arrays on `dst` (views into one pinned host buffer, valid until the next
+    call), None elsewhere.  One all_gather of the sizes, one padded gather (gatherv) over RCCL, one
+    device-to-host copy; staging buffers are pinned and reused."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
+    on_gpu = dist.get_backend() == "nccl"
     if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    n = torch.tensor([len(payload)], dtype=torch.int64, device=device)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
+        device = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    view = np.ascontiguousarray(view, dtype=np.uint8).reshape(-1)
+    n = int(view.nbytes)
+    sizes_t = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes_t, torch.tensor([n], dtype=torch.int64, device=device))
+    sizes = [int(x) for x in sizes_t.cpu().tolist()]
     mx = max(max(sizes), 1)
-    buf = torch.zeros(mx, dtype=torch.uint8, device=device)
-    if payload:
-        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+    send = _staging("send", mx, on_gpu)
+    if n:
+        send.numpy()[:n] = view
+    gsend = send[:mx].to(device, non_blocking=True) if on_gpu else send[:mx]
     if rank == dst:
-        out = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world)]
-        dist.gather(buf, out, dst=dst)
-        return [out[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world)]
-    dist.gather(buf, None, dst=dst)
+        recv = torch.empty(world * mx, dtype=torch.uint8, device=device)
+        dist.gather(gsend, [recv[r * mx:(r + 1) * mx] for r in range(world)], dst=dst)
+        if on_gpu:
+            host = _staging("recv", world * mx, True)
+            host[:world * mx].copy_(recv, non_blocking=True)
+            torch.cuda.synchronize()
+        else:
+            host = recv
+        h = host.numpy()
+        return [h[r * mx:r * mx + sizes[r]] for r in range(world)]
+    dist.gather(gsend, None, dst=dst)
     return None
+
+
+def gather_bytes(payload, device=None, dst=0):
+    """bytes in, list of bytes out on `dst` (copies; the bench and the CLI use gather_records)."""
+    parts = gather_records(np.frombuffer(payload, dtype=np.uint8) if payload else np.zeros(0, dtype=np.uint8), device, dst)
+    return None if parts is None else [p.tobytes() for p in parts]

@@ -166,6 +166,13 @@ class Hits:
             out.append(buf.raw[:k])
         return out
 
+    def view_u8(self):
+        """uint8 numpy view of the record buffer (no copy; valid until close())."""
+        if not self.n:
+            return np.zeros(0, dtype=np.uint8)
+        nbytes = self.n * C.sizeof(_lib.SoHit)
+        return np.frombuffer((C.c_char * nbytes).from_address(C.addressof(self.ptr.contents)), dtype=np.uint8)
+
     def raw_bytes(self):
         if not self.n:
             return b""
