@@ -56,10 +56,15 @@ using SegCfg = rocprim::segmented_radix_sort_config<BITS, rocprim::kernel_config
 // Long segments (weight-6 seeds: tens of thousands of keys per query) want the 8-bit / 256 x 16 instance; short ones
 // (weight-10 seeds: hundreds per query) are served better by the library default with its warp-sort size classes
 // (config 3: 2.7 ms vs 3.7 ms).
-static int seg_variant(size_t n, u32 nseg) {
+// Digit width: the field is bs + bd bits wide (24 on config 2, 27 with 50 k-sequence chunks); 9-bit digits with 512 x 8
+// keys cost the same per pass as 8-bit / 256 x 16 (3.96 vs 3.97 ms on config 2) and keep widths up to 27 at three passes.
+// (10-bit digits with 1024 x 4 keys: 5.3 ms per three passes -- no better than four 8-bit ones.)
+static int seg_variant(size_t n, u32 nseg, int width) {
     static const int v = getenv("SOHIT_SEG_CFG") ? atoi(getenv("SOHIT_SEG_CFG")) : -1;
     if (v >= 0) return v;
-    return (nseg && n / nseg >= 4096) ? 2 : 0;
+    if (!(nseg && n / nseg >= 4096)) return 0;
+    if (width > 24 && width <= 27) return 6;
+    return 2;
 }
 
 template <class Cfg>
@@ -70,11 +75,13 @@ static hipError_t seg_sort(void* temp, size_t& bytes, const u64* in, u64* out, s
 
 static hipError_t seg_sort_dispatch(void* temp, size_t& bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* sb, const u32* se,
                                     int b0, int b1, hipStream_t st) {
-    switch (seg_variant(n, nseg)) {
+    switch (seg_variant(n, nseg, b1 - b0)) {
         case 0: return seg_sort<rocprim::default_config>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
         case 1: return seg_sort<SegCfg<8>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
         case 4: return seg_sort<SegCfg<16, 512>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
         case 5: return seg_sort<SegCfg<8, 1024>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
+        case 6: return seg_sort<SegCfg<8, 512, 9>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
+        case 7: return seg_sort<SegCfg<4, 1024, 10>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
         default: return seg_sort<SegCfg<16>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
     }
 }

@@ -7,3 +7,5 @@ run SOHIT_SEG_CFG=1
 run SOHIT_SEG_CFG=2
 run SOHIT_SEG_CFG=4
 run SOHIT_SEG_CFG=5
+run SOHIT_SEG_CFG=6
+run SOHIT_SEG_CFG=7
