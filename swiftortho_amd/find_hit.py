@@ -90,8 +90,15 @@ def run_rank(p):
     from . import _lib, dist as sdist, fsearch
     import ctypes as C
     rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ.get('LOCAL_RANK', 0))
+    # SOHIT_BENCH_BACKEND=gloo + SOHIT_BENCH_ONE_GPU=1: functional test of the -a N flow on a 1-GPU box (as in bench.py)
+    backend = os.environ.get('SOHIT_BENCH_BACKEND', 'nccl')
+    if os.environ.get('SOHIT_BENCH_ONE_GPU'):
+        local = 0
     torch.cuda.set_device(local)
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     s = fsearch.Searcher(**searcher_kwargs(p, device=local))
     try:
         s.load_ref(p['ref'], p['rstart'], p['rend'])
