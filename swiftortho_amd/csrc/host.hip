@@ -968,8 +968,8 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     b.order.ensure((size_t)NS + 2), b.order2.ensure((size_t)NS + 2), b.tmp64.ensure((size_t)NS + 2);
     launch_iota(b.order.p, NS, c->st);
     if (ftbits + kl.bq <= 64) {
-        launch_combine_q_ft(b.c_q.p, b.c_ft.p, NS, ftbits, b.tmp64.p, c->st);
-        sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, b.order.p, b.order2.p, NS, ftbits + kl.bq, c->st);
+        launch_combine_q_ft(b.c_q.p, b.c_ft.p, NS, ftbits, bsp, b.tmp64.p, c->st);
+        sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, b.order.p, b.order2.p, NS, ftbits - bsp + 1 + kl.bq, c->st);
         std::swap(b.order.p, b.order2.p);
         std::swap(b.order.cap, b.order2.cap);
     } else {

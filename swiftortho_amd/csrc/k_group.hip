@@ -393,10 +393,17 @@ __global__ __launch_bounds__(256) void k_gather_u32_as_u64(const u32* __restrict
     if (i < n) dst[i] = src[idx[i]];
 }
 
-__global__ __launch_bounds__(256) void k_combine_q_ft(const u32* __restrict__ c_q, const u64* __restrict__ c_ft, u32 n, int ftbits,
+// Sort word of a candidate: (query, first-touch key) with the key's low `bsp` bits -- the inverted subject offset --
+// reduced to ONE bit.  Two candidates of one query are different subjects, so their keys can only agree down to
+// (as, qpos, j, tag) when one of them is the offset-0 quirk entry (attributed to j = subject + 1 with pos = 0, the
+// all-ones inverted offset) and the other a real entry of subject j (pos >= 1): the real one is visited first.
+// One radix pass fewer than sorting the full key.
+__global__ __launch_bounds__(256) void k_combine_q_ft(const u32* __restrict__ c_q, const u64* __restrict__ c_ft, u32 n, int ftbits, int bsp,
                                                       u64* __restrict__ dst) {
     const u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) dst[i] = ((u64)c_q[i] << ftbits) | c_ft[i];
+    if (i >= n) return;
+    const u64 ft = c_ft[i], pm = (1ull << bsp) - 1ull;
+    dst[i] = ((u64)c_q[i] << (ftbits - bsp + 1)) | ((ft >> bsp) << 1) | ((ft & pm) == pm ? 1ull : 0ull);
 }
 
 __global__ __launch_bounds__(256) void k_iota(u32* __restrict__ p, u32 n) {
@@ -474,9 +481,9 @@ void launch_gather_u32_as_u64(const u32* src, const u32* idx, u32 n, u64* dst, h
     hipLaunchKernelGGL(k_gather_u32_as_u64, dim3((n + 255) / 256), dim3(256), 0, st, src, idx, n, dst);
 }
 
-void launch_combine_q_ft(const u32* c_q, const u64* c_ft, u32 n, int ftbits, u64* dst, hipStream_t st) {
+void launch_combine_q_ft(const u32* c_q, const u64* c_ft, u32 n, int ftbits, int bsp, u64* dst, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_combine_q_ft, dim3((n + 255) / 256), dim3(256), 0, st, c_q, c_ft, n, ftbits, dst);
+    hipLaunchKernelGGL(k_combine_q_ft, dim3((n + 255) / 256), dim3(256), 0, st, c_q, c_ft, n, ftbits, bsp, dst);
 }
 
 void launch_iota(u32* p, u32 n, hipStream_t st) {
