@@ -38,10 +38,28 @@ def _staging(role, nbytes, pin):
     return buf
 
 
+class Gathered:
+    """Result of gather_records on the destination rank: `sizes` (bytes per rank) is available at once, the
+    records themselves after the device-to-host copy has finished (`arrays()` waits for it), so a caller that
+    pipelines -- bench.py -- lets that copy run under its next step."""
+
+    def __init__(self, host, sizes, mx, event):
+        self._host, self.sizes, self._mx, self._event = host, sizes, mx, event
+
+    def arrays(self):
+        if self._event is not None:
+            self._event.synchronize()
+        h = self._host.numpy()
+        return [h[r * self._mx:r * self._mx + n] for r, n in enumerate(self.sizes)]
+
+
+_send_done = [None]  # event after the last host-to-device copy out of the pinned send buffer
+
+
 def gather_records(view, device=None, dst=0):
     """Gather one uint8 numpy array (the packed hit records of this rank) per rank to rank `dst`.
 
-    Returns a list of uint8 numpy arrays on `dst` (views into one pinned host buffer, valid until the next
+    Returns a `Gathered` on `dst` (its arrays are views into one pinned host buffer, valid until the next
     call), None elsewhere.  One all_gather of the sizes, one padded gather (gatherv) over RCCL, one
     device-to-host copy; staging buffers are pinned and reused."""
     import torch
@@ -57,25 +75,33 @@ def gather_records(view, device=None, dst=0):
     sizes = [int(x) for x in sizes_t.cpu().tolist()]
     mx = max(max(sizes), 1)
     send = _staging("send", mx, on_gpu)
+    if on_gpu and _send_done[0] is not None:
+        _send_done[0].synchronize()  # the previous call's copy out of this buffer
     if n:
         send.numpy()[:n] = view
-    gsend = send[:mx].to(device, non_blocking=True) if on_gpu else send[:mx]
+    if on_gpu:
+        gsend = send[:mx].to(device, non_blocking=True)
+        _send_done[0] = torch.cuda.Event()
+        _send_done[0].record()
+    else:
+        gsend = send[:mx]
     if rank == dst:
         recv = torch.empty(world * mx, dtype=torch.uint8, device=device)
         dist.gather(gsend, [recv[r * mx:(r + 1) * mx] for r in range(world)], dst=dst)
+        event = None
         if on_gpu:
             host = _staging("recv", world * mx, True)
             host[:world * mx].copy_(recv, non_blocking=True)
-            torch.cuda.synchronize()
+            event = torch.cuda.Event()
+            event.record()
         else:
             host = recv
-        h = host.numpy()
-        return [h[r * mx:r * mx + sizes[r]] for r in range(world)]
+        return Gathered(host, sizes, mx, event)
     dist.gather(gsend, None, dst=dst)
     return None
 
 
 def gather_bytes(payload, device=None, dst=0):
     """bytes in, list of bytes out on `dst` (copies; the bench and the CLI use gather_records)."""
-    parts = gather_records(np.frombuffer(payload, dtype=np.uint8) if payload else np.zeros(0, dtype=np.uint8), device, dst)
-    return None if parts is None else [p.tobytes() for p in parts]
+    g = gather_records(np.frombuffer(payload, dtype=np.uint8) if payload else np.zeros(0, dtype=np.uint8), device, dst)
+    return None if g is None else [p.tobytes() for p in g.arrays()]

@@ -110,10 +110,10 @@ def run_rank(p):
         lo, hi = sdist.shard_queries(lens, world, st, ed)[rank]
         hits = s.search(lo, hi) if hi > lo else None
         import numpy as np
-        parts = sdist.gather_records(hits.view_u8() if hits is not None else np.zeros(0, dtype=np.uint8))
+        g = sdist.gather_records(hits.view_u8() if hits is not None else np.zeros(0, dtype=np.uint8))
         if rank == 0:
             # ranks hold contiguous ascending query ranges: writing their blocks in rank order keeps the file order
-            for r, part in enumerate(parts):
+            for r, part in enumerate(g.arrays()):
                 n = len(part) // C.sizeof(_lib.SoHit)
                 arr = (_lib.SoHit * max(n, 1)).from_buffer_copy(part.tobytes() + b'\0' * (C.sizeof(_lib.SoHit) if n == 0 else 0))
                 s._chk(s.L.so_write_sc(s.h, arr, n, os.fsencode(p['outfile']), b'w' if r == 0 else b'a'))
