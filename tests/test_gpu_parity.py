@@ -252,6 +252,54 @@ def test_wide_addends_and_device_wide_sort_paths(fs, oracle, tmp_path, monkeypat
     oracle_vs_gpu(fs, oracle, synthprot.synthprot(1300, 200, 86), kw, tmp_path)
 
 
+def test_very_long_sequences_40k(fs, oracle, tmp_path):
+    """40 000-residue proteins (ten 4096-tiles per alignment, 16-bit position fields, SEG tiles) and a
+    low-complexity repeat next to ordinary sequences"""
+    from swiftortho_amd import synthprot
+    rng = np.random.default_rng(3)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+
+    def rnd(n):
+        return aa[rng.integers(0, 20, n)].tobytes().decode()
+
+    def mut(s, d):
+        b = np.frombuffer(s.encode(), dtype=np.uint8).copy()
+        m = rng.random(len(b)) < d
+        b[m] = aa[rng.integers(0, 20, int(m.sum()))]
+        return b.tobytes().decode()
+
+    A = rnd(40000)
+    recs = [("T0", A), ("T1", mut(A[1000:39000], 0.2)), ("T2", mut(A[20000:33000], 0.1)), ("S0", mut(A[35000:35400], 0.1)),
+            ("R", "MKV" * 700)]
+    fa = "".join(">%s\n%s\n" % r for r in recs).encode() + synthprot.synthprot(300, 250, 9)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_randomised_differential(fs, oracle, tmp_path, monkeypatch, seed):
+    """random workload shapes x flag combinations (the generator of tools/diag/fuzz_parity.py, three draws per seed)"""
+    from swiftortho_amd import synthprot
+    rng = np.random.default_rng(seed)
+    alphas = [oracle.AA9, oracle.AA9 + "/A,KR,EDNQ,C,G,H,ILVM,FYW,P,ST", "A,C,D,E,F,G,H,I,K,L,M,N,P,Q,R,S,T,V,W,Y"]
+    seeds = ["111111", "1101011", "111111,1101011", "11111011111", "1110111", "11011"]
+    for _ in range(3):
+        N, L = int(rng.integers(150, 1200)), int(rng.integers(40, 420))
+        gen = synthprot.uniform_proteins if rng.random() < 0.25 else synthprot.synthprot
+        fa = gen(N, L, int(rng.integers(1, 1 << 30)))
+        kw = dict(ssd=str(rng.choice(seeds)), nr=str(rng.choice(alphas)), ht=int(rng.choice([50021, 1000003, 15000017, 120000000])),
+                  chk=int(rng.choice([50000, N // 3 + 1, 97])), step=int(rng.choice([1, 1, 2, 4])), v=int(rng.choice([500, 50, 5, 1200])),
+                  expect=float(rng.choice([1e-5, 1e-3, 10.0])), flt=str(rng.choice(["T", "T", "F"])), thr=int(rng.choice([-1, -1, 3, 40])),
+                  max_miss=float(rng.choice([1e-3, 0.5])))
+        if kw["nr"].count(",") > 15 and kw["ssd"] == "11011":
+            kw["ssd"] = "1111111"  # weight-4 seeds on 20 letters: hit lists too long for the CPU oracle
+        lo = int(rng.integers(0, N // 2))
+        hi = int(min(N, lo + rng.integers(20, 100)))
+        monkeypatch.setenv("SOHIT_BATCH", str(int(rng.choice([16384, 37]))))
+        monkeypatch.setenv("SOHIT_MAX_HITS", str(int(rng.choice([1 << 30, 50000]))))
+        oracle_vs_gpu(fs, oracle, fa, kw, tmp_path, sub=(lo, hi))
+
+
 def test_exact_threshold_replay(fs, oracle, monkeypatch):
     """the rare exact get_mu_sd replay path gives the same threshold as the integer-sum path"""
     from swiftortho_amd import synthprot
