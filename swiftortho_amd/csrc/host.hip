@@ -640,7 +640,7 @@ struct Batch {
     DevBuf<u32> qbucket, korder, sbeg, scnt, pcnt, eff, nz, hoff, cidx;
     DevBuf<int> ksc;
     DevBuf<u8> mark;
-    DevBuf<u32> cs_hoff, cs_beg, blk_first, qseg;
+    DevBuf<u32> cs_hoff, cs_beg, blk_first, qseg, sel_idx;
     DevBuf<unsigned long long> qhits;
     DevBuf<u64> cs_kbase;
     DevBuf<u64> keys, keys2;
@@ -1135,13 +1135,10 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         if (RR == 0) break;
         if (NR) {
             launch_round_idx(b.tcnt.p, b.roff.p, b.toff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.st_state.p, nq, b.ridx.p, c->st);
-            b.trace.ensure((size_t)std::min(slab, NR) * stride + 64);
+            // score-only: the stop rule needs the maximum alone; the reported rows are traced in a second pass below
             ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
-            for (u32 t = 0; t < NR; t += slab) {
-                const u32 n = std::min(slab, NR - t);
-                launch_align(b.tasks.p, b.ridx.p + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
-                             c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, b.ares.p, c->st);
-            }
+            launch_align(b.tasks.p, b.ridx.p, NR, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p, c->ref.d_off.p,
+                         c->d_b62c.p, nullptr, stride, b.ares.p, false, c->st);
             pt.stop();
         }
         launch_stop_round(b.tasks.p, b.ares.p, b.qcoff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.toff.p, b.rcnt.p, nq,
@@ -1159,6 +1156,20 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     const u32 NO = d2h_u32(c, dNO);
     sc.lap("phase2.stop");
     if (NO) {
+        // second aligner pass, with traces + traceback, over the rows that are reported (a few percent of the alignments)
+        b.sel_idx.ensure((size_t)NO + 4);
+        launch_selected_idx(b.toff.p, b.sel.p, b.nout.p, b.ooff.p, nq, b.sel_idx.p, c->st);
+        b.trace.ensure((size_t)std::min(slab, NO) * stride + 64);
+        {
+            ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
+            for (u32 t = 0; t < NO; t += slab) {
+                const u32 n = std::min(slab, NO - t);
+                launch_align(b.tasks.p, b.sel_idx.p + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
+                             c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, b.ares.p, true, c->st);
+            }
+            pt.stop();
+        }
+        sc.lap("phase2.trace_pass");
         b.outrec.ensure(12 * (size_t)NO + 16);
         launch_emit_hits(b.tasks.p, b.ares.p, b.toff.p, b.sel.p, b.nout.p, b.ooff.p, b.bits.p, nq, b.outrec.p, c->st);
         emit_join(c, out);  // the previous batch's job reads the staging buffer and writes into `out`

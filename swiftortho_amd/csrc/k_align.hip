@@ -94,6 +94,9 @@ __device__ __forceinline__ void dp_cell(m64 valid, int I, int D, int Bd, int s, 
 }
 
 // trace codes: 0 '*' (stop), 1 '\\' (diag), 2 '-' (left), 3 '|' (up)
+// TRACE = false: score-only run (maximum and its cell): the early-stop rule (k_stop_round) needs nothing else, and only the
+// few alignments that end up reported are run again with TRACE = true for the traceback.
+template <bool TRACE>
 __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 ntasks,
                                                const u8* __restrict__ q_res, const u8* __restrict__ q_scls,
                                                const u32* __restrict__ qoff, const u8* __restrict__ r_res,
@@ -166,10 +169,12 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
             keyO = max(keyO, ((u32)nBo << 13) | rk);
             // the row's 4 trace bits (odd cell: bits 3-2, even cell: bits 1-0) are shifted into the trace word, one v_addc
             // per bit; rows outside [1, R] shift in zeros.  Row r of an 8-row word ends up in nibble 7 - (r & 7).
-            tw = shl1_in(shl1_in(shl1_in(shl1_in(tw, to1), to0), te1), te0);
-            if ((!EDGE || (u32)(i - 1) < (u32)R) && ((((u32)(i - 1)) & 7u) == 7u || i == R)) {
-                tr[((u32)(i - 1) >> 3) * 16u + (u32)l] = tw << ((7u - ((u32)(i - 1) & 7u)) << 2);  // left-align a partial last word
-                tw = 0;
+            if (TRACE) {
+                tw = shl1_in(shl1_in(shl1_in(shl1_in(tw, to1), to0), te1), te0);
+                if ((!EDGE || (u32)(i - 1) < (u32)R) && ((((u32)(i - 1)) & 7u) == 7u || i == R)) {
+                    tr[((u32)(i - 1) >> 3) * 16u + (u32)l] = tw << ((7u - ((u32)(i - 1) & 7u)) << 2);  // left-align a partial last word
+                    tw = 0;
+                }
             }
         }
         if (!EDGE) ncell += 8;
@@ -275,11 +280,17 @@ u32 align_trace_stride(int max_cols_plus) {
     return (w + 31u) & ~31u;
 }
 
+// with_traceback = false: scores only (trace may be null); true: traces + traceback statistics
 void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u32* qoff, const u8* r_res,
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, AlnRes* out,
-                  hipStream_t st) {
+                  bool with_traceback, hipStream_t st) {
     if (!ntasks) return;
-    hipLaunchKernelGGL(k_align, dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_res, q_scls, qoff, r_res, r_scls, roff,
+    if (!with_traceback) {
+        hipLaunchKernelGGL((k_align<false>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_res, q_scls, qoff, r_res, r_scls,
+                           roff, b62g, trace, trace_stride, out);
+        return;
+    }
+    hipLaunchKernelGGL((k_align<true>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_res, q_scls, qoff, r_res, r_scls, roff,
                        b62g, trace, trace_stride, out);
     hipLaunchKernelGGL(k_traceback, dim3((ntasks + 63) / 64), dim3(64), 0, st, tasks, ridx, ntasks, q_res, qoff, r_res, roff, trace,
                        trace_stride, out);

@@ -278,6 +278,15 @@ __global__ __launch_bounds__(64) void k_final_select(const u32* __restrict__ tof
 }
 
 // final records: 12 x i32 per reported row
+// task slots of the rows that will be reported (the traced second aligner pass runs on these only)
+__global__ __launch_bounds__(64) void k_selected_idx(const u32* __restrict__ toff, const u32* __restrict__ sel, const u32* __restrict__ nout,
+                                                     const u32* __restrict__ ooff, u32 nq, u32* __restrict__ idx) {
+    const u32 q = blockIdx.x * 64u + threadIdx.x;
+    if (q >= nq) return;
+    const u32 t0 = toff[q], no = nout[q], o0 = ooff[q];
+    for (u32 k = 0; k < no; ++k) idx[o0 + k] = t0 + sel[t0 + k];
+}
+
 __global__ __launch_bounds__(64) void k_emit_hits(const AlnTask* __restrict__ tasks, const AlnRes* __restrict__ res,
                                                   const u32* __restrict__ toff, const u32* __restrict__ sel, const u32* __restrict__ nout,
                                                   const u32* __restrict__ ooff, const int* __restrict__ bits, u32 nq,
@@ -361,6 +370,11 @@ void launch_stop_round(const AlnTask* tasks, const AlnRes* res, const u32* qcoff
 void launch_final_select(const u32* toff, u32 nq, i64 v, u32* sel, const u32* st_state, const int* bits, u32* nout, hipStream_t st) {
     if (!nq) return;
     hipLaunchKernelGGL(k_final_select, dim3((nq + 63) / 64), dim3(64), 0, st, toff, nq, v, sel, st_state, bits, nout);
+}
+
+void launch_selected_idx(const u32* toff, const u32* sel, const u32* nout, const u32* ooff, u32 nq, u32* idx, hipStream_t st) {
+    if (!nq) return;
+    hipLaunchKernelGGL(k_selected_idx, dim3((nq + 63) / 64), dim3(64), 0, st, toff, sel, nout, ooff, nq, idx);
 }
 
 void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, const u32* sel, const u32* nout, const u32* ooff,

@@ -81,7 +81,7 @@ void launch_emit_cands(const u32* order, u32 n, const u32* c_q, const u32* c_rec
 // k_align.hip
 u32 align_trace_stride(int max_rows);
 void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u32* qoff, const u8* r_res,
-                  const u8* r_scls, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, AlnRes* out,
+                  const u8* r_scls, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, AlnRes* out, bool with_traceback,
                   hipStream_t st);
 
 // k_phase2.hip
@@ -103,6 +103,7 @@ void launch_stop_round(const AlnTask* tasks, const AlnRes* res, const u32* qcoff
                        const int* bittab, int bittab_n, i64 D, double expect, double max_miss, i64 v, u32* sel, u32* st_state, int* bits,
                        hipStream_t st);
 void launch_final_select(const u32* toff, u32 nq, i64 v, u32* sel, const u32* st_state, const int* bits, u32* nout, hipStream_t st);
+void launch_selected_idx(const u32* toff, const u32* sel, const u32* nout, const u32* ooff, u32 nq, u32* idx, hipStream_t st);
 void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, const u32* sel, const u32* nout, const u32* ooff,
                       const int* bits, u32 nq, int* out, hipStream_t st);
 void launch_sum_cells(const AlnRes* res, u32 n, unsigned long long* total, hipStream_t st);
