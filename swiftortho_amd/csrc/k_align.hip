@@ -164,9 +164,13 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
             Be = nBe, Bo = nBo, Io_out = nIo, Do_out = nDo;
             if (EDGE) ncell = inc_if(inc_if(ncell, ve), vo);
             // first strict maximum in row-major order == largest (score, 8191 - i) key; keys of invalid cells are < any valid one
-            const u32 rk = (u32)(8191 - i) & 8191u;
-            keyE = max(keyE, ((u32)nBe << 13) | rk);
-            keyO = max(keyO, ((u32)nBo << 13) | rk);
+            if (TRACE) {
+                const u32 rk = (u32)(8191 - i) & 8191u;
+                keyE = max(keyE, ((u32)nBe << 13) | rk);
+                keyO = max(keyO, ((u32)nBo << 13) | rk);
+            } else {  // score-only: the position of the maximum is not needed
+                keyE = max(keyE, max((u32)nBe, (u32)nBo));
+            }
             // the row's 4 trace bits (odd cell: bits 3-2, even cell: bits 1-0) are shifted into the trace word, one v_addc
             // per bit; rows outside [1, R] shift in zeros.  Row r of an 8-row word ends up in nibble 7 - (r & 7).
             if (TRACE) {
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     // lane best: max score, then smallest i, then the even cell (smaller j)
     int best, bi, bj;
     {
-        const int sE = (int)(keyE >> 13), sO = (int)(keyO >> 13);
+        const int sE = TRACE ? (int)(keyE >> 13) : (int)keyE, sO = TRACE ? (int)(keyO >> 13) : 0;
         const int iE = 8191 - (int)(keyE & 8191u), iO = 8191 - (int)(keyO & 8191u);
         const bool takeO = (sO > sE) || (sO == sE && iO < iE);
         best = takeO ? sO : sE;
