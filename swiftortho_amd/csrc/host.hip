@@ -687,7 +687,7 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
         if (c->filter) {
             c->d_segmask.ensure(nres_b + 64);
             launch_seg(c->qry.d_res.p, c->qry.d_off.p, (u32)q_lo, b.nq, b.dev.d_off.p, c->d_symmap.p, c->d_upmap.p, c->d_segtab.p,
-                       c->d_segmask.p, b.dev.d_res.p, c->st);
+                       c->d_segmask.p, b.dev.d_res.p, b.maxqlen, c->st);
         } else {
             launch_copy_range(c->qry.d_res.p + Q.off[q_lo], b.dev.d_res.p, nres_b, c->st);
         }

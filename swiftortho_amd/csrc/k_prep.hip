@@ -94,25 +94,37 @@ struct SegTab {
     double log2v;
 };
 #define SEG_TILE 512
+#define SEG_STAGE_MAX 4096  // queries up to this length keep their residues and mask in LDS (STAGE = true)
 
+// STAGE: the sequential parts (addition replay, output walk) are chains of dependent loads; from LDS a step costs
+// ~100 cycles, from global memory ~600.
+template <bool STAGE>
 __global__ __launch_bounds__(64) void k_seg(const u8* __restrict__ raw, const u32* __restrict__ src_off, u32 q_lo, u32 nq,
                                             const u32* __restrict__ dst_off, const u8* __restrict__ symmap /*256: upper-cased byte*/,
                                             const u8* __restrict__ upmap /*256*/, const SegTab* __restrict__ tab, u8* __restrict__ mk,
-                                            u8* __restrict__ out) {
+                                            u8* __restrict__ out, int min_len /*this instance serves lengths > min_len*/) {
     __shared__ u8 s_sym[256], s_up[256];
     __shared__ int s_off[64];  // reference counter - occurrences in the window, per symbol
     __shared__ double s_t1[SEG_TILE], s_t2[SEG_TILE];
+    __shared__ u8 s_S[STAGE ? SEG_STAGE_MAX : 4], s_m[STAGE ? SEG_STAGE_MAX : 4];
     const int lane = threadIdx.x;
     for (int i = lane; i < 256; i += 64) s_sym[i] = symmap[i], s_up[i] = upmap[i];
     s_off[lane] = 0;
     __syncthreads();
     const u32 q = blockIdx.x;
     if (q >= nq) return;
-    const u8* S = raw + src_off[q_lo + q];
+    const u8* Sg = raw + src_off[q_lo + q];
     const int n = (int)(src_off[q_lo + q + 1] - src_off[q_lo + q]);
     u8* o = out + dst_off[q];
-    u8* m = mk + dst_off[q];
+    u8* mg = mk + dst_off[q];
     if (n <= 0) return;
+    if ((STAGE && n > SEG_STAGE_MAX) || n <= min_len) return;  // the host launches the unstaged instance for longer queries
+    if (STAGE) {
+        for (int i = lane; i < n; i += 64) s_S[i] = Sg[i];
+        __syncthreads();
+    }
+    const u8* S = STAGE ? s_S : Sg;
+    u8* m = STAGE ? s_m : mg;
     const double minent = 2.2, window = 12.;
     const double log2v = tab->log2v;
     const int w = n < 12 ? n : 12;
@@ -209,9 +221,12 @@ __global__ __launch_bounds__(256) void k_copy_range(const u8* __restrict__ src, 
 }
 
 void launch_seg(const u8* raw, const u32* src_off, u32 q_lo, u32 nq, const u32* dst_off, const u8* symmap, const u8* upmap,
-                const void* tab, u8* mk, u8* out, hipStream_t st) {
+                const void* tab, u8* mk, u8* out, u32 max_len, hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_seg, dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk, out);
+    hipLaunchKernelGGL((k_seg<true>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk, out, 0);
+    if (max_len > SEG_STAGE_MAX)
+        hipLaunchKernelGGL((k_seg<false>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk, out,
+                           SEG_STAGE_MAX);
 }
 
 void launch_copy_range(const u8* src, u8* dst, size_t n, hipStream_t st) {

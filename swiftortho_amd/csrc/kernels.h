@@ -25,7 +25,7 @@ void launch_layout(const u8* res, const u32* off, u32 nseq, u32 P, u32 Ppad, con
                    hipStream_t st);
 void launch_scls(const u8* res, size_t n, const u8* smap, u8* scls, u8* scls4 /*nullable: class * 4*/, hipStream_t st);
 void launch_seg(const u8* raw, const u32* src_off, u32 q_lo, u32 nq, const u32* dst_off, const u8* symmap, const u8* upmap,
-                const void* tab /*SegTab on the device*/, u8* mk, u8* out, hipStream_t st);
+                const void* tab /*SegTab on the device*/, u8* mk, u8* out, u32 max_len, hipStream_t st);
 void launch_copy_range(const u8* src, u8* dst, size_t n, hipStream_t st);
 
 // k_index.hip
