@@ -863,6 +863,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     kl.finish();
     const int bsp = ceil_log2((u64)ch.maxslen + 1);
     const int ft_bits_entry = (kl.bs + 1) + kl.ba + bsp;
+    const bool ft_walk = AS > 1;  // several (alphabet, pattern) combinations: a group's first-touch key needs all its hits
     if (kl.total > 64) throw SoError("sort key needs " + std::to_string(kl.total) + " bits (> 64): lower SOHIT_BATCH or -c");
     if (kl.ba + kl.bp + ft_bits_entry > 64) throw SoError("first-touch key exceeds 64 bits: sequences too long for this build");
     b.cs_hoff.ensure((size_t)K + 2), b.cs_beg.ensure((size_t)K + 2), b.cs_kbase.ensure((size_t)K + 2);
@@ -921,7 +922,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     b.stepshard.ensure(UG_SHARDS);
     HIP_CHECK(hipMemsetAsync(b.shard.p, 0, (2 * UG_SHARDS + 8) * sizeof(u32), c->st));
     HIP_CHECK(hipMemsetAsync(b.stepshard.p, 0, UG_SHARDS * sizeof(unsigned long long), c->st));
-    launch_ungap(b.keys2.p, H, kl, ft_bits_entry, bsp, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo,
+    launch_ungap(b.keys2.p, H, kl, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo,
                  c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
     // contiguous pass list; the group counters and the pass total come back in one synchronisation
     u32* shard_off = b.shard.p + UG_SHARDS;
@@ -944,6 +945,8 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         launch_compact_shards(b.shard.p, shard_off, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.q_qs.p, b.q_sd.p, b.q_ft.p, c->st);
         q_qs = b.q_qs.p, q_sd = b.q_sd.p, q_ft = b.q_ft.p;
     }
+    // first-touch keys of the passing groups (k_ungap left the head hit's key / position in the third array)
+    if (NP) launch_first_touch(ft_walk, b.keys2.p, H, kl, ft_bits_entry, bsp, c->ref.d_off.p + ch.seq_lo, const_cast<u64*>(q_ft), NP, c->st);
     if (NP == 0) {
         c->cnt.seed_ms += (t1 - t0) * 1e3;
         c->cnt.group_ms += (wall() - t1) * 1e3;

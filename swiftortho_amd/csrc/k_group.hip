@@ -35,7 +35,7 @@ __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global
 // (group fetch, hit walk) runs only when enough lanes wait for it.  Passing groups (score >= 25) are
 // buffered in LDS and flushed to one of UG_SHARDS regions with ONE atomic per flush (wave-ballot
 // compaction inside the wave).   p_qs = (q << bs) | subject_local, p_sd = (score << 32) | (u32)dist,
-// p_ft = first-touch key.
+// p_ft = the head hit's key (or its position when ft_walk): k_first_touch turns it into the first-touch key.
 #define UW_WAVES 4
 #define UW_RANGE 4096   // head positions owned by one wave
 #define UW_QCAP 128     // group-head ring (u32 hit indices)
@@ -45,7 +45,7 @@ __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global
 
 enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN = 5 };
 
-__global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restrict__ keys, u32 H, KeyLayout kl, int ft_bits_entry, int bsp,
+__global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restrict__ keys, u32 H, KeyLayout kl, int ft_walk,
                                                          const u8* __restrict__ q_scls, const u32* __restrict__ qoff,
                                                          const u8* __restrict__ r_scls,
                                                          const u32* __restrict__ roff /*chunk-local offsets (absolute values)*/,
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
     const unsigned long long lt = (1ull << lane) - 1ull;
     const u64 kmask = (kl.total >= 64) ? ~0ull : ((1ull << kl.total) - 1ull);
     const u64 qall = (1ull << kl.bq) - 1ull;
-    const u64 pmask = (1ull << kl.bp) - 1ull, amask = (1ull << kl.ba) - 1ull;
+    const u64 pmask = (1ull << kl.bp) - 1ull;
     const u32 shard = blockIdx.x & (UG_SHARDS - 1);
 
     // wave-uniform bookkeeping
@@ -97,7 +97,8 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
     int ql = 0, sl = 0;
     int prev_qpos = -1, scores = 0, x0 = 0, y0 = 0, x = 0, y = 0;
     bool first = true, single = false, havekey = false;
-    u64 ft = ~0ull, hkey = 0;
+    u64 hkey = 0;  // the head hit's key
+    u32 h0 = 0;    // the head hit's position (ft_walk mode)
     u32 cq = 0xFFFFFFFFu, cqb = 0;  // last query looked up (groups arrive sorted by query)
     int cql = 0;
     int Qst = 0, Sst = 0, qlo = 0, slo = 0, ci = 0, cn = 0, score8 = 0 /*running score x 256*/, mp = 255 /*packed running maximum*/, best = -1, r_qed = 0, r_sed = 0;
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                         const u32 qe = s_queue[(qfront + r) & (UW_QCAP - 1)];
                         const u64 k0 = s_qkey[(qfront + r) & (UW_QCAP - 1)];
                         h = qe & 0x7FFFFFFFu;
+                        h0 = h;
                         single = (qe >> 31) != 0;
                         hkey = k0, havekey = true;
                         gpre = k0 >> kl.sh_diag;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                         qb = cqb, ql = cql;
                         sb = roff[gsubj];
                         sl = (int)(roff[gsubj + 1] - sb);
-                        prev_qpos = -1, scores = 0, x0 = y0 = x = y = 0, first = true, ft = ~0ull;
+                        prev_qpos = -1, scores = 0, x0 = y0 = x = y = 0, first = true;
                         phase = PH_HIT;
                     } else if (cur >= b0) {
                         phase = PH_DONE;  // nothing left to hand out
@@ -180,18 +182,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                     fin = true;
                 } else {
                     const int qpos = (int)((k >> kl.sh_qpos) & pmask);
-                    const u32 as = kl.ba ? (u32)((k >> kl.sh_as) & amask) : 0u;
-                    const u32 tag = kl.ba ? (u32)(k & amask) : 0u;
                     const int sst = (int)((i64)qpos - gdiag);
-                    {  // first-touch key: emission order (as, qpos), then index slot order == descending (j, tag, pos)
-                        u32 j = gsubj, pos = (u32)sst;
-                        if (sst == sl) j = gsubj + 1, pos = 0;  // offset-0 entry of the next chunk sequence
-                        const u64 jmax = (1ull << (kl.bs + 1)) - 1ull, tmax = amask, pmax = (1ull << bsp) - 1ull;
-                        const u64 inv = ((jmax - j) << (kl.ba + bsp)) | ((tmax - tag) << bsp) | (pmax - pos);
-                        const u64 emit = ((u64)as << kl.bp) | (u64)qpos;
-                        const u64 f = (emit << ft_bits_entry) | inv;
-                        ft = f < ft ? f : ft;
-                    }
                     if (qpos == prev_qpos) {
                         ++h;  // duplicate (qst, sst) pair: dropped by lis()
                     } else {
@@ -304,7 +295,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                     const u32 i = npb + (u32)__popcll(pb & lt);
                     s_pqs[i] = ((u64)gq << kl.bs) | gsubj;
                     s_psd[i] = ((u64)(u32)scores << 32) | (u64)(u32)dist;
-                    s_pft[i] = ft;
+                    s_pft[i] = ft_walk ? (u64)h0 : hkey;  // k_first_touch turns this into the first-touch key
                 }
                 npb += np;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -323,6 +314,53 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
         }
     }
     if (lane == 0 && ngroups) atomicAdd(&group_count[shard], (unsigned long long)ngroups);
+}
+
+// ---- first-touch keys of the passing groups ----------------------------------------------------------
+// Group visiting order, "first best diagonal wins" and the candidate order are functions of the minimum, over a
+// group's hits, of (emission order (as, qpos), then index slot order == descending (j, tag, pos)).  Only the passing
+// groups (a few percent) need it, so it is computed here, one thread per pass record, instead of inside the extension
+// kernel for every hit.  With one alphabet x one seed pattern (as == 0 everywhere) the minimum is the head hit's (the
+// hits of a group are ordered by query position) and the record carries that key; otherwise (WALK) it carries the
+// head's position and the group's hits are read back from the sorted key array.
+template <bool WALK>
+__global__ __launch_bounds__(256) void k_first_touch(const u64* __restrict__ keys, u32 H, KeyLayout kl, int ft_bits_entry, int bsp,
+                                                     const u32* __restrict__ roff, u64* __restrict__ p_ft, u32 n) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const u64 kmask = (kl.total >= 64) ? ~0ull : ((1ull << kl.total) - 1ull);
+    const u64 pmask = (1ull << kl.bp) - 1ull, amask = (1ull << kl.ba) - 1ull;
+    const u64 jmax = (1ull << (kl.bs + 1)) - 1ull, pmax = (1ull << bsp) - 1ull;
+    u32 h = WALK ? (u32)p_ft[i] : 0u;
+    const u64 k0 = WALK ? (keys[h] & kmask) : p_ft[i];
+    const u64 gpre = k0 >> kl.sh_diag;
+    const u32 gsubj = (u32)((k0 >> kl.sh_subj) & ((1ull << kl.bs) - 1ull));
+    const i64 gdiag = (i64)((k0 >> kl.sh_diag) & ((1ull << kl.bd) - 1ull)) - kl.diag_off;  // qpos - sst
+    const int sl = (int)(roff[gsubj + 1] - roff[gsubj]);
+    u64 ft = ~0ull;
+    for (u64 k = k0;;) {
+        const int qpos = (int)((k >> kl.sh_qpos) & pmask);
+        const u32 as = kl.ba ? (u32)((k >> kl.sh_as) & amask) : 0u;
+        const u32 tag = kl.ba ? (u32)(k & amask) : 0u;
+        const int sst = (int)((i64)qpos - gdiag);
+        u32 j = gsubj, pos = (u32)sst;
+        if (sst == sl) j = gsubj + 1, pos = 0;  // offset-0 entry of the next chunk sequence
+        const u64 inv = ((jmax - j) << (kl.ba + bsp)) | ((amask - tag) << bsp) | (pmax - pos);
+        const u64 f = ((((u64)as << kl.bp) | (u64)qpos) << ft_bits_entry) | inv;
+        ft = f < ft ? f : ft;
+        if (!WALK) break;
+        if (++h >= H) break;
+        k = keys[h] & kmask;
+        if ((k >> kl.sh_diag) != gpre) break;
+    }
+    p_ft[i] = ft;
+}
+
+void launch_first_touch(bool walk, const u64* keys, u32 H, const KeyLayout& kl, int ft_bits_entry, int bsp, const u32* roff, u64* p_ft, u32 n,
+                        hipStream_t st) {
+    if (!n) return;
+    if (walk) hipLaunchKernelGGL((k_first_touch<true>), dim3((n + 255) / 256), dim3(256), 0, st, keys, H, kl, ft_bits_entry, bsp, roff, p_ft, n);
+    else hipLaunchKernelGGL((k_first_touch<false>), dim3((n + 255) / 256), dim3(256), 0, st, keys, H, kl, ft_bits_entry, bsp, roff, p_ft, n);
 }
 
 // shard offsets (exclusive scan over UG_SHARDS counters) + total
@@ -447,11 +485,11 @@ u32 ungap_shard_cap(u32 H) {
     return ((nblk + UG_SHARDS - 1) / UG_SHARDS) * (UW_RANGE * UW_WAVES);
 }
 
-void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, int ft_bits_entry, int bsp, const u8* q_scls, const u32* qoff,
+void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, bool ft_walk, const u8* q_scls, const u32* qoff,
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt, u32 shard_cap, u64* p_qs, u64* p_sd,
                   u64* p_ft, unsigned long long* group_count, hipStream_t st) {
     if (!H) return;
-    hipLaunchKernelGGL(k_ungap, dim3(ungap_num_blocks(H)), dim3(64 * UW_WAVES), 0, st, keys, H, kl, ft_bits_entry, bsp, q_scls, qoff, r_scls,
+    hipLaunchKernelGGL(k_ungap, dim3(ungap_num_blocks(H)), dim3(64 * UW_WAVES), 0, st, keys, H, kl, ft_walk ? 1 : 0, q_scls, qoff, r_scls,
                        roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count);
 }
 

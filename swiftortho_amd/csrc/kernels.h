@@ -63,9 +63,11 @@ void launch_lookup(const u32* cs_hoff, const u32* cs_base, const u64* cs_kbase, 
 // k_group.hip
 void launch_group_list(const u32* flags, const u32* gidx, u32 H, u32* ghead, hipStream_t st);
 u32 ungap_shard_cap(u32 H);
-void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, int ft_bits_entry, int bsp, const u8* q_scls, const u32* qoff,
+void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, bool ft_walk, const u8* q_scls, const u32* qoff,
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt, u32 shard_cap, u64* p_qs, u64* p_sd,
                   u64* p_ft, unsigned long long* group_count, hipStream_t st);
+void launch_first_touch(bool walk, const u64* keys, u32 H, const KeyLayout& kl, int ft_bits_entry, int bsp, const u32* roff, u64* p_ft, u32 n,
+                        hipStream_t st);
 void launch_shard_scan(const u32* shard_cnt, u32* shard_off, hipStream_t st);
 void launch_compact_shards(const u32* shard_cnt, u32* shard_off, u32 shard_cap, const u64* a0, const u64* a1, const u64* a2, u64* b0,
                            u64* b1, u64* b2, hipStream_t st);
