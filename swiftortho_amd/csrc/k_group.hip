@@ -95,8 +95,8 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
     i64 gdiag = 0;
     u32 qb = 0, sb = 0;
     int ql = 0, sl = 0;
-    int prev_qpos = -1, scores = 0, x0 = 0, y0 = 0, x = 0, y = 0;
-    bool first = true, single = false, havekey = false;
+    int prev_qpos = -1, scores = 0, x = 0, y = 0;  // x, y: right end of the previous segment (0, 0 before the first)
+    bool single = false, havekey = false;
     u64 hkey = 0;  // the head hit's key
     u32 h0 = 0;    // the head hit's position (ft_walk mode)
     u32 cq = 0xFFFFFFFFu, cqb = 0;  // last query looked up (groups arrive sorted by query)
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                         qb = cqb, ql = cql;
                         sb = roff[gsubj];
                         sl = (int)(roff[gsubj + 1] - sb);
-                        prev_qpos = -1, scores = 0, x0 = y0 = x = y = 0, first = true;
+                        prev_qpos = -1, scores = 0, x = y = 0;
                         phase = PH_HIT;
                     } else if (cur >= b0) {
                         phase = PH_DONE;  // nothing left to hand out
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                     } else {
                         prev_qpos = qpos;
                         // Fasta.ungap set-up (2455-2464): first seed unbounded, later ones bounded by the previous segment's end
-                        qlo = first ? 0 : x;
-                        slo = first ? 0 : y;
+                        qlo = x;
+                        slo = y;
                         const int off = max(max(qlo - qpos, slo - sst), 0);
                         Qst = qpos + off;
                         Sst = sst + off;
@@ -257,14 +257,10 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                 phase = PH_LEFT;
             }
             if (phase == PH_LEFT && (ci >= cn || stop)) {
-                const int l_qst = best >= 0 ? Qst - 1 - best : Qst - 1, l_sst = best >= 0 ? Sst - 1 - best : Sst - 1;
-                const int max_score = mp >> 8;
-                if (first) {  // get_ungap_scores (2497-2509)
-                    scores = max_score, x0 = l_qst, y0 = l_sst;
-                    first = false;
-                } else {
-                    scores += max_score;
-                }
+                // get_ungap_scores (2497-2509): segment maxima add up; the next seed is bounded by this segment's right end.
+                // The left end (start of the first segment) only enters guess_start, which needs no end point at all: every
+                // segment of a group lies on the group's diagonal, so (sst0 - qst0) + (sed - qed) = 2 * (sst - qst).
+                scores += mp >> 8;
                 x = r_qed, y = r_sed;
                 ++h;
                 phase = single ? PH_FIN : PH_HIT;  // a singleton group is complete: no second visit to find its end
@@ -289,9 +285,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                     __builtin_amdgcn_wave_barrier();
                 }
                 if (pass) {
-                    // guess_start over [[x0, y0], [x, y]]: floor(((y0 - x0) + (y - x)) / 2)
-                    const int d2 = (y0 - x0) + (y - x);
-                    const int dist = (d2 >= 0) ? d2 / 2 : -((-d2 + 1) / 2);
+                    const int dist = (int)(-gdiag);  // guess_start (2544-2553): floor(2 * (sst - qst) / 2) = the diagonal
                     const u32 i = npb + (u32)__popcll(pb & lt);
                     s_pqs[i] = ((u64)gq << kl.bs) | gsubj;
                     s_psd[i] = ((u64)(u32)scores << 32) | (u64)(u32)dist;
