@@ -92,16 +92,20 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
     u32 h = 0;
     u64 gpre = 0;
     u32 gq = 0, gsubj = 0;
-    i64 gdiag = 0;
-    u32 qb = 0, sb = 0;
-    int ql = 0, sl = 0;
-    int prev_qpos = -1, scores = 0, x = 0, y = 0;  // x, y: right end of the previous segment (0, 0 before the first)
+    // All hits of a group lie on one diagonal, so the subject coordinate is always (query coordinate + dlt):
+    //   dlt = sst - qst;  sbd = subject offset + dlt (subject byte of query position p is r_scls[sbd + p]);
+    //   lim = min(ql, sl - dlt): first query coordinate past either sequence;
+    //   lo  = lower bound of the next segment in query coordinates: max(0, -dlt) before the first segment
+    //         (qlo = slo = 0, fsearch.py:2455-2464), then the previous segment's right end.
+    int dlt = 0, sbd = 0, lim = 0, lo = 0;
+    u32 qb = 0;
+    int prev_qpos = -1, scores = 0;
     bool single = false, havekey = false;
     u64 hkey = 0;  // the head hit's key
     u32 h0 = 0;    // the head hit's position (ft_walk mode)
     u32 cq = 0xFFFFFFFFu, cqb = 0;  // last query looked up (groups arrive sorted by query)
     int cql = 0;
-    int Qst = 0, Sst = 0, qlo = 0, slo = 0, ci = 0, cn = 0, score8 = 0 /*running score x 256*/, mp = 255 /*packed running maximum*/, best = -1, r_qed = 0, r_sed = 0;
+    int Qst = 0, ci = 0, cn = 0, score8 = 0 /*running score x 256*/, mp = 255 /*packed running maximum*/, best = -1, r_qed = 0;
     int qcur = 0, scur = 0;  // byte offsets of the next chunk in the two class arrays
     bool stop = false;
 
@@ -152,12 +156,15 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                         gpre = k0 >> kl.sh_diag;
                         gq = (u32)((k0 >> kl.sh_q) & qall);
                         gsubj = (u32)((k0 >> kl.sh_subj) & ((1ull << kl.bs) - 1ull));
-                        gdiag = (i64)((k0 >> kl.sh_diag) & ((1ull << kl.bd) - 1ull)) - kl.diag_off;  // qpos - sst
+                        dlt = (int)(kl.diag_off - (i64)((k0 >> kl.sh_diag) & ((1ull << kl.bd) - 1ull)));  // sst - qpos
                         if (gq != cq) cq = gq, cqb = qoff[gq], cql = (int)(qoff[gq + 1] - cqb);
-                        qb = cqb, ql = cql;
-                        sb = roff[gsubj];
-                        sl = (int)(roff[gsubj + 1] - sb);
-                        prev_qpos = -1, scores = 0, x = y = 0;
+                        qb = cqb;
+                        const u32 sb = roff[gsubj];
+                        const int sl = (int)(roff[gsubj + 1] - sb);
+                        sbd = (int)sb + dlt;
+                        lim = min(cql, sl - dlt);
+                        lo = max(0, -dlt);
+                        prev_qpos = -1, scores = 0;
                         phase = PH_HIT;
                     } else if (cur >= b0) {
                         phase = PH_DONE;  // nothing left to hand out
@@ -182,20 +189,16 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                     fin = true;
                 } else {
                     const int qpos = (int)((k >> kl.sh_qpos) & pmask);
-                    const int sst = (int)((i64)qpos - gdiag);
                     if (qpos == prev_qpos) {
                         ++h;  // duplicate (qst, sst) pair: dropped by lis()
                     } else {
                         prev_qpos = qpos;
-                        // Fasta.ungap set-up (2455-2464): first seed unbounded, later ones bounded by the previous segment's end
-                        qlo = x;
-                        slo = y;
-                        const int off = max(max(qlo - qpos, slo - sst), 0);
-                        Qst = qpos + off;
-                        Sst = sst + off;
-                        cn = (qlo < Qst && slo < Sst) ? min(ql - Qst, sl - Sst) : 0;
+                        // Fasta.ungap set-up (2455-2464): first seed unbounded, later ones bounded by the previous segment's end;
+                        // off = max(qlo - qst, slo - sst, 0) and both differences are equal on a diagonal
+                        Qst = qpos + max(lo - qpos, 0);
+                        cn = (lo < Qst) ? lim - Qst : 0;  // qlo < qst and slo < sst; min(ql - qst, sl - sst) steps
                         ci = 0, score8 = 0, mp = 255, best = -1, stop = false;
-                        qcur = (int)qb + Qst, scur = (int)sb + Sst;
+                        qcur = (int)qb + Qst, scur = sbd + Qst;
                         phase = PH_RIGHT;
                     }
                 }
@@ -247,13 +250,12 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                 ci += 8;
             }
             if (phase == PH_RIGHT && (ci >= cn || stop)) {
-                r_qed = best >= 0 ? Qst + best : Qst;
-                r_sed = best >= 0 ? Sst + best : Sst;
+                r_qed = Qst + max(best, 0);
                 // left pass from (Qst - 1, Sst - 1); the score continues from the maximum (2479-2492)
                 score8 = mp & ~255;
                 stop = false, best = -1, ci = 0;
-                qcur = (int)qb + Qst - 8, scur = (int)sb + Sst - 8;
-                cn = (Qst - 1 < ql && Sst - 1 < sl) ? min(Qst - 1 - qlo, Sst - 1 - slo) : 0;
+                qcur = (int)qb + Qst - 8, scur = sbd + Qst - 8;
+                cn = (Qst - 1 < lim) ? Qst - 1 - lo : 0;  // min(qst - 1 - qlo, sst - 1 - slo) steps
                 phase = PH_LEFT;
             }
             if (phase == PH_LEFT && (ci >= cn || stop)) {
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                 // The left end (start of the first segment) only enters guess_start, which needs no end point at all: every
                 // segment of a group lies on the group's diagonal, so (sst0 - qst0) + (sed - qed) = 2 * (sst - qst).
                 scores += mp >> 8;
-                x = r_qed, y = r_sed;
+                lo = r_qed;
                 ++h;
                 phase = single ? PH_FIN : PH_HIT;  // a singleton group is complete: no second visit to find its end
             }
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restric
                     __builtin_amdgcn_wave_barrier();
                 }
                 if (pass) {
-                    const int dist = (int)(-gdiag);  // guess_start (2544-2553): floor(2 * (sst - qst) / 2) = the diagonal
+                    const int dist = dlt;  // guess_start (2544-2553): floor(2 * (sst - qst) / 2) = the diagonal
                     const u32 i = npb + (u32)__popcll(pb & lt);
                     s_pqs[i] = ((u64)gq << kl.bs) | gsubj;
                     s_psd[i] = ((u64)(u32)scores << 32) | (u64)(u32)dist;
