@@ -45,7 +45,7 @@ __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global
 
 enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN = 5 };
 
-__global__ __launch_bounds__(64 * UW_WAVES, 7) void k_ungap(const u64* __restrict__ keys, u32 H, KeyLayout kl, int ft_walk,
+__global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restrict__ keys, u32 H, KeyLayout kl, int ft_walk,
                                                          const u8* __restrict__ q_scls, const u32* __restrict__ qoff,
                                                          const u8* __restrict__ r_scls,
                                                          const u32* __restrict__ roff /*chunk-local offsets (absolute values)*/,
