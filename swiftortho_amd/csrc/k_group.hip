@@ -41,7 +41,7 @@ __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global
 #define UW_QCAP 128     // group-head ring (u32 hit indices)
 #define UW_PCAP 64     // buffered pass records per wave
 #define UW_WAIT 20      // run the bookkeeping part when this many lanes wait for it
-#define UG_PIN8 (-(1 << 30))  // running (x 256) score after an X-drop: below anything reachable, 8 more sentinel steps (-128 << 8 each) still fit int32
+#define UG_PIN8 (-(1 << 30))  // running word after an X-drop: below anything reachable, 8 more sentinel steps still fit int32
 
 enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN = 5 };
 
@@ -54,15 +54,19 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                                                          u64* __restrict__ p_ft, unsigned long long* __restrict__ group_count) {
     // score table addressed by ONE v_perm per element: (query class << 8) | (subject class * 4).  Row stride 256 B; the
     // * 4 spreads the 24 subject classes over 24 LDS banks (a row stride of 64 dwords keeps the bank = column / 4).
-    __shared__ signed char s_b62[32 * 256];
+    // 16-bit entries T = (score << 4) - 1 at byte offset (query class << 8) | (subject class * 4): adding T to the running
+    // word advances (score << 4 | 15 - k) by one element in ONE add (see the chunk loop).  Row 31 (query class of the
+    // elements past a pass limit) holds a byte-uniform sentinel, so whatever stray byte the subject side supplies -- at
+    // whatever alignment -- reads as an immediate X-drop.
+    __shared__ short s_b62[32 * 128];
     __shared__ u32 s_queue_all[UW_WAVES][UW_QCAP];   // head position | (1 << 31) when the group is a singleton
     __shared__ u64 s_qkey_all[UW_WAVES][UW_QCAP];    // the head's (masked) key
     __shared__ u64 s_pb_all[UW_WAVES][3][UW_PCAP];
-    for (int i = threadIdx.x; i < 32 * 256; i += 64 * UW_WAVES) {
-        const int a = i >> 8, b = (i & 255) >> 2;  // b: subject class of column i & 255 (columns between the * 4 slots are never read
-                                                   // by in-sequence bytes; stray pad bytes only meet query class 31)
-        // class 31 never occurs in data: it marks elements past a pass limit and scores -128
-        s_b62[i] = (a < SCLS_N && b < SCLS_N) ? b62g[a * SCLS_N + b] : ((a == 31 || b == 31) ? (signed char)-128 : (signed char)-4);
+    for (int i = threadIdx.x; i < 32 * 128; i += 64 * UW_WAVES) {
+        const int a = i >> 7, b = (i & 127) >> 1;  // b: subject class of byte column 2 * (i & 127) (the slots between the * 4
+                                                   // columns are never read by in-sequence bytes)
+        const int v = (a < SCLS_N && b < SCLS_N) ? (int)b62g[a * SCLS_N + b] : -4;
+        s_b62[i] = (a == 31) ? (short)0xF7F7 /* -2057: far below the X-drop threshold */ : (short)((v << 4) - 1);
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
     u32 h0 = 0;    // the head hit's position (ft_walk mode)
     u32 cq = 0xFFFFFFFFu, cqb = 0;  // last query looked up (groups arrive sorted by query)
     int cql = 0;
-    int Qst = 0, ci = 0, cn = 0, score8 = 0 /*running score x 256*/, mp = 255 /*packed running maximum*/, best = -1, r_qed = 0;
+    int Qst = 0, ci = 0, cn = 0, score8 = 16 /*running word: (score << 4) + position nibble*/, mp = 15 /*packed running maximum*/, best = -1, r_qed = 0;
     int qcur = 0, scur = 0;  // byte offsets of the next chunk in the two class arrays
     bool stop = false;
 
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                         // off = max(qlo - qst, slo - sst, 0) and both differences are equal on a diagonal
                         Qst = qpos + max(lo - qpos, 0);
                         cn = (lo < Qst) ? lim - Qst : 0;  // qlo < qst and slo < sst; min(ql - qst, sl - sst) steps
-                        ci = 0, score8 = 0, mp = 255, best = -1, stop = false;
+                        ci = 0, score8 = 16, mp = 15, best = -1, stop = false;
                         qcur = (int)qb + Qst, scur = sbd + Qst;
                         phase = PH_RIGHT;
                     }
@@ -229,30 +233,33 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                 for (int k = 0; k < 8; ++k) {
                     const u32 qh = (u32)(k < 4 ? qw : qw >> 32), sh = (u32)(k < 4 ? sw : sw >> 32);
                     // byte0 = subject byte k, byte1 = query byte k, bytes 2-3 = 0   (selector 0x0c = constant 0x00)
-                    sc[k] = s_b62[__builtin_amdgcn_perm(qh, sh, 0x0c0c0400u + (u32)(k & 3) * 0x0101u)];
+                    const u32 boff = __builtin_amdgcn_perm(qh, sh, 0x0c0c0400u + (u32)(k & 3) * 0x0101u);
+                    sc[k] = *reinterpret_cast<const short*>(reinterpret_cast<const char*>(s_b62) + boff);
                 }
-                // Scores are carried scaled by 256 (`score8`), so that the running maximum and its FIRST position share one
-                // word: mp = (max << 8) | (255 - k).  A later equal score has a smaller low byte and loses; the incoming
-                // maximum carries 255 and wins every tie.  With d = mp - P = ((max - ns) << 8) + (low-byte difference in
-                // [-7, 7]) the X-drop test  ns + 30 < max  is  d >= (31 << 8) - 7.  Six VALU per element.
+                // The running word R carries (score << 4) + (15 - k) after element k: score and position of the element in one
+                // word, advanced by ONE add of the table entry (score << 4) - 1 (the chunk starts at (score + 1) << 4).  The
+                // running maximum mp keeps the largest R seen: a later equal score has a smaller low nibble and loses, the
+                // incoming maximum carries 15 and wins every tie -- the FIRST position of the maximum, as the reference's
+                // strict `>`.  With d = mp - R = ((max - ns) << 4) + (nibble difference in [0, 7]) the X-drop test
+                // ns + 30 < max  is  d >= (31 << 4) - 7.  Five VALU per element.
                 const int mp_in = mp;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int ns8 = (sc[k] << 8) + score8;
-                    const int P = ns8 | (255 - k);
-                    const bool drop = mp - P >= ((DROPX + 1) << 8) - 7;
-                    mp = max(mp, P);
-                    score8 = drop ? UG_PIN8 : ns8;
+                    score8 += sc[k];
+                    const bool drop = mp - score8 >= ((DROPX + 1) << 4) - 7;
+                    mp = max(mp, score8);
+                    score8 = drop ? UG_PIN8 : score8;
                 }
-                if (mp != mp_in) best = ci + (255 - (mp & 255));
-                mp |= 255;
+                if (mp != mp_in) best = ci + (15 - (mp & 15));
+                mp |= 15;
                 stop = score8 < (UG_PIN8 >> 1);
+                score8 += 8;  // low nibble 8 -> (score + 1) << 4 for the next chunk
                 ci += 8;
             }
             if (phase == PH_RIGHT && (ci >= cn || stop)) {
                 r_qed = Qst + max(best, 0);
                 // left pass from (Qst - 1, Sst - 1); the score continues from the maximum (2479-2492)
-                score8 = mp & ~255;
+                score8 = (mp & ~15) + 16;
                 stop = false, best = -1, ci = 0;
                 qcur = (int)qb + Qst - 8, scur = sbd + Qst - 8;
                 cn = (Qst - 1 < lim) ? Qst - 1 - lo : 0;  // min(qst - 1 - qlo, sst - 1 - slo) steps
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                 // get_ungap_scores (2497-2509): segment maxima add up; the next seed is bounded by this segment's right end.
                 // The left end (start of the first segment) only enters guess_start, which needs no end point at all: every
                 // segment of a group lies on the group's diagonal, so (sst0 - qst0) + (sed - qed) = 2 * (sst - qst).
-                scores += mp >> 8;
+                scores += mp >> 4;
                 lo = r_qed;
                 ++h;
                 phase = single ? PH_FIN : PH_HIT;  // a singleton group is complete: no second visit to find its end
