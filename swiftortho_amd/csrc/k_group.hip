@@ -111,6 +111,8 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
     int cql = 0;
     int Qst = 0, ci = 0, cn = 0, score8 = 16 /*running word: (score << 4) + position nibble*/, mp = 15 /*packed running maximum*/, best = -1, r_qed = 0;
     int qcur = 0, scur = 0;  // byte offsets of the next chunk in the two class arrays
+    int dstep = 8;           // +8 on the right pass, -8 on the left pass
+    u32 selA = 0x03020100u, selB = 0x07060504u;  // v_perm selectors of the low / high half of a chunk in element order
     bool stop = false;
 
     for (;;) {
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                         cn = (lo < Qst) ? lim - Qst : 0;  // qlo < qst and slo < sst; min(ql - qst, sl - sst) steps
                         ci = 0, score8 = 16, mp = 15, best = -1, stop = false;
                         qcur = (int)qb + Qst, scur = sbd + Qst;
+                        dstep = 8, selA = 0x03020100u, selB = 0x07060504u;
                         phase = PH_RIGHT;
                     }
                 }
@@ -216,16 +219,16 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
         // nor matter -- exactly the sequential loop's `break`.
         if (phase == PH_RIGHT || phase == PH_LEFT) {
             if (ci < cn && !stop) {
-                const bool left = phase == PH_LEFT;
                 // right: bytes [Qst + ci, +8), element k in byte k;  left: bytes [Qst - 8 - ci, +8), element k in byte 7 - k
                 // (qcur / scur walk by +-8 per chunk).  A left window may start up to 8 bytes before its sequence (the arrays
                 // have 16 readable bytes in front): those elements lie past the pass limit and are never active.
-                u64 qw = load8u(q_scls + qcur), sw = load8u(r_scls + scur);
-                qcur += left ? -8 : 8;
-                scur += left ? -8 : 8;
-                const u64 qr = __builtin_bswap64(qw), sr = __builtin_bswap64(sw);
-                qw = left ? qr : qw;
-                sw = left ? sr : sw;
+                const u64 q0 = load8u(q_scls + qcur), s0 = load8u(r_scls + scur);
+                qcur += dstep;
+                scur += dstep;
+                // element order: one v_perm per 32-bit half with the pass's selectors (identity on the right pass, byte
+                // reversal across the two halves on the left pass)
+                u64 qw = (u64)__builtin_amdgcn_perm((u32)(q0 >> 32), (u32)q0, selA) | ((u64)__builtin_amdgcn_perm((u32)(q0 >> 32), (u32)q0, selB) << 32);
+                u64 sw = (u64)__builtin_amdgcn_perm((u32)(s0 >> 32), (u32)s0, selA) | ((u64)__builtin_amdgcn_perm((u32)(s0 >> 32), (u32)s0, selB) << 32);
                 const int m = cn - ci;
                 if (m < 8) qw = (qw & ~(~0ull << (8 * m))) | (0x1F1F1F1F1F1F1F1Full << (8 * m));  // elements >= m: exactly class 31 (row 31 = -128)
                 int sc[8];
@@ -262,6 +265,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                 score8 = (mp & ~15) + 16;
                 stop = false, best = -1, ci = 0;
                 qcur = (int)qb + Qst - 8, scur = sbd + Qst - 8;
+                dstep = -8, selA = 0x04050607u, selB = 0x00010203u;
                 cn = (Qst - 1 < lim) ? Qst - 1 - lo : 0;  // min(qst - 1 - qlo, sst - 1 - slo) steps
                 phase = PH_LEFT;
             }
