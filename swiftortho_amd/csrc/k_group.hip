@@ -41,11 +41,13 @@ __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global
 #define UW_QCAP 128     // group-head ring (u32 hit indices)
 #define UW_PCAP 64     // buffered pass records per wave
 #define UW_WAIT 20      // run the bookkeeping part when this many lanes wait for it
+#define UW_CPI 3        // 8-residue chunks per loop iteration (the right -> left hand-over sits between them)
 #define UG_PIN8 (-(1 << 30))  // running word after an X-drop: below anything reachable, 8 more sentinel steps still fit int32
 
 enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN = 5 };
 
-__global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restrict__ keys, u32 H, KeyLayout kl, int ft_walk,
+template <int CPI /*chunks per loop iteration*/>
+__global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restrict__ keys, u32 H, KeyLayout kl, int ft_walk, u32 wait_n,
                                                          const u8* __restrict__ q_scls, const u32* __restrict__ qoff,
                                                          const u8* __restrict__ r_scls,
                                                          const u32* __restrict__ roff /*chunk-local offsets (absolute values)*/,
@@ -84,6 +86,8 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
     const u64 qall = (1ull << kl.bq) - 1ull;
     const u64 pmask = (1ull << kl.bp) - 1ull;
     const u32 shard = blockIdx.x & (UG_SHARDS - 1);
+    const u8* q_m16 = q_scls - 16;  // both class arrays have 16 readable bytes in front (left windows start up to 8 bytes early)
+    const u8* r_m16 = r_scls - 16;
 
     // wave-uniform bookkeeping
     u32 cur = a0;              // next position to scan for heads
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
         const unsigned long long waitb = __ballot(phase == PH_NEED || phase == PH_HIT);
         const unsigned long long workb = __ballot(phase == PH_RIGHT || phase == PH_LEFT);
         if (!waitb && !workb) break;
-        if (waitb && (!workb || __popcll(waitb) >= UW_WAIT)) {
+        if (waitb && (!workb || (u32)__popcll(waitb) >= wait_n)) {
             // ---- refill the head ring -----------------------------------------------------------------
             while (qback - qfront < 64u && cur < b0) {
                 const u32 pos = cur + (u32)lane;
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                         Qst = qpos + max(lo - qpos, 0);
                         cn = (lo < Qst) ? lim - Qst : 0;  // qlo < qst and slo < sst; min(ql - qst, sl - sst) steps
                         ci = 0, score8 = 16, mp = 15, best = -1, stop = false;
-                        qcur = (int)qb + Qst, scur = sbd + Qst;
+                        qcur = (int)qb + Qst + 16, scur = sbd + Qst + 16;  // offsets from (array - 16): never negative
                         dstep = 8, selA = 0x03020100u, selB = 0x07060504u;
                         phase = PH_RIGHT;
                     }
@@ -218,11 +222,13 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
         // drop the running score is pinned far below zero so later elements can neither raise the maximum
         // nor matter -- exactly the sequential loop's `break`.
         if (phase == PH_RIGHT || phase == PH_LEFT) {
+#pragma unroll
+          for (int rep = 0; rep < CPI; ++rep) {
             if (ci < cn && !stop) {
                 // right: bytes [Qst + ci, +8), element k in byte k;  left: bytes [Qst - 8 - ci, +8), element k in byte 7 - k
                 // (qcur / scur walk by +-8 per chunk).  A left window may start up to 8 bytes before its sequence (the arrays
                 // have 16 readable bytes in front): those elements lie past the pass limit and are never active.
-                const u64 q0 = load8u(q_scls + qcur), s0 = load8u(r_scls + scur);
+                const u64 q0 = load8u(q_m16 + (u32)qcur), s0 = load8u(r_m16 + (u32)scur);  // scalar base + 32-bit offset
                 qcur += dstep;
                 scur += dstep;
                 // element order: one v_perm per 32-bit half with the pass's selectors (identity on the right pass, byte
@@ -264,11 +270,12 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                 // left pass from (Qst - 1, Sst - 1); the score continues from the maximum (2479-2492)
                 score8 = (mp & ~15) + 16;
                 stop = false, best = -1, ci = 0;
-                qcur = (int)qb + Qst - 8, scur = sbd + Qst - 8;
+                qcur = (int)qb + Qst + 8, scur = sbd + Qst + 8;  // (Qst - 8) + 16
                 dstep = -8, selA = 0x04050607u, selB = 0x00010203u;
                 cn = (Qst - 1 < lim) ? Qst - 1 - lo : 0;  // min(qst - 1 - qlo, sst - 1 - slo) steps
                 phase = PH_LEFT;
             }
+          }
             if (phase == PH_LEFT && (ci >= cn || stop)) {
                 // get_ungap_scores (2497-2509): segment maxima add up; the next seed is bounded by this segment's right end.
                 // The left end (start of the first segment) only enters guess_start, which needs no end point at all: every
@@ -496,8 +503,12 @@ void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, bool ft_walk, con
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt, u32 shard_cap, u64* p_qs, u64* p_sd,
                   u64* p_ft, unsigned long long* group_count, hipStream_t st) {
     if (!H) return;
-    hipLaunchKernelGGL(k_ungap, dim3(ungap_num_blocks(H)), dim3(64 * UW_WAVES), 0, st, keys, H, kl, ft_walk ? 1 : 0, q_scls, qoff, r_scls,
-                       roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count);
+    // SOHIT_UG_CPI / SOHIT_UG_WAIT: tuning switches (results do not depend on them)
+    const int cpi = getenv("SOHIT_UG_CPI") ? atoi(getenv("SOHIT_UG_CPI")) : UW_CPI;
+    const u32 wait_n = getenv("SOHIT_UG_WAIT") ? (u32)atoi(getenv("SOHIT_UG_WAIT")) : UW_WAIT;
+    auto kern = cpi == 1 ? k_ungap<1> : cpi == 2 ? k_ungap<2> : k_ungap<3>;
+    hipLaunchKernelGGL(kern, dim3(ungap_num_blocks(H)), dim3(64 * UW_WAVES), 0, st, keys, H, kl, ft_walk ? 1 : 0, wait_n, q_scls, qoff,
+                       r_scls, roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count);
 }
 
 void launch_shard_scan(const u32* shard_cnt, u32* shard_off, hipStream_t st) {
