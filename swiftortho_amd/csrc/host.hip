@@ -962,6 +962,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     const u32* dS = scan_u32(b.flags.p, b.gidx.p, NP, false, c->d_scan_tmp.p, c->st);
     const u32 NS = d2h_u32(c, dS);
     b.shead.ensure((size_t)NS + 2);
+    if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] seed pass: queries %u..%u hits %u seeds %u pass records %u candidates %u\n", qa, qb, H, K, NP, NS);
     launch_group_list(b.flags.p, b.gidx.p, NP, b.shead.p, c->st);
     b.c_ft.ensure((size_t)NS + 2), b.c_ft2.ensure((size_t)NS + 2), b.c_q.ensure((size_t)NS + 2), b.c_rec.ensure(4 * (size_t)NS + 8);
     launch_best(b.p_qs2.p, b.pidx2.p, b.shead.p, NS, NP, q_sd, q_ft, (u32)ch.seq_lo, kl.bs, b.c_ft.p, b.c_q.p, b.c_rec.p, c->st);

@@ -342,3 +342,41 @@ def test_full_size_properties(fs):
     h2.close()
     hits.close()
     s.close()
+
+
+RCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from swiftortho_amd import dist as sdist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+for n in (0, 80, 80 * 50001):
+    recs = (np.arange(n, dtype=np.int64) %% 251).astype(np.uint8)
+    g = sdist.gather_records(recs)
+    assert g.sizes == [n], g.sizes
+    got = g.arrays()[0]
+    assert got.shape == (n,) and np.array_equal(got, recs)
+t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+print("RCCL_GATHER_OK", float(t.item()))
+dist.destroy_process_group()
+'''
+
+
+def test_gather_records_over_rccl(tmp_path):
+    """The hit gather of bench.py / find_hit.py -a N on the backend the GPU box really uses ("nccl" == RCCL):
+    size all_gather, padded gather, pinned device-to-host copy, and the all_reduce / barrier bench.py issues.
+    One rank (the box has one GPU); the world_size-2 flow is covered on gloo in test_host_logic.py."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200), WORLD_SIZE="1", RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    assert "RCCL_GATHER_OK 1.5" in p.stdout
