@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -35,6 +36,9 @@ struct DevBuf {
         size_t nc = n + n / 8 + 64;
         T* np_ = nullptr;
         HIP_CHECK(hipMalloc((void**)&np_, nc * sizeof(T)));
+        // SOHIT_POISON=<byte>: fill every fresh allocation (tests: results must not depend on what device memory held before)
+        static const char* poison = getenv("SOHIT_POISON");
+        if (poison) HIP_CHECK(hipMemset(np_, (int)strtol(poison, nullptr, 0) & 0xFF, nc * sizeof(T)));
         if (keep && p && cap) {
             HIP_CHECK(hipMemcpyAsync(np_, p, cap * sizeof(T), hipMemcpyDeviceToDevice, st));
             HIP_CHECK(hipStreamSynchronize(st));

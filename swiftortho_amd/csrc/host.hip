@@ -338,10 +338,10 @@ void upload_constants(so_ctx* c) {
 void layout_set(so_ctx* c, SeqSet& s, const bool present[256], size_t nres, u32 nseq) {
     u8 hmap[256];
     build_hash_classes(present, c->codes, hmap, s.lut);
-    s.d_scls_store.ensure(nres + 64 + 16);
-    s.d_scls.p = s.d_scls_store.p + 16;
-    s.d_scls4_store.ensure(nres + 64 + 16);
-    s.d_scls4.p = s.d_scls4_store.p + 16;
+    s.d_scls_store.ensure(nres + SCLS_PAD_FRONT + SCLS_PAD_BACK);
+    s.d_scls.p = s.d_scls_store.p + SCLS_PAD_FRONT;
+    s.d_scls4_store.ensure(nres + SCLS_PAD_FRONT + SCLS_PAD_BACK);
+    s.d_scls4.p = s.d_scls4_store.p + SCLS_PAD_FRONT;
     HIP_CHECK(hipMemcpyAsync(c->d_hmap.p, hmap, 256, hipMemcpyHostToDevice, c->st));
     launch_scls(s.d_res.p, nres, c->d_smap.p, s.d_scls.p, s.d_scls4.p, c->st);
     if ((u64)nres + nseq + 64 > 0xFFFFFFF0ull) throw SoError("sequence set too large for 32-bit packed positions");

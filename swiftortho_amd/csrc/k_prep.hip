@@ -62,6 +62,13 @@ __global__ __launch_bounds__(256) void k_scls(const u8* __restrict__ res, size_t
     __shared__ u8 s_map[256];
     s_map[threadIdx.x] = smap[threadIdx.x];
     __syncthreads();
+    // the 16 bytes in front of and the 64 bytes behind both arrays belong to them (k_ungap's windows reach up to 8 bytes
+    // past either end): class 0, so that no lookup offset ever depends on what the allocation held before
+    if (blockIdx.x == 0 && threadIdx.x < SCLS_PAD_FRONT + SCLS_PAD_BACK) {
+        const ptrdiff_t o = threadIdx.x < SCLS_PAD_FRONT ? (ptrdiff_t)threadIdx.x - SCLS_PAD_FRONT : (ptrdiff_t)(n + threadIdx.x - SCLS_PAD_FRONT);
+        scls[o] = 0;
+        if (scls4) scls4[o] = 0;
+    }
     size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 3 < n) {
         uchar4 v = *reinterpret_cast<const uchar4*>(res + i);
@@ -243,7 +250,6 @@ void launch_layout(const u8* res, const u32* off, u32 nseq, u32 P, u32 Ppad, con
 }
 
 void launch_scls(const u8* res, size_t n, const u8* smap, u8* scls, u8* scls4, hipStream_t st) {
-    if (n == 0) return;
-    size_t thr = (n + 3) / 4;
+    size_t thr = std::max<size_t>((n + 3) / 4, 1);  // n == 0: the pads alone
     hipLaunchKernelGGL(k_scls, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, st, res, n, smap, scls, scls4);
 }

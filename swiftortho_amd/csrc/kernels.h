@@ -23,6 +23,10 @@ void sort_pairs_u64_u32(void* temp, size_t temp_bytes, const u64* kin, u64* kout
 // k_prep.hip
 void launch_layout(const u8* res, const u32* off, u32 nseq, u32 P, u32 Ppad, const u8* hmap, u32* pseq, u8* pcls, u32* words,
                    hipStream_t st);
+// score classes of n residues; scls / scls4 point SCLS_PAD_FRONT bytes into allocations of n + SCLS_PAD_FRONT + SCLS_PAD_BACK
+// bytes, and the pads are zeroed here
+#define SCLS_PAD_FRONT 16
+#define SCLS_PAD_BACK 64
 void launch_scls(const u8* res, size_t n, const u8* smap, u8* scls, u8* scls4 /*nullable: class * 4*/, hipStream_t st);
 void launch_seg(const u8* raw, const u32* src_off, u32 q_lo, u32 nq, const u32* dst_off, const u8* symmap, const u8* upmap,
                 const void* tab /*SegTab on the device*/, u8* mk, u8* out, u32 max_len, hipStream_t st);

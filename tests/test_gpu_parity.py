@@ -380,3 +380,18 @@ def test_gather_records_over_rccl(tmp_path):
     p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
     assert "RCCL_GATHER_OK 1.5" in p.stdout
+
+
+@pytest.mark.parametrize("poison", ["0xFF", "0x5A"])
+def test_results_do_not_depend_on_stale_device_memory(poison):
+    """Every fresh device allocation is filled with a byte pattern (SOHIT_POISON) and a short randomised differential
+    runs in that process: regression for the class-array pads k_ungap's windows reach into (a stale 0xFF there once
+    read one byte past the LDS score table).  tools/diag/fuzz_parity.py compares rows and candidate lists with the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SOHIT_POISON=poison)
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "diag", "fuzz_parity.py"), "4", "20261002"], env=env, cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert p.stdout.count(" ok ") == 4, p.stdout[-3000:]
