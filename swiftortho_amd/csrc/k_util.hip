@@ -104,6 +104,43 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* __restri
     }
 }
 
+// short inputs (per-query counters: one value per query of a batch): one block walks the tiles with a running carry,
+// one launch instead of three
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_small(const u32* __restrict__ in, u32* __restrict__ out, size_t n, u32* __restrict__ total,
+                                                             int inclusive) {
+    __shared__ u32 lds4[4];
+    u32 carry = 0;
+    for (size_t i0 = 0; i0 < n; i0 += SCAN_THREADS * 4) {
+        const size_t i = i0 + (size_t)threadIdx.x * 4;
+        u32 a = 0, b = 0, c = 0, d = 0;
+        if (i + 3 < n) {
+            uint4 v = *reinterpret_cast<const uint4*>(in + i);
+            a = v.x, b = v.y, c = v.z, d = v.w;
+        } else {
+            if (i < n) a = in[i];
+            if (i + 1 < n) b = in[i + 1];
+            if (i + 2 < n) c = in[i + 2];
+            if (i + 3 < n) d = in[i + 3];
+        }
+        u32 s = a + b + c + d, tot;
+        const u32 ex = carry + block_excl_scan_u32(s, lds4, &tot);
+        u32 o0, o1, o2, o3;
+        if (inclusive) o0 = ex + a, o1 = o0 + b, o2 = o1 + c, o3 = o2 + d;
+        else o0 = ex, o1 = ex + a, o2 = o1 + b, o3 = o2 + c;
+        if (i + 3 < n) {
+            *reinterpret_cast<uint4*>(out + i) = make_uint4(o0, o1, o2, o3);
+        } else {
+            if (i < n) out[i] = o0;
+            if (i + 1 < n) out[i + 1] = o1;
+            if (i + 2 < n) out[i + 2] = o2;
+            if (i + 3 < n) out[i + 3] = o3;
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+#define SCAN_SMALL_TILES 8  // up to 64 k values
+
 size_t scan_u32_temp_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 2; }
 
 // out[i] = sum(in[0..i)) (exclusive) or sum(in[0..i]) (inclusive); in may alias out (16-byte aligned).
@@ -113,6 +150,10 @@ const u32* scan_u32(const u32* in, u32* out, size_t n, bool inclusive, u32* temp
     if (nb == 0) {
         HIP_CHECK(hipMemsetAsync(temp, 0, sizeof(u32), st));
         return temp;
+    }
+    if (nb <= SCAN_SMALL_TILES) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(SCAN_THREADS), 0, st, in, out, n, temp + nb, inclusive ? 1 : 0);
+        return temp + nb;
     }
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, temp);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_THREADS), 0, st, temp, nb);
