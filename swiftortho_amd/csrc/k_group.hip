@@ -31,8 +31,9 @@ __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global
 //     NEED_GROUP -> NEXT_HIT -> RIGHT pass -> LEFT pass -> NEXT_HIT -> ... -> (group done) -> NEED_GROUP
 // pulling the next group as soon as it finishes one: a wave's time is (sum of its lanes' work) / 64
 // instead of 64 x the slowest group, and no separate head-flag / scan / list kernels are needed.
-// One loop iteration = one 8-residue chunk for every lane that is inside a pass; the bookkeeping part
-// (group fetch, hit walk) runs only when enough lanes wait for it.  Passing groups (score >= 25) are
+// One loop iteration = CPI 8-residue chunks for every lane that is inside a pass (a lane whose right pass ends goes
+// straight on with its left pass in the next chunk); the bookkeeping part (group fetch, hit walk) runs only when enough
+// lanes wait for it.  Passing groups (score >= 25) are
 // buffered in LDS and flushed to one of UG_SHARDS regions with ONE atomic per flush (wave-ballot
 // compaction inside the wave).   p_qs = (q << bs) | subject_local, p_sd = (score << 32) | (u32)dist,
 // p_ft = the head hit's key (or its position when ft_walk): k_first_touch turns it into the first-touch key.
