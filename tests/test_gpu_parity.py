@@ -395,3 +395,48 @@ def test_results_do_not_depend_on_stale_device_memory(poison):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:]
     assert p.stdout.count(" ok ") == 4, p.stdout[-3000:]
+
+
+def _cli(args, **kw):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable] + args, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, **kw)
+
+
+@pytest.mark.parametrize("name", ["toy_default", "toy_chunks", "toy_multiseed", "example_cfg1"])
+def test_fsearch_c_stand_in_cli_matches_golden(tmp_path, name):
+    """bin/fsearch-c (the reference's native CLI, fsearch.py:3152-3264) with the golden's own flags: the -o file is the
+    golden .sc; split in two -l/-u blocks with -O a (find_hit.py's block scheme, 119-132) it is the same file; with -o
+    empty the rows go to stdout (3253)."""
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    ref = os.path.join(GOLD, name + ".ref.fsa")
+    qry = os.path.join(GOLD, name + ".qry.fsa") if meta["separate_query"] else ref
+    want = open(os.path.join(GOLD, name + ".sc"), "rb").read()
+    base = [os.path.join("bin", "fsearch-c"), "-p", "blastp", "-i", qry, "-d", ref] + list(meta["flags"])
+    out = tmp_path / "whole.sc"
+    p = _cli(base + ["-o", str(out)])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out.read_bytes() == want
+    nq = sum(1 for l in open(qry, "rb") if l.startswith(b">"))
+    if nq >= 2:
+        out2 = tmp_path / "blocks.sc"
+        mid = nq // 2
+        for lo, hi, mode in ((0, mid, "w"), (mid, nq, "a")):
+            p = _cli(base + ["-o", str(out2), "-l", str(lo), "-u", str(hi), "-O", mode])
+            assert p.returncode == 0, p.stderr[-2000:]
+        assert out2.read_bytes() == want
+    p = _cli(base)
+    assert p.returncode == 0 and p.stdout == want
+
+
+@pytest.mark.parametrize("name", ["toy_default", "toy_aa20"])
+def test_find_hit_cli_matches_golden(tmp_path, name):
+    """bin/find_hit.py with the reference's flag letters (find_hit.py:227-228) writes the golden .sc."""
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    ref = os.path.join(GOLD, name + ".ref.fsa")
+    qry = os.path.join(GOLD, name + ".qry.fsa") if meta["separate_query"] else ref
+    out = tmp_path / "fh.sc"
+    p = _cli([os.path.join("bin", "find_hit.py"), "-p", "blastp", "-i", qry, "-d", ref, "-o", str(out), "-a", "1"] + list(meta["flags"]))
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-2000:])
+    assert out.read_bytes() == open(os.path.join(GOLD, name + ".sc"), "rb").read()
