@@ -238,7 +238,13 @@ __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ ta
     const u8* rraw = swp ? (q_res + qb + qi) : (r_res + sb + qj);
     const u32* tr = trace + (size_t)tid * trace_stride;
     const int bi = r.qst, bj = r.qed;
-    int i = bi, j = bj, AL = 0, matches = 0, gaps = 0, run = 0, rtype = 0;
+    // The reference derives its statistics from the two aligned STRINGS, gap columns spelled '-' (1454-1471): identity
+    // compares characters, and the gap counter is a three-state machine over them (op = -1 / 0 / 1; a '-' in string 0 opens
+    // when op != 0, else one in string 1 opens when op != 1, else op resets) -- so a run of L gap columns counts ceil(L / 2)
+    // openings, and a literal '-' residue behaves like a gap character.  The walk below runs from the END of the alignment,
+    // the machine from its start: f_s = openings counted from the current column to the end if the machine enters it in
+    // state s; three counters, updated per column, and the answer is f(-1) at the first column.
+    int i = bi, j = bj, AL = 0, matches = 0, fm1 = 0, f0 = 0, f1 = 0;
     int wkey = -1;  // (8-row block, lane) of the cached trace word
     u32 wv = 0;
     while (i > 0 || j > 0) {
@@ -256,20 +262,15 @@ __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ ta
         }
         if (tc == 0) break;
         ++AL;
-        if (tc == 1) {
-            matches += (craw[j - 1] == rraw[i - 1]) ? 1 : 0;
-            --i, --j;
-            run = 0, rtype = 0;
-        } else {
-            // a run of L same-direction gap columns counts ceil(L / 2) openings (1462-1469)
-            if (rtype != tc) run = 0, rtype = tc;
-            if ((run & 1) == 0) ++gaps;
-            ++run;
-            if (tc == 2) --j;
-            else --i;
-        }
+        const int a0 = tc == 3 ? '-' : (int)craw[j - 1], a1 = tc == 2 ? '-' : (int)rraw[i - 1];  // the column's two characters (1419-1432)
+        matches += (a0 == a1) ? 1 : 0;
+        const bool g0 = a0 == '-', g1 = a1 == '-';
+        const int nm1 = g0 ? 1 + f0 : (g1 ? 1 + f1 : fm1), n0 = g1 ? 1 + f1 : fm1, n1 = g0 ? 1 + f0 : fm1;
+        fm1 = nm1, f0 = n0, f1 = n1;
+        if (tc != 3) --j;
+        if (tc != 2) --i;
     }
-    r.aln = AL, r.matches = matches, r.gap = gaps;
+    r.aln = AL, r.matches = matches, r.gap = fm1;
     if (swp) {  // rows = query, columns = subject (1473-1474)
         r.qst = i + qi, r.qed = bi + qi, r.sst = j + qj, r.sed = bj + qj;
     } else {

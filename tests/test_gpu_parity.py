@@ -440,3 +440,65 @@ def test_find_hit_cli_matches_golden(tmp_path, name):
     p = _cli([os.path.join("bin", "find_hit.py"), "-p", "blastp", "-i", qry, "-d", ref, "-o", str(out), "-a", "1"] + list(meta["flags"]))
     assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-2000:])
     assert out.read_bytes() == open(os.path.join(GOLD, name + ".sc"), "rb").read()
+
+
+def _ragged_queries(base):
+    recs, cur = {}, None
+    for l in base.decode().strip().split("\n"):
+        if l.startswith(">"):
+            cur = l
+            recs[cur] = ""
+        else:
+            recs[cur] += l
+    names = list(recs)
+    s0, s1 = recs[names[0]], recs[names[1]]
+    return b"".join([
+        (names[0] + " some description here\n").encode(), (s0[:50] + "\n" + s0[50:] + "\n").encode(),  # wrapped lines, description
+        b">tiny\nMKV\n",                                                  # shorter than every seed: no hits (our definition)
+        b">empty\n",                                                      # empty record: skipped
+        b">allx\n" + b"X" * 40 + b"\n",                                   # every window rejected
+        b">lower\n" + s1.lower().encode() + b"\n",                        # lower case scores like upper case, hashes differently
+        b">crlf\r\n" + s1[:60].encode() + b"\r\n" + s1[60:].encode() + b"\r\n",  # '\r' is kept as a residue / in the id (F1)
+        b">weird\n" + (s0[:30] + "*U-J" + s0[30:]).encode() + b"\n",      # bytes outside the 23 letters score -4
+        b">last_no_newline\n" + s0.encode(),                              # file ends without '\n'
+    ])
+
+
+@pytest.mark.parametrize("kw", [dict(ssd="111111", expect=1e-3, v=500, step=1, ht=1000003, chk=50000),
+                                dict(ssd="1101011", expect=10.0, v=5, step=2, ht=50021, chk=17, flt="F")])
+def test_ragged_inputs_vs_oracle(fs, oracle, tmp_path, kw):
+    """Empty, tiny, all-X, lower-case, CRLF, non-alphabet and unterminated query records against a small family set."""
+    from swiftortho_amd import synthprot
+    base = synthprot.synthprot(60, 120, 5)
+    qry = _ragged_queries(base)
+    qp, rp, op = tmp_path / "q.fsa", tmp_path / "r.fsa", tmp_path / "o.sc"
+    qp.write_bytes(qry), rp.write_bytes(base)
+    r = oracle.blastp(str(qp), str(rp), str(op), **kw)
+    want = op.read_bytes()
+    assert len(want) > 0 and r.nqueries == 8
+    s, hits, rows = gpu_rows(fs, base, qry, dict(nr=oracle.AA9, thr=-1, max_miss=1e-3, flt="T", **kw) if "flt" not in kw else
+                             dict(nr=oracle.AA9, thr=-1, max_miss=1e-3, **kw))
+    if rows != want:
+        a, b = rows.split(b"\n"), want.split(b"\n")
+        for i in range(max(len(a), len(b))):
+            x = a[i] if i < len(a) else b"<none>"
+            y = b[i] if i < len(b) else b"<none>"
+            assert x == y, "row %d differs\n gpu: %r\n ref: %r" % (i, x, y)
+    hits.close()
+    s.close()
+
+
+def test_no_hits_and_empty_sets(fs, tmp_path):
+    """Unrelated query, queries that cannot seed, empty query file, empty reference: no rows, no crash."""
+    from swiftortho_amd import synthprot
+    ref = synthprot.uniform_proteins(50, 80, 11)
+    kw = dict(ssd="11111011111", nr="AST,CFILMVY,DN,EQ,G,H,KR,P,W", ht=1000003, chk=50000, step=1, v=500, thr=-1, expect=1e-30, max_miss=1e-3, flt="T")
+    for qry in (synthprot.uniform_proteins(5, 70, 12), b">tiny\nMK\n>empty\n", b""):
+        s, hits, rows = gpu_rows(fs, ref, qry, kw)
+        assert rows == b"" and len(hits) == 0
+        hits.close()
+        s.close()
+    s, hits, rows = gpu_rows(fs, b"", ref, kw)  # empty reference: nothing to hit
+    assert rows == b"" and len(hits) == 0
+    hits.close()
+    s.close()

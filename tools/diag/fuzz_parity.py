@@ -20,6 +20,16 @@ for case in range(ncase):
     N = int(rng.integers(150, 1600)); L = int(rng.integers(40, 420))
     uniform = rng.random() < 0.25
     fa = (synthprot.uniform_proteins if uniform else synthprot.synthprot)(N, L, int(rng.integers(1, 1 << 30)))
+    if rng.random() < 0.35:  # odd residues: gap / stop characters, masked and ambiguous letters, lower case, a '\r'
+        lines = fa.split(b"\n")
+        odd = b"-*xXUuBZJO.a" + b"lkde\r"
+        for li, ln in enumerate(lines):
+            if ln and not ln.startswith(b">") and rng.random() < 0.2:
+                bb = bytearray(ln)
+                for pos in rng.integers(0, len(bb), size=int(rng.integers(1, 6))):
+                    bb[int(pos)] = odd[int(rng.integers(0, len(odd)))]
+                lines[li] = bytes(bb)
+        fa = b"\n".join(lines)
     kw = dict(ssd=str(rng.choice(SEEDS)), nr=str(rng.choice(ALPHAS)), ht=int(rng.choice([50021, 1000003, 15000017, 120000000])),
               chk=int(rng.choice([50000, N // 3 + 1, 97])), step=int(rng.choice([1, 1, 2, 4])), v=int(rng.choice([500, 50, 5, 1200])),
               expect=float(rng.choice([1e-5, 1e-3, 10.0])), flt=str(rng.choice(["T", "T", "F"])),

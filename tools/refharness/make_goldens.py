@@ -48,6 +48,23 @@ def messy_fasta(rng):
     return "".join(out).encode()
 
 
+def oddchar_fasta():
+    """Residues outside the alphabet inside homologous regions: literal '-' (the reference's statistics read aligned
+    STRINGS, so a '-' residue counts like a gap character, fsearch.py:1454-1471), '*', '.', U / J / O / B / Z, x / X and lower
+    case -- a few per record, so that the alignments run across them."""
+    rng = np.random.default_rng(77)
+    base = synthprot.synthprot(60, 120, 5).decode().strip().split("\n")
+    odd = "-*.UJOBZxXak-"
+    out = []
+    for i in range(0, len(base), 2):
+        sq = list(base[i + 1])
+        if (i // 2) % 3 != 2:
+            for p in rng.integers(8, len(sq) - 8, size=int(rng.integers(1, 5))):
+                sq[int(p)] = odd[int(rng.integers(0, len(odd)))]
+        out.append(base[i] + "\n" + "".join(sq) + "\n")
+    return "".join(out).encode()
+
+
 FORCE = "--force" in sys.argv
 
 
@@ -241,6 +258,7 @@ def main():
             base + ["-s", "11111", "-r", AA9 + "/" + AA10B, "-M", "300007", "-c", "25000"])
     run_e2e(m, "toy_uniform", synthprot.uniform_proteins(60, 150, 8), base + ["-s", "111111", "-r", AA9, "-M", "5003", "-c", "50000"])
     run_e2e(m, "toy_messy", messy_fasta(rng), ["-e", "1e-3", "-v", "5", "-j", "1", "-F", "T", "-s", "111111", "-r", AA9, "-M", "1000003", "-c", "10"])
+    run_e2e(m, "toy_oddchars", oddchar_fasta(), ["-e", "1e-3", "-v", "500", "-j", "1", "-F", "T", "-s", "111111", "-r", AA9, "-M", "1000003", "-c", "50000"])
     run_e2e(m, "toy_w10", synthprot.synthprot(70, 200, 12), base + ["-s", "11111011111", "-r", AA9, "-M", "120000000", "-c", "50000"])
     refA, qryA, refB, qryB = long_sets()
     lf = ["-e", "1e-5", "-v", "500", "-j", "1", "-F", "T", "-s", "111111", "-r", AA9, "-M", "1000003", "-c", "50000"]
