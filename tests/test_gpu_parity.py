@@ -502,3 +502,43 @@ def test_no_hits_and_empty_sets(fs, tmp_path):
     assert rows == b"" and len(hits) == 0
     hits.close()
     s.close()
+
+
+def test_fasta_quirks_vs_oracle(fs, oracle, tmp_path):
+    """Record parsing exactly as fsearch.py:1543-1553 / 2182-2205: '>' only starts a record at a line start, blank lines and
+    blanks inside sequence lines stay residues or vanish as the reference's join makes them, ids end at the first space
+    (tabs stay), duplicate ids and a 300-character id, and the same records on the reference side (column 16 = whole header)."""
+    from swiftortho_amd import synthprot
+    base = synthprot.synthprot(60, 120, 5)
+    recs, cur = {}, None
+    for l in base.decode().strip().split("\n"):
+        if l.startswith(">"):
+            cur = l
+            recs[cur] = ""
+        else:
+            recs[cur] += l
+    names = list(recs)
+    s0, s1, s2 = recs[names[0]], recs[names[1]], recs[names[2]]
+    rag = b"".join([
+        b">gt_inside\n" + (s0[:40] + ">" + s0[40:]).encode() + b"\n",
+        b">blank_lines\n" + s1[:30].encode() + b"\n\n" + s1[30:].encode() + b"\n\n",
+        b">spaces in\theader\twith tabs\n" + (s2[:20] + "  " + s2[20:70] + " " + s2[70:]).encode() + b"\n",
+        b">dup\n" + s0.encode() + b"\n", b">dup\n" + s0.encode() + b"\n",
+        b">" + b"L" * 300 + b" longheader\n" + s1.encode() + b"\n",
+    ])
+    ref = base + rag
+    qp, rp, op = tmp_path / "q.fsa", tmp_path / "r.fsa", tmp_path / "o.sc"
+    qp.write_bytes(rag), rp.write_bytes(ref)
+    kw = dict(ssd="111111", expect=1e-3, v=500, step=1, ht=1000003, chk=50000)
+    r = oracle.blastp(str(qp), str(rp), str(op), **kw)
+    want = op.read_bytes()
+    assert r.nqueries == 6 and want.count(b"\n") > 12
+    s, hits, rows = gpu_rows(fs, ref, rag, dict(nr=oracle.AA9, thr=-1, max_miss=1e-3, flt="T", **kw))
+    if rows != want:
+        a, b = rows.split(b"\n"), want.split(b"\n")
+        for i in range(max(len(a), len(b))):
+            x = a[i] if i < len(a) else b"<none>"
+            y = b[i] if i < len(b) else b"<none>"
+            assert x == y, "row %d differs\n gpu: %r\n ref: %r" % (i, x, y)
+    hits.close()
+    s.close()

@@ -65,6 +65,54 @@ def oddchar_fasta():
     return "".join(out).encode()
 
 
+def fasta_quirks():
+    """Record parsing (fsearch.py:1543-1553, 2182-2205): '>' inside a line, blank lines, blanks inside sequence lines, tabs in
+    a header, duplicate ids, a 300-character id.  Returns (reference, queries)."""
+    base = synthprot.synthprot(60, 120, 5)
+    recs, cur = {}, None
+    for l in base.decode().strip().split("\n"):
+        if l.startswith(">"):
+            cur = l
+            recs[cur] = ""
+        else:
+            recs[cur] += l
+    names = list(recs)
+    s0, s1, s2 = recs[names[0]], recs[names[1]], recs[names[2]]
+    rag = b"".join([
+        b">gt_inside\n" + (s0[:40] + ">" + s0[40:]).encode() + b"\n",
+        b">blank_lines\n" + s1[:30].encode() + b"\n\n" + s1[30:].encode() + b"\n\n",
+        b">spaces in\theader\twith tabs\n" + (s2[:20] + "  " + s2[20:70] + " " + s2[70:]).encode() + b"\n",
+        b">dup\n" + s0.encode() + b"\n", b">dup\n" + s0.encode() + b"\n",
+        b">" + b"L" * 300 + b" longheader\n" + s1.encode() + b"\n",
+    ])
+    return base + rag, rag
+
+
+def ragged_queries():
+    """Query records the reference still defines: wrapped lines + description, all-X, lower case, CRLF line ends (the '\\r'
+    stays in the id and in the residues), bytes outside the alphabet, last record without a newline.  (Records shorter
+    than the seed or empty crash the reference and are our own definition: tests/test_gpu_parity.py.)"""
+    base = synthprot.synthprot(60, 120, 5)
+    recs, cur = {}, None
+    for l in base.decode().strip().split("\n"):
+        if l.startswith(">"):
+            cur = l
+            recs[cur] = ""
+        else:
+            recs[cur] += l
+    names = list(recs)
+    s0, s1 = recs[names[0]], recs[names[1]]
+    qry = b"".join([
+        (names[0] + " some description here\n").encode(), (s0[:50] + "\n" + s0[50:] + "\n").encode(),
+        b">allx\n" + b"X" * 40 + b"\n",
+        b">lower\n" + s1.lower().encode() + b"\n",
+        b">crlf\r\n" + s1[:60].encode() + b"\r\n" + s1[60:].encode() + b"\r\n",
+        b">weird\n" + (s0[:30] + "*U-J" + s0[30:]).encode() + b"\n",
+        b">last_no_newline\n" + s0.encode(),
+    ])
+    return base, qry
+
+
 FORCE = "--force" in sys.argv
 
 
@@ -259,6 +307,10 @@ def main():
     run_e2e(m, "toy_uniform", synthprot.uniform_proteins(60, 150, 8), base + ["-s", "111111", "-r", AA9, "-M", "5003", "-c", "50000"])
     run_e2e(m, "toy_messy", messy_fasta(rng), ["-e", "1e-3", "-v", "5", "-j", "1", "-F", "T", "-s", "111111", "-r", AA9, "-M", "1000003", "-c", "10"])
     run_e2e(m, "toy_oddchars", oddchar_fasta(), ["-e", "1e-3", "-v", "500", "-j", "1", "-F", "T", "-s", "111111", "-r", AA9, "-M", "1000003", "-c", "50000"])
+    qref, qqry = fasta_quirks()
+    run_e2e(m, "toy_fastaquirks", qref, ["-e", "1e-3", "-v", "500", "-j", "1", "-F", "T", "-s", "111111", "-r", AA9, "-M", "1000003", "-c", "50000"], qry=qqry)
+    rref, rqry = ragged_queries()
+    run_e2e(m, "toy_ragged", rref, ["-e", "1e-3", "-v", "500", "-j", "1", "-F", "T", "-s", "111111", "-r", AA9, "-M", "1000003", "-c", "50000"], qry=rqry)
     run_e2e(m, "toy_w10", synthprot.synthprot(70, 200, 12), base + ["-s", "11111011111", "-r", AA9, "-M", "120000000", "-c", "50000"])
     refA, qryA, refB, qryB = long_sets()
     lf = ["-e", "1e-5", "-v", "500", "-j", "1", "-F", "T", "-s", "111111", "-r", AA9, "-M", "1000003", "-c", "50000"]
