@@ -542,3 +542,47 @@ def test_fasta_quirks_vs_oracle(fs, oracle, tmp_path):
             assert x == y, "row %d differs\n gpu: %r\n ref: %r" % (i, x, y)
     hits.close()
     s.close()
+
+
+FLAG_EXTREMES = [
+    dict(rst=10, red=40), dict(rst=55, red=1000), dict(rst=0, red=1),
+    dict(chk=1), dict(chk=2), dict(chk=7, rst=3, red=33),
+    dict(v=1), dict(v=2, expect=10.0), dict(v=1000),
+    dict(step=50), dict(step=500), dict(step=3, ssd="1101011,111111"),
+    dict(st=-1, ed=5), dict(st=55, ed=1000), dict(st=70, ed=80), dict(st=30, ed=10), dict(st=59, ed=60),
+    dict(expect=0.0), dict(expect=1e300), dict(expect=1e-300),
+    dict(max_miss=0.0), dict(max_miss=5.0), dict(max_miss=0.9999),
+    dict(thr=0), dict(thr=1), dict(thr=100000),
+    dict(ht=2), dict(ht=7), dict(ht=257),
+    dict(flt="F", v=3, chk=11, step=2),
+]
+
+
+@pytest.mark.parametrize("over", FLAG_EXTREMES, ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
+def test_flag_extremes_vs_oracle(fs, oracle, tmp_path, over):
+    """Corner values of every flag of the path (-L/-U reference ranges, one-sequence chunks, -v 1, steps longer than the
+    sequences, query ranges past the end or reversed, e-value bounds 0 / 1e300, -m outside (0, 1), -t 0 / huge, 2-bucket
+    tables): rows identical to the oracle's."""
+    from swiftortho_amd import synthprot
+    fa = synthprot.synthprot(60, 110, 9)
+    p = tmp_path / "x.fsa"
+    p.write_bytes(fa)
+    o = dict(ssd="111111", nr=oracle.AA9, expect=1e-3, v=500, max_miss=1e-3, st=-1, ed=-1, rst=-1, red=-1, thr=-1, step=1, flt="T", ht=1000003,
+             chk=50000)
+    o.update(over)
+    out = tmp_path / "o.sc"
+    oracle.blastp(str(p), str(p), str(out), **o)
+    want = out.read_bytes()
+    s = fs.Searcher(ssd=o["ssd"], nr=o["nr"], ht=o["ht"], chk=o["chk"], step=o["step"], v=o["v"], thr=o["thr"], expect=o["expect"],
+                    max_miss=o["max_miss"], flt=o["flt"])
+    s.load_ref_bytes(fa, o["rst"], o["red"])
+    s.load_queries_bytes(fa)
+    hits = s.search(o["st"], o["ed"])
+    rows = b"".join(hits.rows())
+    if rows != want:
+        a, b = rows.split(b"\n"), want.split(b"\n")
+        assert len(a) == len(b), "gpu %d rows, oracle %d rows" % (len(a) - 1, len(b) - 1)
+        for i in range(len(a)):
+            assert a[i] == b[i], "row %d differs\n gpu: %r\n ref: %r" % (i, a[i], b[i])
+    hits.close()
+    s.close()
