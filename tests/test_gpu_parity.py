@@ -586,3 +586,29 @@ def test_flag_extremes_vs_oracle(fs, oracle, tmp_path, over):
             assert a[i] == b[i], "row %d differs\n gpu: %r\n ref: %r" % (i, a[i], b[i])
     hits.close()
     s.close()
+
+
+def test_tile_boundary_lengths_vs_oracle(fs, oracle, tmp_path):
+    """Sequence lengths on both sides of the 4096-residue tile size of kswat_st_long (fsearch.py:1480-1498, 3068): 4095 /
+    4096 / 4097 / 8191 / 8192 / 8193, each with a mutated copy, a prefix and a suffix, all against all."""
+    from swiftortho_amd import synthprot
+    rng = np.random.default_rng(17)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+
+    def rnd(n):
+        return aa[rng.integers(0, 20, n)].tobytes().decode()
+
+    def mut(s, d):
+        b = np.frombuffer(s.encode(), dtype=np.uint8).copy()
+        m = rng.random(len(b)) < d
+        b[m] = aa[rng.integers(0, 20, int(m.sum()))]
+        return b.tobytes().decode()
+
+    recs = []
+    for n in (4095, 4096, 4097, 8191, 8192, 8193):
+        a = rnd(n)
+        recs += [("a%d" % n, a), ("m%d" % n, mut(a, 0.12)), ("p%d" % n, mut(a[:n - 4096 + 300], 0.05) if n > 4096 else mut(a[:3000], 0.05)),
+                 ("s%d" % n, mut(a[4090:], 0.05) if n > 4400 else mut(a[3700:], 0.05))]
+    fa = "".join(">%s\n%s\n" % r for r in recs).encode() + synthprot.synthprot(40, 200, 3)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
