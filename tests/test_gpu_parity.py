@@ -612,3 +612,25 @@ def test_tile_boundary_lengths_vs_oracle(fs, oracle, tmp_path):
     fa = "".join(">%s\n%s\n" % r for r in recs).encode() + synthprot.synthprot(40, 200, 3)
     kw = dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=50000, step=1, v=500, expect=1e-5, flt="T")
     oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+
+
+@pytest.mark.parametrize("flt", ["F", "T"])
+def test_tandem_repeats_and_homopolymers_vs_oracle(fs, oracle, tmp_path, flt):
+    """Homopolymers and tandem repeats of period 2..11 (unmasked with -F F): hundreds of seed hits per diagonal, every
+    diagonal of a pair populated, long chains of overlapping segments, duplicate (qst, sst) pairs across seed patterns."""
+    from swiftortho_amd import synthprot
+    rng = np.random.default_rng(23)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    recs = []
+    for k, period in enumerate((1, 1, 2, 3, 5, 7, 11, 4, 9)):
+        unit = "".join(aa[int(x)] for x in rng.integers(0, 20, period))
+        for c in range(3):
+            n = int(rng.integers(120, 420))
+            s = (unit * (n // period + 1))[:n]
+            b = list(s)
+            for p in rng.integers(0, n, size=n // 25):  # a few point changes so copies differ
+                b[int(p)] = aa[int(rng.integers(0, 20))]
+            recs.append(("rep%d_%d_%d" % (period, k, c), "".join(b)))
+    fa = "".join(">%s\n%s\n" % r for r in recs).encode() + synthprot.synthprot(60, 150, 8)
+    kw = dict(ssd="111111,1101011", nr=oracle.AA9, ht=1000003, chk=20, step=1, v=500, expect=1e-3, flt=flt)
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
