@@ -634,3 +634,24 @@ def test_tandem_repeats_and_homopolymers_vs_oracle(fs, oracle, tmp_path, flt):
     fa = "".join(">%s\n%s\n" % r for r in recs).encode() + synthprot.synthprot(60, 150, 8)
     kw = dict(ssd="111111,1101011", nr=oracle.AA9, ht=1000003, chk=20, step=1, v=500, expect=1e-3, flt=flt)
     oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+
+
+@pytest.mark.parametrize("v", [500, 50])
+def test_massive_score_ties_vs_oracle(fs, oracle, tmp_path, v):
+    """700 identical copies of one protein plus near-copies: every candidate of a query has the same ungapped score and
+    most alignments the same bit score, so the reported set and its order are decided purely by the reference's non-stable
+    quicksort (fsearch.py:260-327) on ties -- beyond the vmax = max(100, v + 100, 1.1 v) cut as well."""
+    from swiftortho_amd import synthprot
+    rng = np.random.default_rng(31)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    core = "".join(aa[int(x)] for x in rng.integers(0, 20, 180))
+    recs = [("same%04d" % i, core) for i in range(700)]
+    for i in range(60):
+        b = list(core)
+        for p in rng.integers(0, len(b), size=int(rng.integers(1, 4))):
+            b[int(p)] = aa[int(rng.integers(0, 20))]
+        recs.append(("near%03d" % i, "".join(b)))
+    order = rng.permutation(len(recs))
+    fa = "".join(">%s\n%s\n" % recs[int(i)] for i in order).encode() + synthprot.synthprot(40, 150, 2)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=300, step=1, v=v, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path, sub=(0, 120))
