@@ -655,3 +655,17 @@ def test_massive_score_ties_vs_oracle(fs, oracle, tmp_path, v):
     fa = "".join(">%s\n%s\n" % recs[int(i)] for i in order).encode() + synthprot.synthprot(40, 150, 2)
     kw = dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=300, step=1, v=v, expect=1e-5, flt="T")
     oracle_vs_gpu(fs, oracle, fa, kw, tmp_path, sub=(0, 120))
+
+
+@pytest.mark.parametrize("lens", [(6,), (7,), (6, 6), (30,), (12, 6, 40), (6, 7, 8, 9, 10, 11, 12)])
+def test_micro_references_vs_oracle(fs, oracle, tmp_path, lens):
+    """References holding one to a handful of seed windows (the last index slot is never read, fsearch.py:2277 / 2539;
+    offset-0 seeds resolve to the previous sequence, 2638-2642): same rows as the oracle, usually none."""
+    rng = np.random.default_rng(sum(lens) * 7 + len(lens))
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    core = "".join(aa[int(x)] for x in rng.integers(0, 20, 64))
+    recs = [("s%d" % i, core[:n]) for i, n in enumerate(lens)]
+    fa = "".join(">%s\n%s\n" % r for r in recs).encode()
+    for kw in (dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=50000, step=1, v=500, expect=10.0, flt="F"),
+               dict(ssd="111111", nr=oracle.AA9, ht=13, chk=1, step=1, v=500, expect=1e300, flt="F", thr=1)):
+        oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
