@@ -36,6 +36,9 @@ for case in range(ncase):
               thr=int(rng.choice([-1, -1, 3, 40])), max_miss=float(rng.choice([1e-3, 0.5])))
     if kw["nr"].count(",") > 15 and kw["ssd"] in ("11011",):
         kw["ssd"] = "1111111"   # weight-4 seeds on a 20-letter alphabet explode the hit lists of the CPU oracle
+    if rng.random() < 0.2:  # corner values
+        kw["chk"] = int(rng.choice([1, 2, 5])); kw["step"] = int(rng.choice([7, 50]))
+    rst, red = (-1, -1) if rng.random() < 0.7 else (int(rng.integers(0, N // 2)), int(rng.integers(N // 2, N + 50)))
     lo = int(rng.integers(0, N // 2)); hi = int(min(N, lo + rng.integers(20, 120)))
     os.environ["SOHIT_BATCH"] = str(int(rng.choice([16384, 37])))
     os.environ["SOHIT_MAX_HITS"] = str(int(rng.choice([1 << 30, 50000])))
@@ -44,8 +47,8 @@ for case in range(ncase):
     p = os.path.join(d, "x.fsa"); open(p, "wb").write(fa)
     out = os.path.join(d, "o.sc")
     r = oracle.blastp(p, p, out, ssd=kw["ssd"], nr=kw["nr"], expect=kw["expect"], v=kw["v"], step=kw["step"], flt=kw["flt"], ht=kw["ht"],
-                      chk=kw["chk"], st=lo, ed=hi, thr=kw["thr"], max_miss=kw["max_miss"])
-    s = fsearch.Searcher(**kw); s.load_ref_bytes(fa); s.load_queries_bytes(fa)
+                      chk=kw["chk"], st=lo, ed=hi, thr=kw["thr"], max_miss=kw["max_miss"], rst=rst, red=red)
+    s = fsearch.Searcher(**kw); s.load_ref_bytes(fa, rst, red); s.load_queries_bytes(fa)
     h = s.search(lo, hi); rows = b"".join(h.rows()); want = open(out, "rb").read()
     ok = rows == want
     for qrel in range(r.nqueries):
@@ -62,7 +65,7 @@ for case in range(ncase):
             break
     print("case %2d %s N=%d L=%d %s rows=%d  %s" % (case, "ok  " if ok else "FAIL", N, L, "uniform" if uniform else "families", len(r.ints),
                                                     {k: kw[k] for k in ("ssd", "ht", "chk", "step", "v", "expect", "flt", "thr", "max_miss")}),
-          "alpha=%d" % ALPHAS.index(kw["nr"]), "batch", os.environ["SOHIT_BATCH"], "maxhits", os.environ["SOHIT_MAX_HITS"], flush=True)
+          "alpha=%d" % ALPHAS.index(kw["nr"]), "ref", (rst, red), "batch", os.environ["SOHIT_BATCH"], "maxhits", os.environ["SOHIT_MAX_HITS"], flush=True)
     h.close(); s.close()
     if not ok:
         bad += 1
