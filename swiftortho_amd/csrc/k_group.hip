@@ -433,10 +433,8 @@ __global__ __launch_bounds__(256) void k_best(const u64* __restrict__ sorted_qs,
     u32 qi, qj;
     if (bdist > 0) qi = 0, qj = (u32)bdist;
     else qi = (u32)(-bdist), qj = 0;
-    c_rec[4 * s + 0] = ((u32)qs & ((1u << bs) - 1u)) + seq_lo;  // global subject id
-    c_rec[4 * s + 1] = bscore;
-    c_rec[4 * s + 2] = qi;
-    c_rec[4 * s + 3] = qj;
+    // [global subject id, ungapped score, qi, qj]: one 16-byte store
+    *reinterpret_cast<uint4*>(c_rec + 4 * (size_t)s) = make_uint4(((u32)qs & ((1u << bs) - 1u)) + seq_lo, bscore, qi, qj);
 }
 
 // gather helpers for the two-pass (ft, then stable q) ordering
@@ -476,7 +474,10 @@ __global__ __launch_bounds__(256) void k_emit_cands(const u32* __restrict__ orde
     out_q[i] = q;
     const uint4 v = *reinterpret_cast<const uint4*>(c_rec + 4 * (size_t)r);
     *reinterpret_cast<uint4*>(out_rec + 4 * (size_t)i) = v;
-    if (i == 0 || c_q[order[i - 1]] != q) seg_first[q] = i;
+    // previous element's query: the neighbouring lane has it (one gather per wave instead of one per element)
+    u32 qp = __shfl_up(q, 1);
+    if ((threadIdx.x & 63u) == 0) qp = i ? c_q[order[i - 1]] : ~q;
+    if (qp != q) seg_first[q] = i;
 }
 
 __global__ __launch_bounds__(256) void k_seg_counts(const u32* __restrict__ out_q, u32 n, const u32* __restrict__ seg_first,
