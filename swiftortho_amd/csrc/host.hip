@@ -971,11 +971,13 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     const int ftbits = kl.ba + kl.bp + ft_bits_entry;
     b.order.ensure((size_t)NS + 2), b.order2.ensure((size_t)NS + 2), b.tmp64.ensure((size_t)NS + 2);
     launch_iota(b.order.p, NS, c->st);
+    int qshift = 0;  // where the query sits in the final sort's key stream (b.c_ft2)
     if (ftbits + kl.bq <= 64) {
         launch_combine_q_ft(b.c_q.p, b.c_ft.p, NS, ftbits, bsp, b.tmp64.p, c->st);
         sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, b.order.p, b.order2.p, NS, ftbits - bsp + 1 + kl.bq, c->st);
         std::swap(b.order.p, b.order2.p);
         std::swap(b.order.cap, b.order2.cap);
+        qshift = ftbits - bsp + 1;
     } else {
         sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.c_ft.p, b.c_ft2.p, b.order.p, b.order2.p, NS, ftbits, c->st);
         launch_gather_u32_as_u64(b.c_q.p, b.order2.p, NS, b.tmp64.p, c->st);
@@ -987,7 +989,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
     b.cand_rec.ensure(4 * ((size_t)base + NS) + 16, true, c->st);
     b.segfirst.ensure((size_t)b.nq + 4);
-    launch_emit_cands(b.order.p, NS, b.c_q.p, b.c_rec.p, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, b.segfirst.p, c->st);
+    launch_emit_cands(b.order.p, NS, b.c_ft2.p, qshift, b.c_rec.p, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, b.segfirst.p, c->st);
     b.chunk_base.back() = base + NS;
     c->cnt.candidates += NS;
     HIP_CHECK(hipStreamSynchronize(c->st));

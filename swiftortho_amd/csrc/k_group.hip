@@ -464,20 +464,17 @@ __global__ __launch_bounds__(256) void k_iota(u32* __restrict__ p, u32 n) {
 
 // final order -> chunk candidate region; the region is sorted by query, so per-query counts are
 // segment lengths: the thread at a segment's last element knows them without atomics.
-__global__ __launch_bounds__(256) void k_emit_cands(const u32* __restrict__ order, u32 n, const u32* __restrict__ c_q,
+__global__ __launch_bounds__(256) void k_emit_cands(const u32* __restrict__ order, u32 n, const u64* __restrict__ sorted_key, int qshift,
                                                     const u32* __restrict__ c_rec, u32* __restrict__ out_q, u32* __restrict__ out_rec,
                                                     u32* __restrict__ seg_first) {
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const u32 r = order[i];
-    const u32 q = c_q[r];
+    const u32 q = (u32)(sorted_key[i] >> qshift);  // the query sits on top of the sort word: read in order, not gathered
     out_q[i] = q;
     const uint4 v = *reinterpret_cast<const uint4*>(c_rec + 4 * (size_t)r);
     *reinterpret_cast<uint4*>(out_rec + 4 * (size_t)i) = v;
-    // previous element's query: the neighbouring lane has it (one gather per wave instead of one per element)
-    u32 qp = __shfl_up(q, 1);
-    if ((threadIdx.x & 63u) == 0) qp = i ? c_q[order[i - 1]] : ~q;
-    if (qp != q) seg_first[q] = i;
+    if (i == 0 || (u32)(sorted_key[i - 1] >> qshift) != q) seg_first[q] = i;
 }
 
 __global__ __launch_bounds__(256) void k_seg_counts(const u32* __restrict__ out_q, u32 n, const u32* __restrict__ seg_first,
@@ -549,9 +546,9 @@ void launch_iota(u32* p, u32 n, hipStream_t st) {
     hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, st, p, n);
 }
 
-void launch_emit_cands(const u32* order, u32 n, const u32* c_q, const u32* c_rec, u32* out_q, u32* out_rec, u32* qcnt,
+void launch_emit_cands(const u32* order, u32 n, const u64* sorted_key, int qshift, const u32* c_rec, u32* out_q, u32* out_rec, u32* qcnt,
                        u32* seg_first, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_emit_cands, dim3((n + 255) / 256), dim3(256), 0, st, order, n, c_q, c_rec, out_q, out_rec, seg_first);
+    hipLaunchKernelGGL(k_emit_cands, dim3((n + 255) / 256), dim3(256), 0, st, order, n, sorted_key, qshift, c_rec, out_q, out_rec, seg_first);
     hipLaunchKernelGGL(k_seg_counts, dim3((n + 255) / 256), dim3(256), 0, st, out_q, n, seg_first, qcnt);
 }

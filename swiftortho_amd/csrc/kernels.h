@@ -81,8 +81,8 @@ void launch_best(const u64* sorted_qs, const u32* idx, const u32* shead, u32 nse
 void launch_gather_u32_as_u64(const u32* src, const u32* idx, u32 n, u64* dst, hipStream_t st);
 void launch_iota(u32* p, u32 n, hipStream_t st);
 void launch_combine_q_ft(const u32* c_q, const u64* c_ft, u32 n, int ftbits, int bsp, u64* dst, hipStream_t st);
-void launch_emit_cands(const u32* order, u32 n, const u32* c_q, const u32* c_rec, u32* out_q, u32* out_rec, u32* qcnt,
-                       u32* seg_first, hipStream_t st);
+void launch_emit_cands(const u32* order, u32 n, const u64* sorted_key /*the final sort's key stream*/, int qshift /*query = key >> qshift*/,
+                       const u32* c_rec, u32* out_q, u32* out_rec, u32* qcnt, u32* seg_first, hipStream_t st);
 
 // k_align.hip
 u32 align_trace_stride(int max_rows);
