@@ -18,6 +18,8 @@ d = tempfile.mkdtemp()
 bad = 0
 for case in range(ncase):
     N = int(rng.integers(150, 1600)); L = int(rng.integers(40, 420))
+    if os.environ.get("FUZZ_LONG"):  # few, long sequences: tiled alignments, wide position fields
+        N = int(rng.integers(20, 120)); L = int(rng.integers(500, 6000))
     uniform = rng.random() < 0.25
     fa = (synthprot.uniform_proteins if uniform else synthprot.synthprot)(N, L, int(rng.integers(1, 1 << 30)))
     if rng.random() < 0.35:  # odd residues: gap / stop characters, masked and ambiguous letters, lower case, a '\r'
