@@ -33,7 +33,7 @@ typedef struct so_ctx so_ctx;
 typedef struct so_params {
     const char *seeds;    /* -s  comma-separated spaced-seed patterns, e.g. "111111"          */
     const char *alphabet; /* -r  reduced alphabet groups; '/' separates several alphabets     */
-    int64_t nc;           /* -M  number of hash buckets NC (fsearch.py:2230); must be >= 1    */
+    int64_t nc;           /* -M  number of hash buckets NC; < 1 = the reference's default (2228-2231) */
     int64_t chunk;        /* -c  reference sequences per index chunk (fsearch.py:2283-2295)   */
     int64_t step;         /* -j  reference seed step (2244); queries always use step 1 (2658) */
     int64_t max_hits;     /* -v  rows reported per query                                      */
@@ -118,6 +118,19 @@ int so_search_loaded(so_ctx *ctx, int64_t q_lo, int64_t q_hi, so_hit **hits, int
 int so_search(so_ctx *ctx, const char *qry_fasta_path, int64_t q_lo, int64_t q_hi, so_hit **hits, int64_t *n_hits);
 void so_free_hits(so_hit *hits);
 
+/* Multi-GPU support.  The reference runs one fsearch-c process per query block and joins the part files with `cat`
+ * (find_hit.py:107-146); here one process per GPU searches a query shard and the hit records are exchanged over RCCL, so
+ * they must be able to stay in HBM until after the exchange:
+ * so_search_device() = so_search_loaded() whose so_hit records (same 80-byte layout, same values) are left in device
+ * memory owned by the ctx (*d_hits, valid until the next so_search* call on the ctx or so_destroy);
+ * so_device_hits_copy() copies the first n_hits of them device-to-device into a caller-owned device buffer (e.g. the
+ * send buffer of a collective).
+ * so_query_work() fills work[0 .. q_hi-q_lo) with the number of index entries each query visits over all chunks (one
+ * hash + bucket-bounds + frequency-cap pre-pass, no search): the cost estimate used to balance query shards. */
+int so_search_device(so_ctx *ctx, int64_t q_lo, int64_t q_hi, const so_hit **d_hits, int64_t *n_hits);
+int so_device_hits_copy(so_ctx *ctx, void *dst_device, int64_t n_hits);
+int so_query_work(so_ctx *ctx, int64_t q_lo, int64_t q_hi, uint64_t *work);
+
 /* Output.  Replaces: the row formatter of entry_point (fsearch.py:3234-3258; f2s 43-61):
  * writes the 16-column tab-separated rows for hits of the currently loaded query and
  * reference files.  mode "w" or "a" (-O).  so_format_hit() renders one row into buf. */
@@ -125,6 +138,10 @@ int so_write_sc(so_ctx *ctx, const so_hit *hits, int64_t n_hits, const char *pat
 int64_t so_format_hit(so_ctx *ctx, const so_hit *hit, char *buf, int64_t cap);
 
 /* Introspection (tests, bench). */
+/* switch params.profile (HIP-event kernel timers + stage laps, which synchronise the stream) on or off */
+int so_set_profile(so_ctx *ctx, int on);
+/* NC actually in use: -M, or the reference's `bins` default when -M < 1 (fsearch.py:2228-2231) */
+int64_t so_bucket_count(const so_ctx *ctx);
 int so_get_counters(const so_ctx *ctx, so_counters *out);
 int so_reset_counters(so_ctx *ctx);
 /* "stage=ms;stage=ms;..." wall-clock laps of the pipeline stages (only with params.profile) */

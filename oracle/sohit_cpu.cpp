@@ -660,6 +660,17 @@ struct Cand {
     uint32_t subj, score, qi, qj;
 };
 
+// NC = ht < 1 and bins or ht (fsearch.py:2228-2231).  self.scale is overwritten with the parameter (-1, line 2216), so
+// bins = min(int(pow(-1, mw)) * nssp * 5, 128Mi): 5 * nssp for an even maximum seed weight; negative for an odd one
+// (an empty table and an IndexError in the reference) -> returned as is, callers refuse values < 1.
+i64 resolve_nc(const Params& p) {
+    if (p.ht >= 1) return p.ht;
+    int mw = 0;
+    for (auto& s : split(p.ssd, ',')) mw = std::max(mw, (int)std::count(s.begin(), s.end(), '1'));
+    const i64 nssp = (i64)std::count(p.ssd.begin(), p.ssd.end(), ',') + 1;
+    return std::min<i64>((mw % 2 == 0 ? 1 : -1) * nssp * 5, 128ll * 1024 * 1024);
+}
+
 struct Index {
     std::vector<std::vector<int>> codes;
     std::vector<std::string> spaces;
@@ -680,7 +691,8 @@ struct Index {
         for (auto& s : spaces) mink = std::min(mink, (int)s.size());
         offset = start_;
         offend = end_ + 1;
-        NC = p.ht;  // ht < 1 would take the reference's `bins` branch (pow(-1,mw)*nssp*5): unusable, callers always pass -M
+        NC = resolve_nc(p);
+        if (NC < 1) NC = 0;  // refused by the callers (blastp / oc_index_build)
         start.assign((size_t)NC, 0);
         i64 st = std::min<i64>(std::max<i64>(0, start_), fa.N);
         i64 ed = std::min<i64>(end_ < 0 ? fa.N : end_, fa.N);
@@ -902,6 +914,10 @@ int blastp(const char* qry, const char* ref, const Params& p0, FILE* out, Stats&
     init_b62();
     Params p = p0;
     p.max_miss = std::max(p.max_miss, 1e-3);
+    if (resolve_nc(p) < 1) {
+        fprintf(stderr, "sohit_cpu: -M < 1 with an odd seed weight gives the reference a negative table size (fsearch.py:2228-2231)\n");
+        return 2;
+    }
     Fasta seqs, DB;
     if (!seqs.load(qry) || !DB.load(ref)) return 1;
     const i64 N = seqs.N, D = DB.N;
@@ -1107,6 +1123,10 @@ void* oc_index_build(const char* fasta_bytes, i64 nbytes, const char* ssd, const
     OcIndex* o = new OcIndex();
     o->fa.from_bytes(fasta_bytes, nbytes);
     o->p.ssd = ssd, o->p.nr = nr, o->p.step = step, o->p.ht = NC;
+    if (resolve_nc(o->p) < 1) {
+        delete o;
+        return nullptr;
+    }
     o->ix.build(o->fa, o->p, start, end);
     return o;
 }

@@ -37,7 +37,8 @@ class SoCounters(C.Structure):
 EXPORTS = ["so_abi_version", "so_create", "so_destroy", "so_last_error", "so_load_ref", "so_load_ref_mem", "so_build_index", "so_drop_index",
            "so_load_queries", "so_load_queries_mem", "so_num_queries", "so_num_refs", "so_query_len", "so_search_loaded",
            "so_search", "so_free_hits", "so_write_sc", "so_format_hit", "so_get_counters", "so_reset_counters", "so_timing_report",
-           "so_chunk_threshold", "so_chunk_entries", "so_chunk_download", "so_masked_query", "so_query_candidates"]
+           "so_chunk_threshold", "so_chunk_entries", "so_chunk_download", "so_masked_query", "so_query_candidates", "so_set_profile",
+           "so_bucket_count", "so_search_device", "so_device_hits_copy", "so_query_work"]
 
 _lib = None
 
@@ -96,10 +97,16 @@ def load():
     L.so_search_loaded.argtypes = [vp, i64, i64, C.POINTER(C.POINTER(SoHit)), C.POINTER(i64)]
     L.so_search.argtypes = [vp, cp, i64, i64, C.POINTER(C.POINTER(SoHit)), C.POINTER(i64)]
     L.so_free_hits.argtypes = [C.POINTER(SoHit)]
+    L.so_search_device.argtypes = [vp, i64, i64, C.POINTER(vp), C.POINTER(i64)]
+    L.so_device_hits_copy.argtypes = [vp, vp, i64]
+    L.so_query_work.argtypes = [vp, i64, i64, vp]
     L.so_write_sc.argtypes = [vp, C.POINTER(SoHit), i64, cp, cp]
     L.so_format_hit.restype = i64
     L.so_format_hit.argtypes = [vp, C.POINTER(SoHit), cp, i64]
     L.so_get_counters.argtypes = [vp, C.POINTER(SoCounters)]
+    L.so_set_profile.argtypes = [vp, C.c_int]
+    L.so_bucket_count.restype = i64
+    L.so_bucket_count.argtypes = [vp]
     L.so_reset_counters.argtypes = [vp]
     L.so_timing_report.restype = i64
     L.so_timing_report.argtypes = [vp, cp, i64]

@@ -268,6 +268,11 @@ struct so_ctx {
     unsigned long long* h_small = nullptr;  // pinned scratch for the small device -> host reads (counts, totals): 1 KB
     std::map<std::string, double> tm;  // per-stage wall ms (only with params.profile)
     std::shared_ptr<void> batch;       // persistent per-batch scratch (struct Batch)
+    // device-resident results (so_search_device): so_hit records stay in HBM until the caller has exchanged them
+    bool dev_out = false;
+    DevBuf<u8> d_hits;
+    size_t d_hits_n = 0;
+    DevBuf<double> d_p2tab;
 };
 
 namespace {
@@ -288,9 +293,18 @@ void set_params(so_ctx* c, const so_params* p) {
     c->max_miss = std::max(p->max_miss, 1e-3);  // fsearch.py:2970
     c->filter = p->filter != 0;
     c->profile = p->profile != 0;
-    if (c->nc < 1 || c->nc > 0xFFFFFFF0ll) throw SoError("-M (bucket count) must be in [1, 2^32)");
     if (c->step < 1) throw SoError("-j (seed step) must be >= 1");
     auto pats = split(c->seeds, ',');
+    if (c->nc < 1) {
+        // NC = ht < 1 and bins or ht (fsearch.py:2228-2231); self.scale was overwritten with the parameter (-1, line 2216), so
+        // bins = min(int(pow(-1, mw)) * nssp * 5, 128Mi) = 5 * nssp for an even maximum seed weight and negative for an odd
+        // one (an empty table and an IndexError in the reference): refused.
+        int mw = 0;
+        for (auto& sp : pats) mw = std::max(mw, (int)std::count(sp.begin(), sp.end(), '1'));
+        c->nc = std::min<i64>((mw % 2 == 0 ? 1 : -1) * (i64)pats.size() * 5, 128ll * 1024 * 1024);
+        if (c->nc < 1) throw SoError("-M < 1 with an odd maximum seed weight: the reference derives a negative bucket count (fsearch.py:2228-2231); pass -M");
+    }
+    if (c->nc > 0xFFFFFFF0ll) throw SoError("-M (bucket count) must be < 2^32");
     auto alphas = split(c->alphabet, '/');
     if (pats.empty() || (int)pats.size() > MAX_PATTERNS) throw SoError("1.." + std::to_string(MAX_PATTERNS) + " seed patterns supported");
     if (alphas.empty() || (int)alphas.size() > MAX_ALPHA) throw SoError("1.." + std::to_string(MAX_ALPHA) + " alphabets supported");
@@ -790,14 +804,12 @@ struct ProfTimer {
 // seed stage of one (batch, chunk): candidates appended to the batch's candidate store
 void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageClock& sc);
 
-void seed_stage(so_ctx* c, Batch& b, int ci) {
+// bucket bounds of every query window in chunk ci, frequency cap, and the number of index entries each query of the
+// batch will visit there (pinned host array, valid until the next call)
+const unsigned long long* chunk_qhits(so_ctx* c, Batch& b, int ci) {
     ChunkIndex& ch = *c->chunks[ci];
     const int AS = c->cfg.A * c->cfg.S;
     const u32 Ppad = b.dev.Ppad, NC = (u32)c->nc;
-    const u32 nseq_chunk = (u32)(ch.seq_hi - ch.seq_lo);
-    b.chunk_base.push_back(b.chunk_base.empty() ? 0u : b.chunk_base.back());
-    if (nseq_chunk == 0 || ch.E == 0 || b.nq == 0) return;
-    StageClock sc(c);
     {
         ProfTimer pt(c, &c->cnt.bounds_ms, &c->cnt.bounds_launches);
         launch_bounds(b.qbucket.p, Ppad, AS, ch.hkey.p, ch.hval.p, ch.hshift, ch.hmask, NC, ch.E, b.sbeg.p, b.scnt.p, b.pcnt.p, c->st);
@@ -809,8 +821,6 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     if (c->thr >= 1 || threshold == 0) threshold = c->thr;  // `thr < 1 and DB.threshold or thr`, fsearch.py:2992
     b.qhits.ensure((size_t)b.nq + 2);
     launch_cap(b.korder.p, b.dev.d_off.p, b.nq, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, c->st);
-    // Split the batch into query sub-ranges whose seed hits fit the per-pass budget (keys, sort
-    // scratch and group arrays are sized by it; 32-bit hit ordinals need < 2^32 per pass).
     if (c->h_qhits_cap < b.nq) {  // pinned: a pageable read of this array costs more than the kernels around it
         if (c->h_qhits) (void)hipHostFree(c->h_qhits);
         c->h_qhits_cap = (size_t)b.nq + 1024;
@@ -819,6 +829,18 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     unsigned long long* qh = c->h_qhits;
     HIP_CHECK(hipMemcpyAsync(qh, b.qhits.p, (size_t)b.nq * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
     HIP_CHECK(hipStreamSynchronize(c->st));
+    return qh;
+}
+
+void seed_stage(so_ctx* c, Batch& b, int ci) {
+    ChunkIndex& ch = *c->chunks[ci];
+    const u32 nseq_chunk = (u32)(ch.seq_hi - ch.seq_lo);
+    b.chunk_base.push_back(b.chunk_base.empty() ? 0u : b.chunk_base.back());
+    if (nseq_chunk == 0 || ch.E == 0 || b.nq == 0) return;
+    StageClock sc(c);
+    // Split the batch into query sub-ranges whose seed hits fit the per-pass budget (keys, sort
+    // scratch and group arrays are sized by it; 32-bit hit ordinals need < 2^32 per pass).
+    const unsigned long long* qh = chunk_qhits(c, b, ci);
     const unsigned long long budget = c->max_hits_per_pass;
     u32 qa = 0;
     while (qa < b.nq) {
@@ -1178,6 +1200,22 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         sc.lap("phase2.trace_pass");
         b.outrec.ensure(12 * (size_t)NO + 16);
         launch_emit_hits(b.tasks.p, b.ares.p, b.toff.p, b.sel.p, b.nout.p, b.ooff.p, b.bits.p, nq, b.outrec.p, c->st);
+        if (c->dev_out) {
+            // device-resident results: the so_hit records are built in HBM and appended to the ctx's result buffer
+            if (!c->d_p2tab.p) {
+                std::vector<double> p2(1200);
+                for (int k = 0; k < 1200; ++k) p2[k] = p_pow(2, (double)(-k));  // bit2e's pow(2, -bit): exact powers of two from libm
+                c->d_p2tab.ensure(1200);
+                HIP_CHECK(hipMemcpy(c->d_p2tab.p, p2.data(), 1200 * sizeof(double), hipMemcpyHostToDevice));
+            }
+            c->d_hits.ensure((c->d_hits_n + NO) * sizeof(so_hit) + 256, true, c->st);
+            launch_make_hits(b.outrec.p, NO, b.q_lo, c->qry.d_off.p, c->ref.d_off.p, c->ref.N, c->d_p2tab.p, 1200,
+                             c->d_hits.p + c->d_hits_n * sizeof(so_hit), c->st);
+            c->d_hits_n += NO;
+            sc.lap("phase2.emit_device");
+            c->cnt.phase2_ms += (wall() - t0) * 1e3;
+            return;
+        }
         emit_join(c, out);  // the previous batch's job reads the staging buffer and writes into `out`
         sc.lap("phase2.emit_host");
         // pinned staging buffer: pageable D2H runs at ~1 GB/s, pinned at PCIe speed
@@ -1290,7 +1328,7 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
         }
     }
     emit_join(c, out);  // the last batch's rows
-    c->cnt.rows += (i64)out.n;
+    c->cnt.rows += c->dev_out ? (i64)c->d_hits_n : (i64)out.n;
     c->cnt.total_ms += (wall() - t0) * 1e3;
 }
 
@@ -1389,6 +1427,39 @@ void load_queries_common(so_ctx* c) {
     }
     HIP_CHECK(hipStreamSynchronize(c->st));
     c->qry_loaded = true;
+}
+
+// per-query seed-hit counts over all chunks (what the lookup kernel will visit): the work estimate used to shard queries
+void query_work(so_ctx* c, i64 q_lo, i64 q_hi, u64* out) {
+    if (!c->ref_loaded) throw SoError("so_query_work: no reference loaded");
+    if (!c->qry_loaded) throw SoError("so_query_work: no queries loaded");
+    build_index(c);
+    const i64 N = c->qry.N;
+    i64 st = std::min<i64>(std::max<i64>(0, q_lo), N), ed = std::min<i64>(q_hi < 0 ? N : q_hi, N);
+    if (const char* e = getenv("SOHIT_BATCH")) c->max_batch = (u32)std::max(1, atoi(e));
+    const bool prof = c->profile;
+    c->profile = false;  // a pre-pass, not part of any timed stage
+    try {
+        for (i64 b0 = st; b0 < ed; b0 += c->max_batch) {
+            const i64 b1 = std::min<i64>(ed, b0 + c->max_batch);
+            if (!c->batch) c->batch = std::make_shared<Batch>();
+            Batch& b = *static_cast<Batch*>(c->batch.get());
+            const so_counters keep = c->cnt;
+            prepare_batch(c, b, b0, b1);
+            c->cnt = keep;
+            for (u32 i = 0; i < b.nq; ++i) out[b0 - st + i] = 0;
+            for (int ci = 0; ci < (int)c->chunks.size(); ++ci) {
+                ChunkIndex& ch = *c->chunks[ci];
+                if (ch.seq_hi == ch.seq_lo || ch.E == 0 || b.nq == 0) continue;
+                const unsigned long long* qh = chunk_qhits(c, b, ci);
+                for (u32 i = 0; i < b.nq; ++i) out[b0 - st + i] += qh[i];
+            }
+        }
+    } catch (...) {
+        c->profile = prof;
+        throw;
+    }
+    c->profile = prof;
 }
 
 template <class F>
@@ -1519,6 +1590,43 @@ int so_search(so_ctx* c, const char* qry_path, int64_t q_lo, int64_t q_hi, so_hi
 
 void so_free_hits(so_hit* hits) { free(hits); }
 
+int so_search_device(so_ctx* c, int64_t q_lo, int64_t q_hi, const so_hit** d_hits, int64_t* n_hits) {
+    return guarded(c, [&] {
+        if (!n_hits) throw SoError("so_search_device: n_hits is NULL");
+        *n_hits = 0;
+        if (d_hits) *d_hits = nullptr;
+        c->d_hits_n = 0;
+        c->dev_out = true;
+        HitBuf none;
+        try {
+            search_loaded(c, q_lo, q_hi, none);
+        } catch (...) {
+            c->dev_out = false;
+            throw;
+        }
+        c->dev_out = false;
+        HIP_CHECK(hipStreamSynchronize(c->st));
+        *n_hits = (int64_t)c->d_hits_n;
+        if (d_hits) *d_hits = (const so_hit*)c->d_hits.p;
+    });
+}
+
+int so_device_hits_copy(so_ctx* c, void* dst_device, int64_t n_hits) {
+    return guarded(c, [&] {
+        if (n_hits < 0 || (size_t)n_hits > c->d_hits_n) throw SoError("so_device_hits_copy: more records requested than the last so_search_device produced");
+        if (n_hits && !dst_device) throw SoError("so_device_hits_copy: destination is NULL");
+        if (n_hits) HIP_CHECK(hipMemcpyAsync(dst_device, c->d_hits.p, (size_t)n_hits * sizeof(so_hit), hipMemcpyDeviceToDevice, c->st));
+        HIP_CHECK(hipStreamSynchronize(c->st));
+    });
+}
+
+int so_query_work(so_ctx* c, int64_t q_lo, int64_t q_hi, uint64_t* work) {
+    return guarded(c, [&] {
+        if (!work) throw SoError("so_query_work: output is NULL");
+        query_work(c, q_lo, q_hi, work);
+    });
+}
+
 int64_t so_format_hit(so_ctx* c, const so_hit* hit, char* buf, int64_t cap) {
     int64_t need = -1;
     guarded(c, [&] {
@@ -1538,17 +1646,32 @@ int so_write_sc(so_ctx* c, const so_hit* hits, int64_t n, const char* path, cons
         FILE* f = fopen(path, (mode && mode[0] == 'a') ? "ab" : "wb");
         if (!f) throw SoError(std::string("cannot open output ") + path);
         std::string buf;
-        for (int64_t i = 0; i < n; ++i) {
-            buf += format_hit(c, hits[i]);
-            if (buf.size() > (1u << 22)) {
-                fwrite(buf.data(), 1, buf.size(), f);
-                buf.clear();
+        bool ok = true;
+        try {
+            for (int64_t i = 0; i < n && ok; ++i) {
+                buf += format_hit(c, hits[i]);
+                if (buf.size() > (1u << 22)) {
+                    ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+                    buf.clear();
+                }
             }
+        } catch (...) {
+            fclose(f);
+            throw;
         }
-        if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
-        fclose(f);
+        if (ok && !buf.empty()) ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+        if (fclose(f) != 0) ok = false;
+        if (!ok) throw SoError(std::string("short write to ") + path + " (disk full or I/O error)");
     });
 }
+
+int so_set_profile(so_ctx* c, int on) {
+    if (!c) return 1;
+    c->profile = on != 0;
+    return 0;
+}
+
+int64_t so_bucket_count(const so_ctx* c) { return c ? c->nc : -1; }
 
 int so_get_counters(const so_ctx* c, so_counters* out) {
     if (!c || !out) return 1;

@@ -304,6 +304,36 @@ __global__ __launch_bounds__(64) void k_emit_hits(const AlnTask* __restrict__ ta
     }
 }
 
+// so_hit records (include/sohit.h: 2 x i64, 2 x f64, 12 x i32 = 80 bytes) built on the device from the 12-int rows of k_emit_hits,
+// for the device-resident result path (so_search_device).  Same IEEE expressions as the host emission in host.hip:
+// identity = matches * (100. / aln) (fsearch.py:1458-1459, 1471), e = D * qlen * slen * 2^-bit (1086) with the powers of two from
+// a table filled by libm on the host.  The library is built with -ffp-contract=off.
+struct DevHit {
+    long long qidx, sidx;
+    double identity, evalue;
+    int aln, mis, gap, qst, qed, sst, sed, bit, qlen, slen, matches, ungapped;
+};
+static_assert(sizeof(DevHit) == 80, "so_hit layout");
+
+__global__ __launch_bounds__(256) void k_make_hits(const int* __restrict__ rows, u32 n, long long q_lo, const u32* __restrict__ qoff_abs,
+                                                   const u32* __restrict__ roff, long long D, const double* __restrict__ p2tab, int p2n,
+                                                   DevHit* __restrict__ out) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const int* v = rows + 12 * (size_t)i;
+    DevHit h;
+    h.qidx = q_lo + v[0];
+    h.sidx = v[1];
+    h.aln = v[2], h.mis = v[3], h.gap = v[4], h.qst = v[5], h.qed = v[6], h.sst = v[7], h.sed = v[8], h.bit = v[9];
+    h.ungapped = v[10], h.matches = v[11];
+    h.qlen = (int)(qoff_abs[h.qidx + 1] - qoff_abs[h.qidx]);
+    h.slen = (int)(roff[h.sidx + 1] - roff[h.sidx]);
+    h.identity = (double)h.matches * (100. / (double)h.aln);
+    const double pw = (h.bit >= 0 && h.bit < p2n) ? p2tab[h.bit] : (h.bit < 0 ? ldexp(1.0, -h.bit) : 0.0);
+    h.evalue = (double)(D * (long long)h.qlen * (long long)h.slen) * pw;
+    out[i] = h;
+}
+
 __global__ __launch_bounds__(256) void k_sum_cells(const AlnRes* __restrict__ res, u32 n, unsigned long long* __restrict__ total) {
     __shared__ unsigned long long s_w[4];
     unsigned long long c = 0;
@@ -386,4 +416,11 @@ void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, 
 void launch_sum_cells(const AlnRes* res, u32 n, unsigned long long* total, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(k_sum_cells, dim3(std::min<u32>(128u, (n + 255) / 256)), dim3(256), 0, st, res, n, total);
+}
+
+void launch_make_hits(const int* rows, u32 n, i64 q_lo, const u32* qoff_abs, const u32* roff, i64 D, const double* p2tab, int p2n, void* out,
+                      hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_make_hits, dim3((n + 255) / 256), dim3(256), 0, st, rows, n, (long long)q_lo, qoff_abs, roff, (long long)D, p2tab, p2n,
+                       (DevHit*)out);
 }

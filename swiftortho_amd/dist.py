@@ -3,14 +3,22 @@ reference index replicated (each rank builds it locally: deterministic, no broad
 per-rank hit records gathered to rank 0 with torch.distributed (backend "nccl" == RCCL over
 xGMI on ROCm; "gloo" in the CPU tests).  The reference's equivalent is find_hit.py's pool of
 `fsearch-c` processes over query blocks joined with `cat` (find_hit.py:107-146).
+
+Shards are contiguous query ranges (so the concatenation of per-rank outputs is in ascending query
+order, like the reference's block files) balanced by a per-query WEIGHT: the number of index entries
+the query visits (Searcher.query_work(): one bounds + cap pre-pass) plus its residues -- seed hits,
+ungapped extensions and alignments all grow with the size of the query's family, residues do not.
+The exchange is a size-exact gatherv of records that are still in HBM: one all_gather of byte counts,
+then grouped send/recv into ONE destination buffer of sum(sizes) bytes on rank 0 (no padding to the
+largest rank), and a single device-to-host copy there.
 """
 import numpy as np
 
 
-def shard_queries(lengths, world, lo=0, hi=None):
-    """Contiguous query ranges [lo_r, hi_r), r = 0..world-1, balanced by residues.
+def shard_queries(weights, world, lo=0, hi=None):
+    """Contiguous query ranges [lo_r, hi_r), r = 0..world-1, balanced by `weights` (per-query cost; residues or work).
     Contiguity keeps the concatenation of per-rank outputs in ascending query order."""
-    lengths = np.asarray(lengths, dtype=np.int64)
+    lengths = np.asarray(weights, dtype=np.int64)
     hi = len(lengths) if hi is None or hi < 0 else min(hi, len(lengths))
     lo = max(0, lo)
     if hi <= lo:
@@ -21,9 +29,82 @@ def shard_queries(lengths, world, lo=0, hi=None):
     for r in range(1, world):
         target = total * r / world
         k = int(np.searchsorted(cum, target, side="left"))
+        # the boundary nearest to the target (a huge query next to the cut goes to the lighter side)
+        if k > 0 and k < len(cum) and abs(cum[k - 1] - target) <= abs(cum[k] - target):
+            k -= 1
         bounds.append(lo + min(max(k, bounds[-1] - lo), hi - lo))
     bounds.append(hi)
     return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def imbalance(weights, shards):
+    """max / mean of the per-shard weight sums"""
+    w = np.asarray(weights, dtype=np.int64)
+    sums = np.array([int(w[a:b].sum()) for a, b in shards], dtype=np.float64)
+    return float(sums.max() / max(sums.mean(), 1e-300))
+
+
+class GatheredDevice:
+    """Result of gather_device_records on the destination rank: `sizes` (bytes per rank) and ONE tensor of sum(sizes)
+    bytes holding the ranks' records back to back in rank order (on the GPU with RCCL, on the host with gloo)."""
+
+    def __init__(self, buf, sizes):
+        self.buf, self.sizes = buf, sizes
+        self._host = None
+
+    def to_host(self):
+        """-> uint8 numpy array of all records (one device-to-host copy through a pinned buffer)."""
+        if self._host is None:
+            if self.buf.is_cuda:
+                import torch
+                host = _staging("recv", self.buf.numel(), True)
+                host[:self.buf.numel()].copy_(self.buf, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                self._host = host[:self.buf.numel()].numpy()
+            else:
+                self._host = self.buf.numpy()
+        return self._host
+
+    def arrays(self):
+        h = self.to_host()
+        offs = np.concatenate([[0], np.cumsum(self.sizes)])
+        return [h[offs[r]:offs[r + 1]] for r in range(len(self.sizes))]
+
+
+def gather_device_records(t, dst=0):
+    """Gather one uint8 torch tensor of packed hit records per rank to rank `dst`, size-exact.
+
+    With the RCCL backend `t` is a device tensor and nothing touches the host: all_gather of the byte counts, then one
+    grouped batch of point-to-point transfers (isend on the sources, irecv into disjoint slices of a single
+    sum(sizes)-byte device buffer on `dst`) -- xGMI links are point to point, so this is what a gatherv is on this
+    fabric anyway.  With gloo (CPU tests / one-GPU functional runs) the same flow runs on host tensors."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    on_gpu = dist.get_backend() == "nccl"
+    t = t.reshape(-1)
+    if not on_gpu and t.is_cuda:
+        t = t.cpu()
+    dev = t.device
+    n = int(t.numel())
+    sizes_t = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes_t, torch.tensor([n], dtype=torch.int64, device=dev))
+    sizes = [int(x) for x in sizes_t.cpu().tolist()]
+    if rank == dst:
+        total = sum(sizes)
+        recv = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)[:total]
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        if n:
+            recv[offs[rank]:offs[rank + 1]].copy_(t)
+        ops = [dist.P2POp(dist.irecv, recv[offs[r]:offs[r + 1]], r) for r in range(world) if r != dst and sizes[r]]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return GatheredDevice(recv, sizes)
+    if n:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, dst)]):
+            w.wait()
+    return None
 
 
 _pinned = {}  # reusable pinned staging tensors, keyed by role
@@ -38,70 +119,12 @@ def _staging(role, nbytes, pin):
     return buf
 
 
-class Gathered:
-    """Result of gather_records on the destination rank: `sizes` (bytes per rank) is available at once, the
-    records themselves after the device-to-host copy has finished (`arrays()` waits for it), so a caller that
-    pipelines -- bench.py -- lets that copy run under its next step."""
-
-    def __init__(self, host, sizes, mx, event):
-        self._host, self.sizes, self._mx, self._event = host, sizes, mx, event
-
-    def arrays(self):
-        if self._event is not None:
-            self._event.synchronize()
-        h = self._host.numpy()
-        return [h[r * self._mx:r * self._mx + n] for r, n in enumerate(self.sizes)]
-
-
-_send_done = [None]  # event after the last host-to-device copy out of the pinned send buffer
-
-
-def gather_records(view, device=None, dst=0):
-    """Gather one uint8 numpy array (the packed hit records of this rank) per rank to rank `dst`.
-
-    Returns a `Gathered` on `dst` (its arrays are views into one pinned host buffer, valid until the next
-    call), None elsewhere.  One all_gather of the sizes, one padded gather (gatherv) over RCCL, one
-    device-to-host copy; staging buffers are pinned and reused."""
+def gather_bytes(payload, dst=0):
+    """bytes in, list of bytes out on `dst` (host-side convenience over gather_device_records; tests)."""
     import torch
     import torch.distributed as dist
-    world, rank = dist.get_world_size(), dist.get_rank()
-    on_gpu = dist.get_backend() == "nccl"
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-    view = np.ascontiguousarray(view, dtype=np.uint8).reshape(-1)
-    n = int(view.nbytes)
-    sizes_t = torch.zeros(world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(sizes_t, torch.tensor([n], dtype=torch.int64, device=device))
-    sizes = [int(x) for x in sizes_t.cpu().tolist()]
-    mx = max(max(sizes), 1)
-    send = _staging("send", mx, on_gpu)
-    if on_gpu and _send_done[0] is not None:
-        _send_done[0].synchronize()  # the previous call's copy out of this buffer
-    if n:
-        send.numpy()[:n] = view
-    if on_gpu:
-        gsend = send[:mx].to(device, non_blocking=True)
-        _send_done[0] = torch.cuda.Event()
-        _send_done[0].record()
-    else:
-        gsend = send[:mx]
-    if rank == dst:
-        recv = torch.empty(world * mx, dtype=torch.uint8, device=device)
-        dist.gather(gsend, [recv[r * mx:(r + 1) * mx] for r in range(world)], dst=dst)
-        event = None
-        if on_gpu:
-            host = _staging("recv", world * mx, True)
-            host[:world * mx].copy_(recv, non_blocking=True)
-            event = torch.cuda.Event()
-            event.record()
-        else:
-            host = recv
-        return Gathered(host, sizes, mx, event)
-    dist.gather(gsend, None, dst=dst)
-    return None
-
-
-def gather_bytes(payload, device=None, dst=0):
-    """bytes in, list of bytes out on `dst` (copies; the bench and the CLI use gather_records)."""
-    g = gather_records(np.frombuffer(payload, dtype=np.uint8) if payload else np.zeros(0, dtype=np.uint8), device, dst)
+    t = torch.frombuffer(bytearray(payload), dtype=torch.uint8) if payload else torch.zeros(0, dtype=torch.uint8)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    g = gather_device_records(t, dst)
     return None if g is None else [p.tobytes() for p in g.arrays()]

@@ -10,7 +10,7 @@ Reference behaviour mirrored (bin/find_hit.py:194-358):
     block order, 135-146).
 Differences by design: `-a` is the number of GPUs (one process per GPU, queries sharded, hit
 records gathered over RCCL) instead of CPU worker processes; nothing is spilled to `-T`.
-Not implemented yet: the >= 4.2e9-byte reference split/merge (303-351) -- such inputs are refused.
+The >= 4.2e9-byte reference split + `sort -m | awk` merge (303-351) is reproduced (reference_parts / merge_parts).
 """
 import os
 import subprocess
@@ -68,13 +68,30 @@ def searcher_kwargs(p, device=0):
                 max_miss=p['miss'], flt=p['flt'], device=device)
 
 
+def query_range(start, end, n_queries, ncpu=1):
+    """The query ordinals the reference launcher ends up searching (find_hit.py:95-132): Start < 0 -> 0, End < 0 -> N (the
+    QUERY count, not the native's min(D, N) rule of fsearch.py:2981 -- the launcher always passes explicit -l/-u); blocks
+    [st, min(N, st + Step)) for st in range(Start, End, Step), Step = max(min(10000, |End - Start| // ncpu), 1).  The last
+    block is clipped to N but NOT to End, so up to Step - 1 queries past -u are searched too; reproduced."""
+    N = n_queries
+    Start = 0 if start < 0 else start
+    End = N if end < 0 else end
+    Step = max(min(10000, abs(End - Start) // max(1, ncpu)), 1)
+    sts = range(Start, End, Step)
+    if len(sts) == 0:
+        return 0, 0
+    lo, hi = min(Start, N), min(N, sts[-1] + Step)
+    return lo, max(lo, hi)
+
+
 def run_single(p):
     from . import fsearch
     s = fsearch.Searcher(**searcher_kwargs(p))
     try:
         s.load_ref(p['ref'], p['rstart'], p['rend'])
         s.load_queries(p['qry'])
-        hits = s.search(p['start'], p['end'])
+        st, ed = query_range(p['start'], p['end'], s.num_queries, p['ngpu'])
+        hits = s.search(st, ed)
         hits.write(p['outfile'], 'w')
         n = len(hits)
         hits.close()
@@ -87,8 +104,7 @@ def run_rank(p):
     """One rank of a multi-GPU run (launched by torch.distributed.run)."""
     import torch
     import torch.distributed as dist
-    from . import _lib, dist as sdist, fsearch
-    import ctypes as C
+    from . import dist as sdist, fsearch
     rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ.get('LOCAL_RANK', 0))
     # SOHIT_BENCH_BACKEND=gloo + SOHIT_BENCH_ONE_GPU=1: functional test of the -a N flow on a 1-GPU box (as in bench.py)
     backend = os.environ.get('SOHIT_BENCH_BACKEND', 'nccl')
@@ -104,24 +120,117 @@ def run_rank(p):
         s.load_ref(p['ref'], p['rstart'], p['rend'])
         s.load_queries(p['qry'])
         lens = s.query_lengths()
-        N, D = len(lens), s.num_refs
-        st = min(max(0, p['start']), N)
-        ed = min(D if p['end'] < 0 else p['end'], N)   # fsearch.py:2980-2981
-        lo, hi = sdist.shard_queries(lens, world, st, ed)[rank]
-        hits = s.search(lo, hi) if hi > lo else None
-        import numpy as np
-        g = sdist.gather_records(hits.view_u8() if hits is not None else np.zeros(0, dtype=np.uint8))
+        st, ed = query_range(p['start'], p['end'], len(lens), p['ngpu'])
+        # shards balanced by per-query work (index entries visited + residues), not residues alone: family sizes are skewed
+        weights = lens.copy()
+        if ed > st:
+            weights[st:ed] += s.query_work(st, ed)
+        lo, hi = sdist.shard_queries(weights, world, st, ed)[rank]
+        dev = s.search_device(lo, hi)   # hi == lo: an empty result, still takes part in the exchange
+        g = sdist.gather_device_records(dev.tensor())
         if rank == 0:
-            # ranks hold contiguous ascending query ranges: writing their blocks in rank order keeps the file order
-            for r, part in enumerate(g.arrays()):
-                n = len(part) // C.sizeof(_lib.SoHit)
-                arr = (_lib.SoHit * max(n, 1)).from_buffer_copy(part.tobytes() + b'\0' * (C.sizeof(_lib.SoHit) if n == 0 else 0))
-                s._chk(s.L.so_write_sc(s.h, arr, n, os.fsencode(p['outfile']), b'w' if r == 0 else b'a'))
-        if hits is not None:
-            hits.close()
+            # ranks hold contiguous ascending query ranges: their records back to back are the file order
+            arr, n = fsearch.hits_from_bytes(s, g.to_host())
+            s._chk(s.L.so_write_sc(s.h, arr, n, os.fsencode(p['outfile']), b'w'))
+        dev.close()
     finally:
         s.close()
         dist.destroy_process_group()
+
+
+def fasta_parse(f):
+    """find_hit.py:23-37 (the launcher's own parser, used only by the split path): header = line minus '>' and its last
+    character, sequence lines stripped and joined; a record without sequence lines is dropped."""
+    head, seq = '', []
+    for i in f:
+        if i.startswith('>'):
+            if seq:
+                yield head, ''.join(seq)
+            head, seq = i[1:-1], []
+        else:
+            seq.append(i.strip())
+    if seq:
+        yield head, ''.join(seq)
+
+
+def reference_parts(path, max_chr):
+    """find_hit.py:303-344: consecutive records are written to a part until the running character count (header + residues)
+    has exceeded max_chr; the record that opens a new part is counted twice (`flag_chr = l_chr` then `+= l_chr`).
+    Yields the text of each part ('>%s\\n%s\\n' per record)."""
+    cur, flag_chr = [], 0
+    with open(path, 'r', encoding='latin-1') as f:
+        for hd, sq in fasta_parse(f):
+            l_chr = len(hd) + len(sq)
+            if flag_chr > max_chr:
+                yield ''.join(cur)
+                cur, flag_chr = [], l_chr
+            flag_chr += l_chr
+            cur.append('>%s\n%s\n' % (hd, sq))
+    if cur:
+        yield ''.join(cur)
+
+
+def _num_prefix(tok):
+    """`sort -n` key: the leading decimal number of the field, 0 when there is none."""
+    import re
+    m = re.match(rb'\s*(-?\d*\.?\d*)', tok)
+    t = m.group(1) if m else b''
+    try:
+        return float(t) if t not in (b'', b'-', b'.', b'-.') else 0.0
+    except ValueError:
+        return 0.0
+
+
+def merge_parts(part_files, bv, out_path):
+    """find_hit.py:349: `sort -m -k15,15n -k12,12nr parts/*.sc | awk '{if(c[$1]<bv) print $0;c[$1]+=1}' > OUTFILE`.
+    A k-way MERGE (inputs are not re-sorted) of the part files in glob order (bytewise: 0.sc, 1.sc, 10.sc, 2.sc ...) by
+    (column 15 numeric, column 12 numeric descending, then the whole line bytewise -- the C-locale last resort; equal lines
+    keep file order); then at most bv rows per distinct column 1.  Fields are blank-separated as in sort/awk."""
+    import heapq
+
+    def key(line, k):
+        f = line.split()
+        return (_num_prefix(f[14]) if len(f) > 14 else 0.0, -(_num_prefix(f[11]) if len(f) > 11 else 0.0), line, k)
+
+    files = [open(pf, 'rb') for pf in part_files]
+    heap = []
+    for k, f in enumerate(files):
+        line = f.readline()
+        if line:
+            heapq.heappush(heap, key(line, k))
+    seen = {}
+    with open(out_path, 'wb') as out:
+        while heap:
+            _, _, line, k = heapq.heappop(heap)
+            f = line.split()
+            q = f[0] if f else b''
+            c = seen.get(q, 0)
+            if c < bv:
+                out.write(line if line.endswith(b'\n') else line + b'\n')
+            seen[q] = c + 1
+            nxt = files[k].readline()
+            if nxt:
+                heapq.heappush(heap, key(nxt, k))
+    for f in files:
+        f.close()
+
+
+def search_to_file(p, argv):
+    """One reference file -> one output file: in-process on one GPU, or one rank per GPU through torch.distributed.run."""
+    if p['ngpu'] <= 1:
+        run_single(p)
+        return 0
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:  # a free rendezvous port, so concurrent runs do not collide
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    # -d / -o repeated at the end: the flag grammar keeps the last occurrence (the split path searches part files)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(p['ngpu']), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv[1:] + ['-d', p['ref'], '-o', p['outfile']]
+    env = dict(os.environ)
+    env.pop('SWIFTORTHO_MAX_CHR', None)  # the ranks search the file they are given
+    env['PYTHONPATH'] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + env.get('PYTHONPATH', '')
+    return subprocess.call(cmd, env=env)
 
 
 def main(argv=None):
@@ -135,20 +244,30 @@ def main(argv=None):
     if not p['outfile']:
         print('-o is required (the reference names its part files after it, find_hit.py:110)')
         raise SystemExit()
-    if os.path.getsize(p['ref']) >= 4200000000:
-        raise SystemExit('reference files >= 4.2e9 bytes need the split/merge path (find_hit.py:303-351), not implemented yet')
     if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) > 1:
         run_rank(p)
         return 0
-    if p['ngpu'] <= 1:
-        run_single(p)
-        return 0
-    port = 29500 + (os.getpid() % 2000)
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(p['ngpu']), '--master-addr',
-           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv[1:]
-    env = dict(os.environ)
-    env['PYTHONPATH'] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + env.get('PYTHONPATH', '')
-    return subprocess.call(cmd, env=env)
+    # find_hit.py:286-351.  SWIFTORTHO_MAX_CHR stands in for the author's commented test value (line 288).
+    max_chr = int(os.environ.get('SWIFTORTHO_MAX_CHR', '4200000000'))
+    if os.path.getsize(p['ref']) < max_chr:
+        return search_to_file(p, argv)
+    # Reference files of >= max_chr bytes: the reference searches consecutive parts as separate databases (so D, the chunk
+    # boundaries and the per-chunk thresholds are those of the part) and merges the part outputs.  288 GB of HBM would hold
+    # the whole file, but the rows would differ; the observable behaviour is kept instead.
+    import shutil
+    ref_dir = '%s_parts' % p['ref']
+    os.makedirs(ref_dir, exist_ok=True)
+    part_ref = os.path.join(ref_dir, 'ref.fsa')
+    outs, rc = [], 0
+    for k, text in enumerate(reference_parts(p['ref'], max_chr)):
+        with open(part_ref, 'w', encoding='latin-1', newline='') as f:
+            f.write(text)
+        q = dict(p, ref=part_ref, outfile=os.path.join(ref_dir, '%d.sc' % k))
+        rc = search_to_file(q, argv) or rc
+        outs.append(q['outfile'])
+    merge_parts(sorted(o for o in outs if os.path.isfile(o)), p['bv'], p['outfile'])
+    shutil.rmtree(ref_dir, ignore_errors=True)
+    return rc
 
 
 if __name__ == '__main__':

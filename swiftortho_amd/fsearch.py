@@ -39,7 +39,7 @@ class Searcher:
         self.h = self.L.so_create(int(device), C.byref(p))
         if not self.h:
             raise SohitError(self.L.so_last_error(None).decode())
-        self.nc = int(ht)
+        self.nc = int(self.L.so_bucket_count(self.h))  # -M, or the reference's `bins` default when -M < 1
 
     def close(self):
         if getattr(self, "h", None):
@@ -92,10 +92,29 @@ class Searcher:
         self._chk(self.L.so_search_loaded(self.h, st, ed, C.byref(hits), C.byref(n)))
         return Hits(self, hits, n.value)
 
+    def search_device(self, st=-1, ed=-1):
+        """Like search(), but the so_hit records stay in HBM (multi-GPU path: exchanged over RCCL before any host copy)."""
+        n = C.c_int64(0)
+        ptr = C.c_void_p()
+        self._chk(self.L.so_search_device(self.h, st, ed, C.byref(ptr), C.byref(n)))
+        return DeviceHits(self, n.value)
+
+    def query_work(self, st=-1, ed=-1):
+        """Index entries each query of [st, ed) visits over all chunks (pre-pass, no search): the shard-balancing weight."""
+        N = self.num_queries
+        lo = min(max(0, st), N)
+        hi = min(N if ed < 0 else ed, N)
+        out = np.zeros(max(hi - lo, 1), dtype=np.uint64)
+        self._chk(self.L.so_query_work(self.h, lo, hi, out.ctypes.data))
+        return out[:max(hi - lo, 0)].astype(np.int64)
+
     def counters(self):
         c = _lib.SoCounters()
         self.L.so_get_counters(self.h, C.byref(c))
         return c.as_dict()
+
+    def set_profile(self, on):
+        self.L.so_set_profile(self.h, 1 if on else 0)
 
     def reset_counters(self):
         self.L.so_reset_counters(self.h)
@@ -134,6 +153,35 @@ class Searcher:
         return out[:n]
 
 
+class DeviceHits:
+    """so_hit records of one so_search_device() call, resident in the ctx's device memory until its next search."""
+    record_bytes = C.sizeof(_lib.SoHit)
+
+    def __init__(self, s, n):
+        self.s, self.n = s, n
+
+    def __len__(self):
+        return self.n
+
+    def tensor(self, device=None):
+        """uint8 torch tensor (n * 80 bytes) on the ctx's GPU holding a copy of the records (device-to-device)."""
+        import torch
+        t = torch.empty(self.n * self.record_bytes, dtype=torch.uint8, device=device or torch.device("cuda", torch.cuda.current_device()))
+        self.s._chk(self.s.L.so_device_hits_copy(self.s.h, C.c_void_p(t.data_ptr()), self.n))
+        return t
+
+    def close(self):
+        pass
+
+
+def hits_from_bytes(s, data):
+    """so_hit records gathered from other ranks (bytes / uint8 array) -> ctypes array usable with so_write_sc / so_format_hit"""
+    buf = np.ascontiguousarray(data, dtype=np.uint8).tobytes()
+    n = len(buf) // C.sizeof(_lib.SoHit)
+    arr = (_lib.SoHit * max(n, 1)).from_buffer_copy(buf + b"\0" * (C.sizeof(_lib.SoHit) if n == 0 else 0))
+    return arr, n
+
+
 class Hits:
     """Result rows of one search; frees the library buffer on close."""
 
@@ -163,6 +211,11 @@ class Hits:
         out = []
         for i in range(self.n):
             k = self.s.L.so_format_hit(self.s.h, C.byref(self.ptr[i]), buf, len(buf))
+            if k < 0:
+                raise SohitError(self.s.L.so_last_error(self.s.h).decode())
+            if k >= len(buf):  # so_format_hit returns the size it needs: very long headers
+                buf = C.create_string_buffer(int(k) + 1)
+                k = self.s.L.so_format_hit(self.s.h, C.byref(self.ptr[i]), buf, len(buf))
             out.append(buf.raw[:k])
         return out
 
@@ -256,8 +309,12 @@ def entry_point(argv, device=0, searcher=None):
         return 0
     wrt = args['-O']
     wrt = wrt if (wrt and wrt in 'wa') else 'w'
-    s = searcher or Searcher(ssd=args['-s'], nr=args['-r'], ht=ht, chk=chk, step=step, v=bv, thr=thr, expect=exp, max_miss=miss,
-                             flt=args['-F'], device=device)
+    try:
+        s = searcher or Searcher(ssd=args['-s'], nr=args['-r'], ht=ht, chk=chk, step=step, v=bv, thr=thr, expect=exp, max_miss=miss,
+                                 flt=args['-F'], device=device)
+    except SohitError as e:  # e.g. -M < 1 with an odd seed weight (the reference crashes there); the native always returns 0
+        sys.stderr.write('fsearch: %s\n' % e)
+        return 0
     try:
         s.load_ref(args['-d'], rstart, rend)
         s.load_queries(args['-i'])

@@ -15,7 +15,13 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(f[:-3] for f in os.listdir(GOLD) if f.endswith(".sc"))
+    """fsearch-c level goldens (flags of the native)."""
+    return sorted(f[:-3] for f in os.listdir(GOLD) if f.endswith(".sc") and not f.startswith("fh_"))
+
+
+def launcher_golden_names():
+    """goldens produced through the reference's bin/find_hit.py (flags of the launcher; block scheme, split + merge)."""
+    return sorted(f[:-3] for f in os.listdir(GOLD) if f.endswith(".sc") and f.startswith("fh_"))
 
 
 @pytest.fixture(scope="session")

@@ -52,7 +52,7 @@ def test_no_cpu_fallback(lib):
 
 def test_bad_parameters_are_reported_not_aborted(lib):
     L = lib.load()
-    p = lib.SoParams(b"111111", b"AST,CFILMVY,DN,EQ,G,H,KR,P,W", -1, 50000, 1, 500, -1, 1e-5, 1e-3, 1, 0)
+    p = lib.SoParams(b"1111111", b"AST,CFILMVY,DN,EQ,G,H,KR,P,W", -1, 50000, 1, 500, -1, 1e-5, 1e-3, 1, 0)  # -M < 1, odd weight: refused
     assert not L.so_create(0, C.byref(p))
     assert L.so_last_error(None)
     assert L.so_create(0, None) is None or not L.so_create(0, None)

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, golden_names
+from conftest import GOLD, golden_names, launcher_golden_names
 
 pytestmark = pytest.mark.gpu
 
@@ -353,8 +353,9 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 for n in (0, 80, 80 * 50001):
     recs = (np.arange(n, dtype=np.int64) %% 251).astype(np.uint8)
-    g = sdist.gather_records(recs)
+    g = sdist.gather_device_records(torch.from_numpy(recs).cuda())
     assert g.sizes == [n], g.sizes
+    assert g.buf.is_cuda and g.buf.numel() == n
     got = g.arrays()[0]
     assert got.shape == (n,) and np.array_equal(got, recs)
 t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
@@ -368,7 +369,7 @@ dist.destroy_process_group()
 
 def test_gather_records_over_rccl(tmp_path):
     """The hit gather of bench.py / find_hit.py -a N on the backend the GPU box really uses ("nccl" == RCCL):
-    size all_gather, padded gather, pinned device-to-host copy, and the all_reduce / barrier bench.py issues.
+    size all_gather, size-exact device gatherv, pinned device-to-host copy, and the all_reduce / barrier bench.py issues.
     One rank (the box has one GPU); the world_size-2 flow is covered on gloo in test_host_logic.py."""
     import subprocess
     import sys
@@ -440,6 +441,143 @@ def test_find_hit_cli_matches_golden(tmp_path, name):
     p = _cli([os.path.join("bin", "find_hit.py"), "-p", "blastp", "-i", qry, "-d", ref, "-o", str(out), "-a", "1"] + list(meta["flags"]))
     assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-2000:])
     assert out.read_bytes() == open(os.path.join(GOLD, name + ".sc"), "rb").read()
+
+
+ONE_GPU_GLOO = dict(SOHIT_BENCH_BACKEND="gloo", SOHIT_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")  # N ranks share GPU 0
+
+
+@pytest.mark.parametrize("name", launcher_golden_names())
+def test_find_hit_cli_matches_launcher_golden(tmp_path, name):
+    """bin/find_hit.py against outputs of the REAL reference launcher (tools/refharness/ref_find_hit.py): more queries
+    than references with the default -l/-u (End < 0 -> the QUERY count, find_hit.py:97-105), the -a 3 block scheme whose last
+    block runs past -u (107-116; here three ranks over gloo sharing the GPU), and the reference split + `sort -m | awk`
+    merge (303-351) with the threshold forced low."""
+    import shutil
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    ref = str(tmp_path / "ref.fsa")   # the split path creates <ref>_parts next to the file
+    shutil.copyfile(os.path.join(GOLD, name + ".ref.fsa"), ref)
+    qry = os.path.join(GOLD, name + ".qry.fsa")
+    out = tmp_path / "fh.sc"
+    env = dict(os.environ, **ONE_GPU_GLOO)
+    if meta["max_chr"] is not None:
+        env["SWIFTORTHO_MAX_CHR"] = str(meta["max_chr"])
+    p = _cli([os.path.join("bin", "find_hit.py"), "-p", "blastp", "-i", qry, "-d", ref, "-o", str(out)] + list(meta["find_hit_flags"]), env=env)
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+    assert out.read_bytes() == open(os.path.join(GOLD, name + ".sc"), "rb").read()
+    assert not os.path.exists(ref + "_parts")
+
+
+def test_two_rank_search_equals_one_rank(tmp_path):
+    """find_hit.py -a 2 (two ranks, query shards, hit gather; gloo with both ranks on GPU 0) writes the file of -a 1."""
+    from swiftortho_amd import synthprot
+    fa = tmp_path / "w.fsa"
+    fa.write_bytes(synthprot.synthprot(3000, 300, 77))
+    outs = []
+    for a in (1, 2):
+        out = tmp_path / ("a%d.sc" % a)
+        p = _cli([os.path.join("bin", "find_hit.py"), "-p", "blastp", "-i", str(fa), "-d", str(fa), "-o", str(out), "-e", "1e-5", "-s", "111111",
+                  "-a", str(a)], env=dict(os.environ, **ONE_GPU_GLOO))
+        assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+        outs.append(out.read_bytes())
+    assert outs[0].count(b"\n") > 5000
+    assert outs[0] == outs[1]
+
+
+def test_device_resident_results_and_query_work(fs):
+    """so_search_device leaves the same 80-byte so_hit records in HBM that so_search_loaded returns on the host (identity and
+    e-value evaluated on the device: bit-equal doubles); so_query_work's per-query counts add up to the seed hits searched."""
+    import torch
+    from swiftortho_amd import synthprot
+    fa = synthprot.synthprot(1500, 200, 3)
+    kw = dict(ssd="111111", nr="AST,CFILMVY,DN,EQ,G,H,KR,P,W", ht=120000000, chk=700, step=1, v=500, expect=1e-5, flt="T")
+    s = fs.Searcher(**kw)
+    s.load_ref_bytes(fa)
+    s.load_queries_bytes(fa)
+    for lo, hi in ((-1, -1), (100, 433), (7, 7)):
+        h = s.search(lo, hi)
+        host = h.raw_bytes()
+        h.close()
+        d = s.search_device(lo, hi)
+        assert len(d) * d.record_bytes == len(host)
+        assert d.tensor().cpu().numpy().tobytes() == host
+    w = s.query_work()
+    assert len(w) == 1500 and w.min() >= 0
+    s.reset_counters()
+    s.search().close()
+    assert int(w.sum()) == s.counters()["seed_hits"]
+    assert int(s.query_work(100, 433).sum()) == int(w[100:433].sum())
+    s.close()
+
+
+def _properties(g, v=500, expect=1e-5):
+    q = g["qidx"]
+    assert np.all(np.diff(q) >= 0)
+    same = q[1:] == q[:-1]
+    assert np.all(g["bit"][1:][same] <= g["bit"][:-1][same])
+    assert np.all(np.bincount(q - q.min()) <= v)
+    assert np.all(g["evalue"] <= expect)
+    assert np.all((g["qst"] >= 1) & (g["qed"] <= g["qlen"]) & (g["sst"] >= 1) & (g["sed"] <= g["slen"]))
+    assert np.all(g["mis"] + g["matches"] == g["aln"])
+
+
+def _sampled_oracle(s, oracle, fa_path, kw, ranges):
+    """per-query results do not depend on the query partition, so an oracle run of -l/-u sub-ranges against the whole
+    reference checks a sample of a search that is too large to replay on the CPU"""
+    for lo, hi in ranges:
+        out = fa_path + ".%d.sc" % lo
+        oracle.blastp(fa_path, fa_path, out, ssd=kw["ssd"], nr=kw["nr"], expect=kw["expect"], v=kw["v"], step=kw["step"], flt=kw["flt"],
+                      ht=kw["ht"], chk=kw["chk"], st=lo, ed=hi)
+        h = s.search(lo, hi)
+        rows = b"".join(h.rows())
+        h.close()
+        want = open(out, "rb").read()
+        assert want.count(b"\n") > 0
+        assert rows == want, "queries [%d, %d) differ from the oracle" % (lo, hi)
+
+
+def test_config3_full_size(fs, oracle, tmp_path):
+    """BASELINE config 3: 100k proteins x 300 aa self-search, seed 11111011111, two reference chunks of 50k.
+    Full run: size-independent properties; two sampled query ranges (one per chunk's taxa): identical to the oracle."""
+    from swiftortho_amd import synthprot
+    fa = synthprot.synthprot(100000, 300)
+    kw = dict(ssd="11111011111", nr=oracle.AA9, ht=120000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    s, hits, _ = gpu_rows(fs, fa, fa, kw)
+    assert s.counters()["n_chunks"] == 2
+    g = hits.array()
+    assert len(g) > 1000000
+    _properties(g)
+    self_hit = g[g["qidx"] == g["sidx"]]
+    assert len(np.unique(self_hit["qidx"])) >= 0.99 * 100000
+    h2 = s.search(61234, 61300)   # idempotence on a sub-range
+    assert h2.array().tobytes() == g[(g["qidx"] >= 61234) & (g["qidx"] < 61300)].tobytes()
+    h2.close()
+    hits.close()
+    p = str(tmp_path / "c3.fsa")
+    open(p, "wb").write(fa)
+    _sampled_oracle(s, oracle, p, kw, [(777, 793), (88000, 88016)])
+    s.close()
+
+
+def test_config4_shape_sampled(fs, oracle, tmp_path):
+    """BASELINE config 4's shape at a size the suite affords: 200k proteins, four resident 50k chunks, seed 111111
+    (1.6e5 seed hits per query and chunk).  16 sampled queries against all four chunks: identical to the oracle; a
+    512-query range: properties."""
+    from swiftortho_amd import synthprot
+    fa = synthprot.synthprot(200000, 300)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=120000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    s = fs.Searcher(**kw)
+    s.load_ref_bytes(fa)
+    s.load_queries_bytes(fa)
+    h = s.search(150000, 150512)
+    assert s.counters()["n_chunks"] == 4
+    g = h.array()
+    assert len(g) > 5000
+    _properties(g)
+    h.close()
+    p = str(tmp_path / "c4.fsa")
+    open(p, "wb").write(fa)
+    _sampled_oracle(s, oracle, p, kw, [(123450, 123458), (199990, 199998)])
+    s.close()
 
 
 def _ragged_queries(base):

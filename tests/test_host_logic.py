@@ -70,6 +70,38 @@ def test_shard_queries_balanced_contiguous():
     assert shard_queries([5], 4)[-1][1] == 1
 
 
+def test_shards_balanced_by_work_on_skewed_families():
+    """Work per query (seed hits, extensions, alignments) grows with the size of its family; families are skewed.  Shards cut
+    by the per-query work estimate keep max / mean rank work <= 1.1 where residue-balanced shards do not."""
+    from swiftortho_amd.dist import imbalance, shard_queries
+    rng = np.random.default_rng(7)
+    fam = rng.zipf(1.6, 20000).clip(1, 400)           # family size of each query's family, taxon-major order mixes them
+    lens = rng.integers(100, 600, fam.size)
+    work = fam.astype(np.int64) * fam * 300 + lens    # ~ members x hits per member
+    for world in (2, 4, 8):
+        by_work = shard_queries(work, world)
+        assert by_work[0][0] == 0 and by_work[-1][1] == fam.size and all(by_work[i][1] == by_work[i + 1][0] for i in range(world - 1))
+        assert imbalance(work, by_work) <= 1.1
+    assert imbalance(work, shard_queries(lens, 8)) > imbalance(work, shard_queries(work, 8))
+    # one dominant query cannot be split: it gets a shard of its own and the rest is still cut sensibly
+    w = np.ones(1000, dtype=np.int64)
+    w[500] = 10000
+    sh = shard_queries(w, 4)
+    assert any(a <= 500 < b and b - a <= 260 for a, b in sh)
+
+
+def test_launcher_query_range_rule():
+    """find_hit.py:97-116: End < 0 -> the QUERY count; the last block is clipped to N, not to -u"""
+    from swiftortho_amd.find_hit import query_range
+    assert query_range(-1, -1, 70, 1) == (0, 70)
+    assert query_range(5, 48, 70, 3) == (5, 61)             # Step = 43 // 3 = 14: blocks 5, 19, 33, 47 -> [47, 61)
+    assert query_range(0, 15000, 100000, 1) == (0, 20000)   # Step = 10000
+    assert query_range(0, 15000, 12000, 1) == (0, 12000)
+    assert query_range(10, 5, 70, 1) == (0, 0)
+    assert query_range(80, -1, 70, 1) == (0, 0)
+    assert query_range(0, 7, 70, 16) == (0, 7)              # Step = max(7 // 16, 1) = 1
+
+
 WORKER = r'''
 import os, sys
 sys.path.insert(0, %r)

@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLD, golden_names
+from conftest import GOLD, golden_names, launcher_golden_names
 
 
 @pytest.fixture(scope="module")
@@ -112,3 +112,39 @@ def test_query_partition_invariance(oracle, tmp_path):
                        check=True, stderr=subprocess.DEVNULL)
         parts += open(out, "rb").read()
     assert parts == open(os.path.join(GOLD, name + ".sc"), "rb").read()
+
+
+def native_flags(p):
+    """resolved launcher parameters -> the flags find_hit.py puts on the fsearch-c command line (find_hit.py:119-121)"""
+    return ["-e", repr(p["exp"]), "-v", str(p["bv"]), "-L", str(p["rstart"]), "-U", str(p["rend"]), "-m", repr(p["miss"]), "-t", str(p["thr"]),
+            "-j", str(p["step"]), "-F", p["flt"], "-M", str(p["ht"]), "-c", str(p["chk"]), "-s", p["ssd"], "-r", p["nr"]]
+
+
+@pytest.mark.parametrize("name", launcher_golden_names())
+def test_launcher_golden(oracle, name, tmp_path):
+    """Host logic of the drop-in launcher (query_range, reference_parts, merge_parts) around the oracle's `fsearch-c`
+    against outputs of the REAL bin/find_hit.py (tools/refharness/ref_find_hit.py)."""
+    from swiftortho_amd import find_hit as fh
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    ref, qry = os.path.join(GOLD, name + ".ref.fsa"), os.path.join(GOLD, name + ".qry.fsa")
+    p = fh.resolve(fh.parse(["find_hit.py", "-p", "blastp", "-i", qry, "-d", ref, "-o", "x"] + meta["find_hit_flags"]))
+    nq = open(qry, "rb").read().count(b">")
+    lo, hi = fh.query_range(p["start"], p["end"], nq, p["ngpu"])
+
+    def native(ref_path, out):
+        subprocess.run([oracle.EXE, "-p", "blastp", "-i", qry, "-d", ref_path, "-o", out, "-l", str(lo), "-u", str(hi)] + native_flags(p),
+                       check=True, stderr=subprocess.DEVNULL)
+
+    out = str(tmp_path / "o.sc")
+    if meta["max_chr"] is None:
+        native(ref, out)
+    else:
+        outs = []
+        for k, text in enumerate(fh.reference_parts(ref, meta["max_chr"])):
+            part = str(tmp_path / ("part%d.fsa" % k))
+            open(part, "w", encoding="latin-1", newline="").write(text)
+            outs.append(str(tmp_path / ("%d.sc" % k)))
+            native(part, outs[-1])
+        assert len(outs) > 2
+        fh.merge_parts(sorted(outs), p["bv"], out)
+    assert open(out, "rb").read() == open(os.path.join(GOLD, name + ".sc"), "rb").read()

@@ -178,6 +178,29 @@ def run_e2e(m, name, fasta, flags, qry=None):
     print(name, "rows:", open(out, "rb").read().count(b"\n"))
 
 
+def run_find_hit(name, ref, qry, flags, max_chr=None):
+    """End-to-end through the REAL launcher bin/find_hit.py (query blocks, cat; with max_chr the reference split + merge)."""
+    import ref_find_hit
+    if os.path.isfile(os.path.join(GOLD, name + ".sc")) and not FORCE:
+        print(name, "exists, skipped")
+        return
+    tmp = tempfile.mkdtemp(prefix="gold_")
+    fa, qa, out = os.path.join(tmp, "ref.fsa"), os.path.join(tmp, "qry.fsa"), os.path.join(tmp, "out.sc")
+    open(fa, "wb").write(ref)
+    open(qa, "wb").write(qry)
+    ref_find_hit.run(["-p", "blastp", "-i", qa, "-d", fa, "-o", out, "-T", os.path.join(tmp, "t")] + flags, max_chr=max_chr)
+    open(os.path.join(GOLD, name + ".ref.fsa"), "wb").write(ref)
+    open(os.path.join(GOLD, name + ".qry.fsa"), "wb").write(qry)
+    open(os.path.join(GOLD, name + ".sc"), "wb").write(open(out, "rb").read())
+    json.dump({"find_hit_flags": flags, "max_chr": max_chr, "separate_query": True}, open(os.path.join(GOLD, name + ".json"), "w"), indent=1)
+    print(name, "rows:", open(out, "rb").read().count(b"\n"))
+
+
+def first_records(fasta, n):
+    recs = fasta.split(b">")[1:]
+    return b"".join(b">" + r for r in recs[:n])
+
+
 def stage_dump(m, name, fasta, ssd, nr, NC, step=1, nq=12):
     """find_msav_m internals for a few queries: threshold, index digest, candidates."""
     tmp = tempfile.mkdtemp(prefix="gold_")
@@ -332,6 +355,13 @@ def main():
         planted.append(">t%04d|planted%d copy d=%.1f\n%s\n" % (t, t, d, "".join(s)))
     ref = ref + "".join(planted).encode()
     run_e2e(m, "example_cfg1", ref, ["-e", "1e-5", "-s", "111111", "-r", AA9, "-M", "120000000", "-c", "50000", "-j", "1"], qry=qry)
+    # the launcher itself (find_hit.py:95-146, 303-351): more queries than references (End < 0 -> N, the QUERY count), the block
+    # scheme with -a 3 (the last block runs past -u), and the reference split + `sort -m | awk` merge with max_chr forced low
+    whole = synthprot.synthprot(70, 120, 9)
+    fh = ["-e", "1e-5", "-s", "111111", "-M", "1000003", "-c", "50000"]
+    run_find_hit("fh_more_queries", first_records(whole, 30), whole, fh)
+    run_find_hit("fh_blocks", first_records(whole, 30), whole, fh + ["-a", "3", "-l", "5", "-u", "48"])
+    run_find_hit("fh_split", whole, first_records(whole, 40), fh + ["-v", "1"], max_chr=3000)
     stage_dump(m, "stage_default", synthprot.synthprot(99, 150, 21), "111111", AA9, 1000003)
     stage_dump(m, "stage_multi", synthprot.synthprot(60, 100, 3), "111111,1101011", AA9 + "/" + AA10B, 200003)
 
