@@ -16,7 +16,7 @@ def pytest_configure(config):
 
 def golden_names():
     """fsearch-c level goldens (flags of the native)."""
-    return sorted(f[:-3] for f in os.listdir(GOLD) if f.endswith(".sc") and not f.startswith("fh_"))
+    return sorted(f[:-3] for f in os.listdir(GOLD) if f.endswith(".sc") and not f.startswith(("fh_", "orth_")))
 
 
 def launcher_golden_names():
@@ -29,3 +29,14 @@ def oracle():
     from oracle import oracle as o
     o.build()
     return o
+
+
+def orth_golden_cases():
+    """(name, variant) of the find_orth goldens (outputs of the reference's bin/find_orth.py)"""
+    import json
+    out = []
+    for f in sorted(os.listdir(GOLD)):
+        if f.startswith("orth_") and f.endswith(".json"):
+            for v in json.load(open(os.path.join(GOLD, f)))["variants"]:
+                out.append((f[5:-5], v))
+    return out
