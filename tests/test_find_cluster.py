@@ -1,0 +1,69 @@
+"""MCL clustering counterpart (swiftortho_amd/find_cluster.py) against stdout of the REAL reference script
+bin/find_cluster.py -a mcl captured by tools/refharness/make_cluster_goldens.py, plus hand-checkable graphs.
+CPU only (host stage)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import GOLD, ROOT
+
+
+def cluster_cases():
+    out = []
+    for f in sorted(os.listdir(GOLD)):
+        if f.startswith("clu_") and f.endswith(".json"):
+            for v in json.load(open(os.path.join(GOLD, f)))["variants"]:
+                out.append((f[4:-5], v))
+    return out
+
+
+def as_sets(text):
+    """scripts/mcl_cmp.py's view of a clustering: a set of gene sets"""
+    return sorted(tuple(sorted(l.split("\t"))) for l in text.split("\n") if l)
+
+
+@pytest.mark.parametrize("name,variant", cluster_cases())
+def test_groups_match_reference(name, variant):
+    from swiftortho_amd import find_cluster as fc
+    meta = json.load(open(os.path.join(GOLD, "clu_%s.json" % name)))
+    a = fc.parse(["find_cluster.py", "-i", "x"] + meta["variants"][variant])
+    groups = fc.cnc(open(os.path.join(GOLD, meta["input"])), float(a["-I"]))
+    got = "".join("\t".join(g) + "\n" for g in groups)
+    want = open(os.path.join(GOLD, "clu_%s.%s.mcl" % (name, variant))).read()
+    assert as_sets(got) == as_sets(want)        # the groups as sets (what config 5 diffs)
+    assert got == want                          # and the same text: group order and member order too
+
+
+def test_hand_checkable_graphs():
+    """Two cliques joined by one weak edge split at I = 2; a clique stays whole.  The reference's numbering accidents, by hand:
+    best-neighbour components are numbered in popitem() order (last gene of the file first), so the LAST clique of the file is
+    level-1 component 0, is never merged (`if X and Y`, 1533) and is clustered in the shared block -1; level-2 groups are
+    numbered in file order, so the FIRST clique of the file is level-2 group 0 and is dropped (`if cx and cy and cx == cy`, 1584)."""
+    from swiftortho_amd import find_cluster as fc
+
+    def clique(names, w):
+        return ["OT\t%s\t%s\t%s\n" % (a, b, w) for i, a in enumerate(names) for b in names[i + 1:]]
+
+    a, b = ["a|1", "a|2", "a|3", "a|4"], ["b|1", "b|2", "b|3", "b|4"]
+    lines = clique(["z|0", "z|1", "z|2"], 1.0) + clique(a, 1.0) + clique(b, 1.0) + ["OT\ta|1\tb|1\t0.05\n"] + clique(["c|1", "c|2", "c|3"], 2.0)
+    groups = [sorted(g) for g in fc.cnc(lines, 2.0)]
+    assert groups == [["c|1", "c|2", "c|3"], sorted(a), sorted(b)]   # block -1 first, then level-2 groups ascending; z|* dropped
+    # without the bridge nothing changes; with a strong bridge and gentle inflation the two cliques stay together
+    strong = clique(["z|0", "z|1"], 1.0) + clique(a, 1.0) + clique(b, 1.0) + ["OT\ta|%d\tb|%d\t1.0\n" % (i, j) for i in (1, 2, 3, 4) for j in (1, 2, 3, 4)]
+    groups = [sorted(g) for g in fc.cnc(strong + clique(["c|1", "c|2"], 1.0), 1.2)]
+    assert sorted(a + b) in groups
+
+
+def test_find_cluster_cli(tmp_path):
+    meta = json.load(open(os.path.join(GOLD, "clu_taxa4_colon.json")))
+    inp = os.path.join(GOLD, meta["input"])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "find_cluster.py"), "-i", inp, "-a", "mcl", "-I", "1.5"], capture_output=True,
+                       text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == open(os.path.join(GOLD, "clu_taxa4_colon.I1.5.mcl")).read()
+    assert os.listdir(str(tmp_path)) == []
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "find_cluster.py"), "-i", inp], capture_output=True, text=True)
+    assert r.returncode == 2 and "mcl" in r.stderr      # default -a apc: not provided
