@@ -1,0 +1,10 @@
+#!/usr/bin/env python3
+"""Drop-in for SwiftOrtho's scripts/nr2full.py (expand the hits of a collapsed search): see swiftortho_amd/nr.py."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from swiftortho_amd.nr import main_nr2full  # noqa: E402
+
+if __name__ == "__main__":
+    sys.exit(main_nr2full())

@@ -1,0 +1,86 @@
+"""BASELINE config 5: find_hit -> find_orth -> find_cluster -a mcl -I 1.5 end to end, ortholog groups compared with the
+reference pipeline's (tools/refharness/make_pipeline_golden.py: oracle search rows, then the REAL bin/find_orth.py and
+bin/find_cluster.py).  The proteome is regenerated from synthprot (md5-checked), so the fixtures are digests + groups."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import GOLD, ROOT
+
+
+def canonical(groups_text):
+    rows = sorted("\t".join(sorted(l.split("\t"))) for l in groups_text.split("\n") if l)
+    return "\n".join(rows) + "\n"
+
+
+def downstream(sc_path, meta, tmp_path):
+    """the two drop-in CLIs on an .sc file -> (orth text, groups text)"""
+    orth = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "find_orth.py"), "-i", sc_path] + meta["find_orth_flags"], capture_output=True, check=True).stdout
+    op = str(tmp_path / "x.orth")
+    open(op, "wb").write(orth)
+    groups = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "find_cluster.py"), "-i", op] + meta["find_cluster_flags"], capture_output=True,
+                            check=True).stdout
+    return orth, groups.decode()
+
+
+def check(meta, orth, groups, name):
+    assert hashlib.md5(orth).hexdigest() == meta["orth_md5"], "find_orth output differs from the reference's"
+    assert groups.count("\n") == meta["groups"] and len(groups.split()) == meta["genes_in_groups"]
+    assert hashlib.sha256(canonical(groups).encode()).hexdigest() == meta["groups_canonical_sha256"], "ortholog groups differ (as sets)"
+    assert hashlib.sha256(groups.encode()).hexdigest() == meta["groups_text_sha256"]
+    want = open(os.path.join(GOLD, name + ".groups")).read()
+    assert groups.startswith(want)      # c2: the whole file; c3: its first 200 groups
+
+
+def test_downstream_of_oracle_search_c2(oracle, tmp_path):
+    """CPU: oracle rows of the 10k-protein search -> find_orth -> find_cluster == the reference pipeline"""
+    from swiftortho_amd import synthprot
+    meta = json.load(open(os.path.join(GOLD, "pipe_c2.json")))
+    fa = synthprot.synthprot(meta["proteins"], 300)
+    assert hashlib.md5(fa).hexdigest() == meta["fasta_md5"]
+    p = str(tmp_path / "x.fsa")
+    open(p, "wb").write(fa)
+    P, n = os.cpu_count() or 1, meta["proteins"]
+    block = (n + P - 1) // P
+    procs = [subprocess.Popen([oracle.EXE, "-p", "blastp", "-i", p, "-d", p, "-o", str(tmp_path / ("%03d.sc" % k)), "-l", str(k * block), "-u",
+                               str(min(n, (k + 1) * block))] + meta["find_hit_flags"], stderr=subprocess.DEVNULL) for k in range(P)]
+    assert all(q.wait() == 0 for q in procs)
+    sc = str(tmp_path / "all.sc")
+    with open(sc, "wb") as o:
+        for k in range(P):
+            o.write(open(str(tmp_path / ("%03d.sc" % k)), "rb").read())
+    assert hashlib.md5(open(sc, "rb").read()).hexdigest() == meta["sc_md5"]
+    orth, groups = downstream(sc, meta, tmp_path)
+    check(meta, orth, groups, "pipe_c2")
+
+
+def launcher_flags(native):
+    """fsearch-c flags of the golden -> bin/find_hit.py flags (same letters; the alphabet by name)"""
+    d = dict(zip(native[0::2], native[1::2]))
+    return ["-e", d["-e"], "-v", d["-v"], "-j", d["-j"], "-F", d["-F"], "-s", d["-s"], "-r", "aa9", "-M", d["-M"], "-c", d["-c"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["c2", "c3"])
+def test_pipeline_on_gpu(cfg, tmp_path):
+    """GPU: bin/find_hit.py -> bin/find_orth.py -> bin/find_cluster.py; c3 = BASELINE config 5 at full size (100k proteins)"""
+    from swiftortho_amd import synthprot
+    path = os.path.join(GOLD, "pipe_%s.json" % cfg)
+    if not os.path.isfile(path):
+        pytest.skip("no golden for " + cfg)
+    meta = json.load(open(path))
+    fa = synthprot.synthprot(meta["proteins"], 300)
+    assert hashlib.md5(fa).hexdigest() == meta["fasta_md5"]
+    p = str(tmp_path / "x.fsa")
+    open(p, "wb").write(fa)
+    sc = str(tmp_path / "x.sc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "find_hit.py"), "-p", "blastp", "-i", p, "-d", p, "-o", sc, "-a", "1"] + launcher_flags(meta["find_hit_flags"]),
+                       capture_output=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert hashlib.md5(open(sc, "rb").read()).hexdigest() == meta["sc_md5"], "search rows differ from the oracle's"
+    orth, groups = downstream(sc, meta, tmp_path)
+    check(meta, orth, groups, "pipe_" + cfg)
