@@ -102,6 +102,17 @@ struct KeyLayout {
     }
 };
 
+// Bucketed diagonal binning (k_bucket.hip): a bucket = (query of the pass, range of 2^wb chunk sequences); a hit inside a
+// bucket is one 32-bit word  subject_low << (bd + bp) | diagonal << bp | qpos.
+#define BKT_RMAX 512          // subject ranges per chunk (per-wave LDS histogram of the count / scatter passes)
+struct BktLayout {
+    int wb, bd, bp;           // bits: subject inside the range, diagonal, query position
+    int sh_q, sh_qpos;        // where q / qpos sit in the seeds' 64-bit key bases (KeyLayout)
+    u32 nqp, qa;              // queries in the pass, first one (batch-local index)
+    u32 R;                    // subject ranges: bucket id = range * nqp + (q - qa)
+    u32 maxslen;              // KeyLayout::diag_off
+};
+
 // One alignment task / result (phase 2).
 struct AlnTask {
     u32 q;        // query index local to the batch

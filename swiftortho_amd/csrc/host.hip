@@ -658,6 +658,7 @@ struct Batch {
     DevBuf<unsigned long long> qhits;
     DevBuf<u64> cs_kbase;
     DevBuf<u64> keys, keys2;
+    DevBuf<u32> hits32, bmat, bt0, btd, bext, bflag;  // bucketed binning (k_bucket.hip)
     DevBuf<u32> flags, gidx, ghead;
     DevBuf<u64> p_qs, p_sd, p_ft, p_qs2, tmp64, q_qs, q_sd, q_ft;
     DevBuf<u32> shard;
@@ -905,6 +906,90 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         launch_encode_delta(ch.entries.p, ch.E, kl.sh_subj, kl.sh_diag, ch.maxslen, ch.dkeys.p, c->st);
         ch.d_sh_subj = kl.sh_subj, ch.d_sh_diag = kl.sh_diag;
     }
+    // pass-list buffers (k_ungap / k_bkt_ungap append the groups that reach MIN_UNGAP)
+    const u32 shard_cap = ungap_shard_cap(H);
+    const size_t pcap = (size_t)shard_cap * UG_SHARDS + 2;
+    b.p_qs.ensure(pcap), b.p_sd.ensure(pcap), b.p_ft.ensure(pcap);
+    b.shard.ensure(2 * UG_SHARDS + 8);
+    b.stepshard.ensure(UG_SHARDS);
+    b.bflag.ensure(4);
+    double t1 = wall();
+    auto reset_pass_lists = [&] {
+        HIP_CHECK(hipMemsetAsync(b.shard.p, 0, (2 * UG_SHARDS + 8) * sizeof(u32), c->st));
+        HIP_CHECK(hipMemsetAsync(b.stepshard.p, 0, UG_SHARDS * sizeof(unsigned long long), c->st));
+        HIP_CHECK(hipMemsetAsync(b.bflag.p, 0, 4 * sizeof(u32), c->st));
+    };
+
+    // ---- diagonal binning, bucketed (k_bucket.hip): no sort; count -> scan -> scatter (4 B per hit) -> LDS hash grouping ----
+    // One alphabet x one pattern, compact index addends and wb + bd + bp <= 32; returns false when the pass has to take the
+    // sorted path below.
+    auto group_bucketed = [&]() -> bool {
+        static const bool enabled = !(getenv("SOHIT_BUCKET") && atoi(getenv("SOHIT_BUCKET")) == 0);
+        if (!enabled || AS != 1 || !compact || UG_SHARDS != 1) return false;
+        const u32 nqp = qb - qa;
+        const int wb_hi = std::min(std::min(31 - kl.bd - kl.bp, kl.bs), bkt_max_wb());   // hit word < 2^31; subjects per range <= the sort's bins
+        int wb_lo = 0;
+        while (((u64)nseq_chunk + (1ull << wb_lo) - 1) >> wb_lo > BKT_RMAX) ++wb_lo;
+        if (wb_hi < wb_lo || kl.bp > 16) return false;
+        // widest subject range whose average bucket is a few hits per thread of the workgroup that groups it
+        static const u32 target = getenv("SOHIT_BUCKET_AVG") ? (u32)std::max(1, atoi(getenv("SOHIT_BUCKET_AVG"))) : 1536u;
+        int wb = wb_hi;
+        while (wb > wb_lo && (u64)H / ((u64)nqp * (((u64)nseq_chunk + (1ull << wb) - 1) >> wb)) > target) --wb;
+        BktLayout L;
+        L.wb = wb, L.bd = kl.bd, L.bp = kl.bp, L.sh_q = kl.sh_q, L.sh_qpos = kl.sh_qpos, L.nqp = nqp, L.qa = qa;
+        L.R = (u32)(((u64)nseq_chunk + (1ull << wb) - 1) >> wb);
+        L.maxslen = ch.maxslen;
+        if ((u64)L.R * nqp >= 0xFFFFFFF0ull) return false;
+        const u32 nb = L.R * nqp;
+        // tiles: <= 1024 consecutive hit ordinals of one query
+        b.qseg.ensure((size_t)b.nq + 4);
+        launch_query_segments(b.hoff.p, T, b.dev.d_off.p, b.nq, AS, H, b.qseg.p, c->st);
+        const u32* qseg = b.qseg.p + qa;
+        b.bt0.ensure((size_t)nqp + 4);
+        launch_bkt_ntiles(qseg, nqp, b.bt0.p, c->st);
+        c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)nqp + 1) + 8);
+        const u32 NT = d2h_u32(c, scan_u32(b.bt0.p, b.bt0.p, (size_t)nqp + 1, false, c->d_scan_tmp.p, c->st));
+        if ((u64)L.R * NT >= 0xFFFFFFF0ull) return false;
+        b.btd.ensure(4 * (size_t)NT + 8);
+        launch_bkt_tiledesc(qseg, b.bt0.p, nqp, NT, b.cs_hoff.p, K, b.btd.p, c->st);
+        // count per (range, tile), range-major; its exclusive scan is the scatter plan
+        const size_t nm = (size_t)L.R * NT;
+        b.bmat.ensure(nm + 4);
+        HIP_CHECK(hipMemsetAsync(b.bmat.p, 0, (nm + 4) * sizeof(u32), c->st));
+        launch_bkt_pass(false, b.btd.p, qseg, NT, b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, ch.dk32.p, c->ref.d_off.p + ch.seq_lo, L, b.bmat.p, nullptr,
+                        c->st);
+        c->d_scan_tmp.ensure(scan_u32_temp_elems(nm + 1) + 8);
+        const u32 Hv = d2h_u32(c, scan_u32(b.bmat.p, b.bmat.p, nm + 1, false, c->d_scan_tmp.p, c->st));  // hits kept (all but the dropped offset-0 ones)
+        sc.lap("seed.bucket_count");
+        b.hits32.ensure((size_t)H + 2);
+        {
+            ProfTimer pt(c, &c->cnt.lookup_ms, &c->cnt.lookup_launches);
+            launch_bkt_pass(true, b.btd.p, qseg, NT, b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, ch.dk32.p, c->ref.d_off.p + ch.seq_lo, L, b.bmat.p,
+                            b.hits32.p, c->st);
+            pt.stop();
+            if (c->profile) c->cnt.lookup_bytes += (i64)8 * (i64)H;
+        }
+        t1 = wall();
+        sc.lap("seed.bucket_scatter");
+        b.keys2.ensure((size_t)H + 2);
+        b.bext.ensure((size_t)nb + 4);
+        launch_bkt_extents(b.bmat.p, b.bt0.p, NT, nqp, nb, b.bext.p, c->st);
+        launch_bkt_group(b.hits32.p, b.bext.p, nb, L, kl, b.keys2.p, b.bflag.p, c->st);
+        // a group too large for a wave's LDS table (or pool) leaves key slots unwritten: never walk them -- sorted path instead
+        const u32 refused = d2h_u32(c, b.bflag.p);
+        sc.lap("group.bucket_group");
+        if (refused) {
+            if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] bucketed pass refused (flag %u): sorted path\n", refused);
+            return false;
+        }
+        if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] bucketed pass: wb %d ranges %u buckets %u tiles %u hits %u of %u\n", wb, L.R, nb, NT, Hv, H);
+        launch_ungap(b.keys2.p, Hv, kl, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.shard.p,
+                     shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
+        return true;
+    };
+
+    // ---- the sorted path: 8-byte keys, segmented radix sort by (subject, diagonal), group walk over the sorted keys ----
+    auto group_sorted = [&] {
     b.blk_first.ensure((size_t)lookup_num_blocks(H) + 2);
     launch_lookup_blockfirst(b.cs_hoff.p, K, H, b.blk_first.p, c->st);
     b.keys.ensure((size_t)H + 2), b.keys2.ensure((size_t)H + 2);
@@ -915,10 +1000,8 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         pt.stop();
         if (c->profile) c->cnt.lookup_bytes += (i64)8 * (i64)H;
     }
-    const double t1 = wall();
+    t1 = wall();
     sc.lap("seed.compact_lookup");
-    if (getenv("SOHIT_LK_VARIANT") && (atoi(getenv("SOHIT_LK_VARIANT")) == 1 || atoi(getenv("SOHIT_LK_VARIANT")) == 2)) return;  // ablation runs time the lookup only: keys are not valid
-    // diagonal binning: sort keys, find group heads
     // Hits are generated in (query, qpos, as) order (position-major seed ordinals) and the radix sorts are
     // stable, so only the (subject, diagonal) bits need sorting, inside each query's segment: 2 radix passes
     // fewer than a device-wide sort of the (query, subject, diagonal) bits.  One block sorts one segment, so
@@ -937,15 +1020,14 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     }
     sc.lap("group.sort_keys");
     // group walk + chained ungapped extension (the kernel finds the group heads itself)
-    const u32 shard_cap = ungap_shard_cap(H);
-    const size_t pcap = (size_t)shard_cap * UG_SHARDS + 2;
-    b.p_qs.ensure(pcap), b.p_sd.ensure(pcap), b.p_ft.ensure(pcap);
-    b.shard.ensure(2 * UG_SHARDS + 8);
-    b.stepshard.ensure(UG_SHARDS);
-    HIP_CHECK(hipMemsetAsync(b.shard.p, 0, (2 * UG_SHARDS + 8) * sizeof(u32), c->st));
-    HIP_CHECK(hipMemsetAsync(b.stepshard.p, 0, UG_SHARDS * sizeof(unsigned long long), c->st));
     launch_ungap(b.keys2.p, H, kl, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo,
                  c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
+    };
+
+    const bool lk_ablation = getenv("SOHIT_LK_VARIANT") && (atoi(getenv("SOHIT_LK_VARIANT")) == 1 || atoi(getenv("SOHIT_LK_VARIANT")) == 2);
+    reset_pass_lists();
+    if (lk_ablation || !group_bucketed()) group_sorted();
+    if (lk_ablation) return;  // ablation runs time the lookup only: keys are not valid
     // contiguous pass list; the group counters and the pass total come back in one synchronisation
     u32* shard_off = b.shard.p + UG_SHARDS;
     launch_shard_scan(b.shard.p, shard_off, c->st);

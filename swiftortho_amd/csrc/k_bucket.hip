@@ -1,0 +1,401 @@
+// k_bucket.hip -- diagonal binning WITHOUT a sort (fsearch.py:2679-2719: the `hits` dict keyed (subject, qst - sst)).
+//
+// The reference drops every seed hit into a dict keyed by (subject, diagonal).  The first MI355X version of this stage
+// wrote an 8-byte key per hit and ran a library segmented radix sort over them (77 B of HBM traffic per hit).  What the
+// extension kernel needs is weaker than sorted order: the hits of one (query, subject, diagonal) group next to each other,
+// by ascending query position, and neighbouring groups close in the subject array.  This file produces exactly that:
+//
+//   1. tiles           a query's hit ordinals are cut into tiles of <= 1024 (k_bkt_ntiles / k_bkt_tiledesc), so a tile never
+//                      straddles two queries.
+//   2. k_bkt_pass      the seed-lookup kernel, run twice.  A BUCKET is (query, range of W = 2^wb chunk sequences); inside
+//                      its bucket a hit is ONE 32-bit word  subject_low | diagonal | qpos.  Pass 1 counts the hits of
+//                      every (range, tile) in a per-wave LDS histogram and stores the counts range-major; an exclusive scan
+//                      of that matrix IS the scatter plan (buckets range-major, tiles in order inside a bucket); pass 2
+//                      recomputes the hits from the 4-byte index addends (L2 / Infinity-Cache resident) and writes each to
+//                      its final place.  No global atomics, 4 bytes written per hit instead of 8.
+//   3. k_bkt_group     one workgroup per bucket (1-2 k hits): an exact bucket-local sort by (subject, diagonal, qpos) shaped for
+//                      the data -- LDS counting sort by subject, then a rank inside each subject's (mostly tiny) segment.
+//   The extension kernel (k_group.hip: k_ungap) then walks the grouped keys exactly as it walked the sorted ones.
+//
+// The bucket-local sort is a full one, so the scatter needs no stable ranks: an LDS fetch-add hands out slots inside a tile.
+// Scope: one alphabet x one seed pattern, compact index addends and wb + bd + bp <= 31 with wb <= 10; otherwise, or when one
+// subject alone brings more than BG_CAP hits to a query, the host runs the pass on the sorted path.
+#include "common.h"
+#include "kernels.h"
+
+#define BK_WAVES 4
+#define BK_ITERS 16
+#define BK_HITS (64 * BK_ITERS)
+#define BK_SEEDS 256
+
+__device__ __forceinline__ void bk_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ u32 bk_scan_max(u32 x) {  // inclusive max-scan over the wave (DPP)
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+    return x;
+}
+
+// ---- tiles: <= BK_HITS consecutive hit ordinals of ONE query ------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bkt_ntiles(const u32* __restrict__ qseg /*first hit ordinal per pass query, + end*/, u32 nqp,
+                                                    u32* __restrict__ ntile /*nqp + 1*/) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i > nqp) return;
+    ntile[i] = i < nqp ? (qseg[i + 1] - qseg[i] + BK_HITS - 1) / BK_HITS : 0u;
+}
+
+// tile t -> {query (relative to the pass), first ordinal, first seed, last seed}
+__global__ __launch_bounds__(256) void k_bkt_tiledesc(const u32* __restrict__ qseg, const u32* __restrict__ t0 /*nqp + 1*/, u32 nqp, u32 NT,
+                                                      const u32* __restrict__ cs_hoff, u32 K, uint4* __restrict__ td) {
+    const u32 t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= NT) return;
+    u32 lo = 0, hi = nqp;  // largest q with t0[q] <= t (t0[0] == 0; queries without hits own no tile and are skipped by `<=`)
+    while (hi - lo > 1) {
+        const u32 m = (lo + hi) >> 1;
+        if (t0[m] <= t) lo = m;
+        else hi = m;
+    }
+    const u32 q = lo;
+    const u32 first = qseg[q] + (t - t0[q]) * BK_HITS;
+    const u32 last = min(first + BK_HITS, qseg[q + 1]) - 1u;
+    u32 a = 0, b = K;  // largest k with cs_hoff[k] <= first
+    while (b - a > 1) {
+        const u32 m = (a + b) >> 1;
+        if (cs_hoff[m] <= first) a = m;
+        else b = m;
+    }
+    const u32 k0 = a;
+    b = K;
+    while (b - a > 1) {
+        const u32 m = (a + b) >> 1;
+        if (cs_hoff[m] <= last) a = m;
+        else b = m;
+    }
+    td[t] = make_uint4(q, first, k0, a);
+}
+
+// One hit: index addend c (k_encode_delta32 with ba == 0: subject << bd | (maxslen - pos), all-ones diagonal field for an
+// entry at offset 0 of its sequence) + the seed's query position -> subject range and 32-bit word.  Returns false for a
+// dropped hit (offset 0 with no non-empty sequence before it in the chunk: the reference resolves it to index -1,
+// fsearch.py:2685-2688).
+__device__ __forceinline__ bool bk_hit(u32 c, u32 qpos, const BktLayout& L, const u32* __restrict__ roff, u32& range, u32& word) {
+    const u32 dmask = (1u << L.bd) - 1u;
+    u32 j = c >> L.bd, dp = c & dmask;
+    if (dp == dmask) {  // rare: strict `soas[j] < x` puts it at the end of the previous non-empty sequence
+        while (j > 0 && roff[j] == roff[j - 1]) --j;
+        if (j == 0) return false;
+        j -= 1;
+        dp = L.maxslen - (roff[j + 1] - roff[j]);
+    }
+    range = j >> L.wb;
+    word = ((j & ((1u << L.wb) - 1u)) << (L.bd + L.bp)) | ((qpos + dp) << L.bp) | qpos;
+    return true;
+}
+
+// SCATTER = false: mat[range * NT + tile] = hits of the tile in the range (mat zeroed by the host);
+// SCATTER = true : mat holds the exclusive scan of those counts = where the tile's hits of each range go in `out`.
+template <bool SCATTER>
+__global__ __launch_bounds__(64 * BK_WAVES, 4) void k_bkt_pass(const uint4* __restrict__ td, const u32* __restrict__ qseg, u32 NT,
+                                                              const u32* __restrict__ cs_hoff, const u32* __restrict__ cs_base,
+                                                              const u64* __restrict__ cs_kbase, const u32* __restrict__ dk32,
+                                                              const u32* __restrict__ roff, BktLayout L, u32* __restrict__ mat,
+                                                              u32* __restrict__ out) {
+    __shared__ u16 s_owner_all[BK_WAVES][BK_HITS];
+    __shared__ u32 s_base_all[BK_WAVES][BK_SEEDS];
+    __shared__ u16 s_qpos_all[BK_WAVES][BK_SEEDS];
+    __shared__ u32 s_hist_all[BK_WAVES][BKT_RMAX];
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so XCD x takes the x-th contiguous eighth of the
+    // tiles: the tiles of one query, and the output lines they fill, stay in one L2.
+    const u32 per = gridDim.x >> 3;  // the grid is a multiple of 8 workgroups
+    const u32 lb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const u32 t = __builtin_amdgcn_readfirstlane(lb * BK_WAVES + w);
+    if (t >= NT) return;
+    u16* s_owner = s_owner_all[w];
+    u32* s_base = s_base_all[w];
+    u16* s_qpos = s_qpos_all[w];
+    u32* s_hist = s_hist_all[w];
+    const uint4 d = td[t];
+    const u32 q = __builtin_amdgcn_readfirstlane(d.x), lo = __builtin_amdgcn_readfirstlane(d.y);
+    const u32 k0 = __builtin_amdgcn_readfirstlane(d.z), k1 = __builtin_amdgcn_readfirstlane(d.w);
+    const u32 len = min((u32)BK_HITS, __builtin_amdgcn_readfirstlane(qseg[q + 1]) - lo);
+    const u32 ns = k1 - k0 + 1;
+    const u32 pmask = (1u << L.bp) - 1u;
+#pragma unroll
+    for (u32 i = 0; i < BK_ITERS / 4; ++i) reinterpret_cast<uint2*>(s_owner)[i * 64 + lane] = make_uint2(0, 0);
+    for (u32 r = lane; r < L.R; r += 64) s_hist[r] = 0;
+    bk_wave_sync();
+    for (u32 i = lane; i < ns; i += 64) {
+        if (i < BK_SEEDS) {
+            s_base[i] = cs_base[k0 + i];
+            s_qpos[i] = (u16)((u32)(cs_kbase[k0 + i] >> L.sh_qpos) & pmask);
+        }
+        if (i) {
+            const u32 o = cs_hoff[k0 + i] - lo;
+            if (o < len) s_owner[o] = (u16)i;
+        }
+    }
+    bk_wave_sync();
+    u32 word[BK_ITERS], slot[BK_ITERS];  // slot: range | rank << 10; ~0u = no hit
+    u32 carry = 0;
+#pragma unroll
+    for (int it = 0; it < BK_ITERS; ++it) {
+        const u32 hl = it * 64 + lane;
+        const u32 inc = bk_scan_max((u32)s_owner[hl]);
+        const u32 a = max(inc, carry);
+        carry = max(carry, (u32)__builtin_amdgcn_readlane((int)inc, 63));
+        slot[it] = 0xFFFFFFFFu;
+        word[it] = 0;
+        if (hl >= len) continue;
+        const u32 base = (a < BK_SEEDS) ? s_base[a] : cs_base[k0 + a];
+        const u32 qpos = (a < BK_SEEDS) ? (u32)s_qpos[a] : ((u32)(cs_kbase[k0 + a] >> L.sh_qpos) & pmask);
+        const u32 c = dk32[base + lo + hl];
+        u32 r, wd;
+        if (!bk_hit(c, qpos, L, roff, r, wd)) continue;
+        word[it] = wd;
+        slot[it] = r | (atomicAdd(&s_hist[r], 1u) << 10);  // LDS fetch-add: a unique slot inside (tile, range)
+    }
+    bk_wave_sync();
+    if (!SCATTER) {
+        for (u32 r = lane; r < L.R; r += 64) {
+            const u32 n = s_hist[r];
+            if (n) mat[(size_t)r * NT + t] = n;
+        }
+        return;
+    }
+    for (u32 r = lane; r < L.R; r += 64) s_hist[r] = mat[(size_t)r * NT + t];
+    bk_wave_sync();
+#pragma unroll
+    for (int it = 0; it < BK_ITERS; ++it)
+        if (slot[it] != 0xFFFFFFFFu) out[s_hist[slot[it] & 1023u] + (slot[it] >> 10)] = word[it];
+}
+
+// ================================================================================================================
+// grouping kernel: hits of a bucket -> 64-bit keys in (subject, diagonal, qpos) order
+// ================================================================================================================
+// One workgroup per bucket (1-2 k hits over a few hundred subjects).  An exact sort, but shaped for the data: an LDS
+// counting sort by the subject inside the range (one fetch-add per hit), then every hit finds its rank inside its subject's
+// segment by comparing with the segment's other hits.  Nearly all segments hold a handful of hits (a random seed match or
+// two); the few long ones (the query itself, a homolog: hundreds of hits on one or two diagonals) are ranked by whole waves,
+// every lane reading the same LDS word (broadcast).  Hit words of one query are distinct (an index entry meets a query window
+// once), so ranks are unique.  A bucket above BG_CAP hits is done in sub-passes over sub-ranges of its subjects.
+#define BG_THREADS 512
+#define BG_CAP 3072       // hits sorted at a time (6 per thread, kept in registers between the phases)
+#define BG_BINS 1024      // subjects per range (wb <= 10)
+#define BG_SMALL 16       // segments up to this size are ranked by their own hits' threads
+#define BG_NBIG 256       // longer segments per bucket handled by whole waves (more: the slow way, still exact)
+#define BG_SUB 2048       // sub-passes of an oversized bucket are sized for this many hits on average
+#define BG_NONE 0xFFFFFFFFu
+
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt: every barrier would then wait for the key stores
+// of the previous phase and for the next bucket's prefetched hits.  All data the phases exchange lives in LDS; global loads are
+// consumed by the thread that issued them (the compiler counts those).
+__device__ __forceinline__ void bg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// bucket b (range-major) occupies hits[bext[b] .. bext[b + 1])
+__global__ __launch_bounds__(256) void k_bkt_extents(const u32* __restrict__ mat, const u32* __restrict__ t0, u32 NT, u32 nqp, u32 nb,
+                                                     u32* __restrict__ bext /*nb + 1*/) {
+    const u32 b = blockIdx.x * 256u + threadIdx.x;
+    if (b > nb) return;
+    const u32 r = b / nqp, qrel = b - r * nqp;
+    bext[b] = mat[(size_t)r * NT + t0[qrel]];   // b == nb: r = R, qrel = 0 -> mat[R * NT] = total
+}
+
+__global__ __launch_bounds__(BG_THREADS, 4) void k_bkt_group(const u32* __restrict__ hits, const u32* __restrict__ bext /*nb + 1*/, u32 nb,
+                                                            BktLayout L, KeyLayout kl, u64* __restrict__ keys, u32* __restrict__ fallback) {
+    __shared__ u32 s_srt[BG_CAP];          // the hits, grouped by subject
+    __shared__ u32 s_bin[BG_BINS + 1];     // per subject: count -> scatter cursor (= end of its segment afterwards)
+    __shared__ u32 s_big[BG_NBIG];         // long segments: start | size << 16
+    __shared__ u32 s_wsum[BG_THREADS / 64];
+    __shared__ u32 s_ctl[4];               // [0] hits of the sub-pass, [1] long segments, [2] refused
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const u32 dmask = (1u << L.bd) - 1u, pmask = (1u << L.bp) - 1u;
+    const int sshift = L.bd + L.bp;
+    const u32 W = 1u << L.wb;
+    constexpr int HPT = BG_CAP / BG_THREADS;
+    constexpr int BPT = BG_BINS / BG_THREADS;
+    // software pipeline over the persistent loop: extents are fetched two buckets ahead, hits one bucket ahead
+    const u32 G = gridDim.x;
+    u32 e0 = 0, e1 = 0, f0 = 0, f1 = 0, nhit[HPT];
+    auto fetch_extent = [&](u32 b, u32& lo, u32& hi) {
+        lo = hi = 0;
+        if (b < nb) lo = bext[b], hi = bext[b + 1];
+    };
+    auto fetch_hits = [&](u32 lo, u32 hi) {
+        const u32 cnt = hi - lo;
+#pragma unroll
+        for (int k = 0; k < HPT; ++k) {
+            const u32 j = (u32)tid + (u32)k * BG_THREADS;
+            nhit[k] = (cnt <= BG_CAP && j < cnt) ? hits[lo + j] : BG_NONE;
+        }
+    };
+    fetch_extent(blockIdx.x, e0, e1);
+    fetch_hits(e0, e1);
+    fetch_extent(blockIdx.x + G, f0, f1);
+    for (u32 b = blockIdx.x; b < nb; b += G) {
+        const u32 b0 = e0, n = e1 - e0;
+        u32 my[HPT];
+#pragma unroll
+        for (int k = 0; k < HPT; ++k) my[k] = nhit[k];
+        e0 = f0, e1 = f1;
+        fetch_hits(e0, e1);                 // bucket b + G (its extent arrived during the previous bucket)
+        fetch_extent(b + 2 * G, f0, f1);    // bucket b + 2G
+        if (n == 0) continue;
+        const u32 r = b / L.nqp, qrel = b - r * L.nqp;
+        const u64 kq = ((u64)(L.qa + qrel) << kl.sh_q) | ((u64)(r << L.wb) << kl.sh_subj);  // the bucket's share of every key
+        u32 K = 1;
+        while ((u64)K * BG_SUB < n && n > BG_CAP && K < W) K <<= 1;
+        const u32 wsub = W / K;  // subjects per sub-pass
+        u32 cursor = b0;
+        for (u32 sp = 0; sp < K; ++sp) {
+            const u32 slo = sp * wsub;
+            // ---- A: clear the subject bins ----
+            bg_barrier();  // the previous round's LDS is no longer read
+#pragma unroll
+            for (int i = 0; i < BPT; ++i) s_bin[i * BG_THREADS + tid] = 0;
+            if (tid < 4) s_ctl[tid] = 0;
+            bg_barrier();
+            // ---- B: count per subject ----
+            if (K == 1) {
+#pragma unroll
+                for (int k = 0; k < HPT; ++k)
+                    if (my[k] != BG_NONE) atomicAdd(&s_bin[my[k] >> sshift], 1u);
+            } else {
+                u32 mine = 0;
+                for (u32 j = (u32)tid; j < n; j += BG_THREADS) {
+                    const u32 sj = (hits[b0 + j] >> sshift) - slo;
+                    if (sj < wsub) atomicAdd(&s_bin[sj], 1u), ++mine;
+                }
+                if (mine) atomicAdd(&s_ctl[0], mine);
+            }
+            bg_barrier();
+            const u32 npass = K == 1 ? n : s_ctl[0];
+            if (npass > BG_CAP) {  // one subject sub-range still holds too many hits: the host reruns the pass on the sorted path
+                if (tid == 0) atomicOr(fallback, 1u);
+                break;
+            }
+            // ---- C: exclusive prefix over the bins (2 per thread): segment starts ----
+            {
+                u32 c[BPT], tot = 0;
+#pragma unroll
+                for (int k = 0; k < BPT; ++k) {
+                    c[k] = s_bin[tid * BPT + k];
+                    tot += c[k];
+                }
+                u32 inc = tot;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const u32 x = __shfl_up(inc, o);
+                    if (lane >= o) inc += x;
+                }
+                if (lane == 63) s_wsum[w] = inc;
+                bg_barrier();
+                u32 run = inc - tot;
+                for (int k = 0; k < w; ++k) run += s_wsum[k];
+#pragma unroll
+                for (int k = 0; k < BPT; ++k) {
+                    s_bin[tid * BPT + k] = run;
+                    if (c[k] > BG_SMALL) {  // a long segment: whole waves rank it
+                        const u32 i = atomicAdd(&s_ctl[1], 1u);
+                        if (i < BG_NBIG) s_big[i] = run | (c[k] << 16);
+                    }
+                    run += c[k];
+                }
+            }
+            bg_barrier();
+            // ---- D: scatter by subject (the bin becomes the cursor: afterwards it holds the END of its segment) ----
+            if (K == 1) {
+#pragma unroll
+                for (int k = 0; k < HPT; ++k)
+                    if (my[k] != BG_NONE) s_srt[atomicAdd(&s_bin[my[k] >> sshift], 1u)] = my[k];
+            } else {
+                for (u32 j = (u32)tid; j < n; j += BG_THREADS) {
+                    const u32 hw = hits[b0 + j];
+                    const u32 sj = (hw >> sshift) - slo;
+                    if (sj < wsub) s_srt[atomicAdd(&s_bin[sj], 1u)] = hw;
+                }
+            }
+            bg_barrier();
+            // ---- E: rank inside the subject's segment = final position; short segments by their own hits' threads ----
+            const u32 nbig = min(s_ctl[1], (u32)BG_NBIG);
+            const bool big_all = s_ctl[1] > BG_NBIG;  // more long segments than the list holds: everything the slow way
+            for (u32 p = (u32)tid; p < npass; p += BG_THREADS) {
+                const u32 x = s_srt[p];
+                const u32 sj = (x >> sshift) - slo;
+                const u32 a = sj ? s_bin[sj - 1] : 0u, e = s_bin[sj];
+                if (e - a > BG_SMALL && !big_all) continue;
+                u32 rank = 0;
+                for (u32 k = a; k < e; ++k) rank += (s_srt[k] < x) ? 1u : 0u;
+                keys[cursor + a + rank] = kq + ((u64)(x >> sshift) << kl.sh_subj) + ((u64)((x >> L.bp) & dmask) << kl.sh_diag) +
+                                          ((u64)(x & pmask) << kl.sh_qpos);
+            }
+            if (!big_all) {
+                for (u32 i = (u32)w; i < nbig; i += BG_THREADS / 64) {  // a wave per long segment; every lane reads the same word
+                    const u32 a = s_big[i] & 0xFFFFu, sz = s_big[i] >> 16;
+                    for (u32 m0 = 0; m0 < sz; m0 += 64) {
+                        const u32 mi = m0 + (u32)lane;
+                        const u32 x = s_srt[a + min(mi, sz - 1u)];
+                        u32 rank = 0;
+                        for (u32 k = 0; k < sz; k += 4) {
+                            u32 v[4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) v[t] = s_srt[a + min(k + (u32)t, sz - 1u)];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) rank += (k + (u32)t < sz && v[t] < x) ? 1u : 0u;
+                        }
+                        if (mi < sz)
+                            keys[cursor + a + rank] = kq + ((u64)(x >> sshift) << kl.sh_subj) + ((u64)((x >> L.bp) & dmask) << kl.sh_diag) +
+                                                      ((u64)(x & pmask) << kl.sh_qpos);
+                    }
+                }
+            }
+            cursor += npass;
+        }
+    }
+}
+
+// ---- launch wrappers -------------------------------------------------------------------------------
+u32 bkt_tile_hits() { return BK_HITS; }
+
+void launch_bkt_ntiles(const u32* qseg, u32 nqp, u32* ntile, hipStream_t st) {
+    hipLaunchKernelGGL(k_bkt_ntiles, dim3((nqp + 1 + 255) / 256), dim3(256), 0, st, qseg, nqp, ntile);
+}
+
+void launch_bkt_tiledesc(const u32* qseg, const u32* t0, u32 nqp, u32 NT, const u32* cs_hoff, u32 K, void* td, hipStream_t st) {
+    if (!NT) return;
+    hipLaunchKernelGGL(k_bkt_tiledesc, dim3((NT + 255) / 256), dim3(256), 0, st, qseg, t0, nqp, NT, cs_hoff, K, (uint4*)td);
+}
+
+void launch_bkt_pass(bool scatter, const void* td, const u32* qseg, u32 NT, const u32* cs_hoff, const u32* cs_base, const u64* cs_kbase,
+                     const u32* dk32, const u32* roff, const BktLayout& L, u32* mat, u32* out, hipStream_t st) {
+    if (!NT) return;
+    const dim3 g(((NT + BK_WAVES - 1) / BK_WAVES + 7u) & ~7u), bl(64 * BK_WAVES);  // multiple of 8: the XCD-aware tile order
+    if (scatter) hipLaunchKernelGGL((k_bkt_pass<true>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, roff, L, mat, out);
+    else hipLaunchKernelGGL((k_bkt_pass<false>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, roff, L, mat, out);
+}
+
+void launch_bkt_extents(const u32* mat, const u32* t0, u32 NT, u32 nqp, u32 nb, u32* bext, hipStream_t st) {
+    hipLaunchKernelGGL(k_bkt_extents, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, mat, t0, NT, nqp, nb, bext);
+}
+
+int bkt_max_wb() {
+    int lg = 0;
+    while ((1 << lg) < BG_BINS) ++lg;
+    return lg;
+}
+
+void launch_bkt_group(const u32* hits, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, u64* keys, u32* fallback,
+                      hipStream_t st) {
+    if (!nb) return;
+    // persistent workgroups striding over the buckets, range-major: the chip writes one subject range at a time
+    const u32 grid = std::min<u32>(nb, 256u * 4u);
+    hipLaunchKernelGGL(k_bkt_group, dim3(grid), dim3(BG_THREADS), 0, st, hits, bext, nb, L, kl, keys, fallback);
+}

@@ -116,3 +116,14 @@ void launch_sum_cells(const AlnRes* res, u32 n, unsigned long long* total, hipSt
 // so_hit records on the device (80 bytes each) from k_emit_hits rows; qoff_abs = offsets of the whole loaded query set
 void launch_make_hits(const int* rows, u32 n, i64 q_lo, const u32* qoff_abs, const u32* roff, i64 D, const double* p2tab, int p2n, void* out,
                       hipStream_t st);
+
+// k_bucket.hip: diagonal binning without a sort (query-aligned tiles, count -> scan -> scatter, LDS hash grouping)
+u32 bkt_tile_hits();
+void launch_bkt_ntiles(const u32* qseg, u32 nqp, u32* ntile, hipStream_t st);
+void launch_bkt_tiledesc(const u32* qseg, const u32* t0, u32 nqp, u32 NT, const u32* cs_hoff, u32 K, void* td /*uint4 x NT*/, hipStream_t st);
+void launch_bkt_pass(bool scatter, const void* td, const u32* qseg, u32 NT, const u32* cs_hoff, const u32* cs_base, const u64* cs_kbase,
+                     const u32* dk32, const u32* roff, const BktLayout& L, u32* mat, u32* out, hipStream_t st);
+int bkt_max_wb();
+void launch_bkt_extents(const u32* mat, const u32* t0, u32 NT, u32 nqp, u32 nb, u32* bext /*nb + 1*/, hipStream_t st);
+void launch_bkt_group(const u32* hits, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, u64* keys, u32* fallback,
+                      hipStream_t st);

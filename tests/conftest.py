@@ -16,7 +16,7 @@ def pytest_configure(config):
 
 def golden_names():
     """fsearch-c level goldens (flags of the native)."""
-    return sorted(f[:-3] for f in os.listdir(GOLD) if f.endswith(".sc") and not f.startswith(("fh_", "orth_")))
+    return sorted(f[:-3] for f in os.listdir(GOLD) if f.endswith(".sc") and not f.startswith(("fh_", "orth_", "nr_")))
 
 
 def launcher_golden_names():
