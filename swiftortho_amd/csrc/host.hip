@@ -924,7 +924,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     // One alphabet x one pattern, compact index addends and wb + bd + bp <= 32; returns false when the pass has to take the
     // sorted path below.
     auto group_bucketed = [&]() -> bool {
-        static const bool enabled = !(getenv("SOHIT_BUCKET") && atoi(getenv("SOHIT_BUCKET")) == 0);
+        const bool enabled = !(getenv("SOHIT_BUCKET") && atoi(getenv("SOHIT_BUCKET")) == 0);
         if (!enabled || AS != 1 || !compact || UG_SHARDS != 1) return false;
         const u32 nqp = qb - qa;
         const int wb_hi = std::min(std::min(31 - kl.bd - kl.bp, kl.bs), bkt_max_wb());   // hit word < 2^31; subjects per range <= the sort's bins
@@ -932,8 +932,12 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         while (((u64)nseq_chunk + (1ull << wb_lo) - 1) >> wb_lo > BKT_RMAX) ++wb_lo;
         if (wb_hi < wb_lo || kl.bp > 16) return false;
         // widest subject range whose average bucket is a few hits per thread of the workgroup that groups it
-        static const u32 target = getenv("SOHIT_BUCKET_AVG") ? (u32)std::max(1, atoi(getenv("SOHIT_BUCKET_AVG"))) : 1536u;
+        const u32 target = getenv("SOHIT_BUCKET_AVG") ? (u32)std::max(1, atoi(getenv("SOHIT_BUCKET_AVG"))) : 1536u;
         int wb = wb_hi;
+        // sparse passes (long seeds: a few hundred hits per query) would leave the grouping kernel walking mostly empty
+        // buckets: the sorted path handles those well (its segments are short)
+        const u32 sparse = getenv("SOHIT_BUCKET_MIN") ? (u32)std::max(0, atoi(getenv("SOHIT_BUCKET_MIN"))) : 192u;
+        if ((u64)H / ((u64)nqp * (((u64)nseq_chunk + (1ull << wb) - 1) >> wb)) < sparse) return false;
         while (wb > wb_lo && (u64)H / ((u64)nqp * (((u64)nseq_chunk + (1ull << wb) - 1) >> wb)) > target) --wb;
         BktLayout L;
         L.wb = wb, L.bd = kl.bd, L.bp = kl.bp, L.sh_q = kl.sh_q, L.sh_qpos = kl.sh_qpos, L.nqp = nqp, L.qa = qa;

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(BG_THREADS, 4) void k_bkt_group(const u32* __restri
                                                             BktLayout L, KeyLayout kl, u64* __restrict__ keys, u32* __restrict__ fallback) {
     __shared__ u32 s_srt[BG_CAP];          // the hits, grouped by subject
     __shared__ u32 s_bin[BG_BINS + 1];     // per subject: count -> scatter cursor (= end of its segment afterwards)
-    __shared__ u32 s_big[BG_NBIG];         // long segments: start | size << 16
+    __shared__ u32 s_big[BG_NBIG];         // work units of long segments: start | size << 12 | 64-member block << 24
     __shared__ u32 s_wsum[BG_THREADS / 64];
     __shared__ u32 s_ctl[4];               // [0] hits of the sub-pass, [1] long segments, [2] refused
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -303,9 +303,10 @@ __global__ __launch_bounds__(BG_THREADS, 4) void k_bkt_group(const u32* __restri
 #pragma unroll
                 for (int k = 0; k < BPT; ++k) {
                     s_bin[tid * BPT + k] = run;
-                    if (c[k] > BG_SMALL) {  // a long segment: whole waves rank it
-                        const u32 i = atomicAdd(&s_ctl[1], 1u);
-                        if (i < BG_NBIG) s_big[i] = run | (c[k] << 16);
+                    if (c[k] > BG_SMALL) {  // a long segment: whole waves rank it, 64 members per work unit
+                        const u32 nu = (c[k] + 63u) >> 6;
+                        const u32 i = atomicAdd(&s_ctl[1], nu);
+                        for (u32 u = 0; u < nu && i + u < BG_NBIG; ++u) s_big[i + u] = run | (c[k] << 12) | (u << 24);
                     }
                     run += c[k];
                 }
@@ -338,23 +339,20 @@ __global__ __launch_bounds__(BG_THREADS, 4) void k_bkt_group(const u32* __restri
                                           ((u64)(x & pmask) << kl.sh_qpos);
             }
             if (!big_all) {
-                for (u32 i = (u32)w; i < nbig; i += BG_THREADS / 64) {  // a wave per long segment; every lane reads the same word
-                    const u32 a = s_big[i] & 0xFFFFu, sz = s_big[i] >> 16;
-                    for (u32 m0 = 0; m0 < sz; m0 += 64) {
-                        const u32 mi = m0 + (u32)lane;
-                        const u32 x = s_srt[a + min(mi, sz - 1u)];
-                        u32 rank = 0;
-                        for (u32 k = 0; k < sz; k += 4) {
-                            u32 v[4];
+                for (u32 i = (u32)w; i < nbig; i += BG_THREADS / 64) {  // a wave per unit; every lane reads the same word (broadcast)
+                    const u32 a = s_big[i] & 0xFFFu, sz = (s_big[i] >> 12) & 0xFFFu, mi = (s_big[i] >> 24) * 64u + (u32)lane;
+                    const u32 x = s_srt[a + min(mi, sz - 1u)];
+                    u32 rank = 0;
+                    for (u32 k = 0; k < sz; k += 4) {
+                        u32 v[4];
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) v[t] = s_srt[a + min(k + (u32)t, sz - 1u)];
+                        for (int t = 0; t < 4; ++t) v[t] = s_srt[a + min(k + (u32)t, sz - 1u)];
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) rank += (k + (u32)t < sz && v[t] < x) ? 1u : 0u;
-                        }
-                        if (mi < sz)
-                            keys[cursor + a + rank] = kq + ((u64)(x >> sshift) << kl.sh_subj) + ((u64)((x >> L.bp) & dmask) << kl.sh_diag) +
-                                                      ((u64)(x & pmask) << kl.sh_qpos);
+                        for (int t = 0; t < 4; ++t) rank += (k + (u32)t < sz && v[t] < x) ? 1u : 0u;
                     }
+                    if (mi < sz)
+                        keys[cursor + a + rank] = kq + ((u64)(x >> sshift) << kl.sh_subj) + ((u64)((x >> L.bp) & dmask) << kl.sh_diag) +
+                                                  ((u64)(x & pmask) << kl.sh_qpos);
                 }
             }
             cursor += npass;

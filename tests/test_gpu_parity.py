@@ -300,6 +300,45 @@ def test_randomised_differential(fs, oracle, tmp_path, monkeypatch, seed):
         oracle_vs_gpu(fs, oracle, fa, kw, tmp_path, sub=(lo, hi))
 
 
+BUCKET_CASES = {
+    # name: (proteins, length, rng seed, kwargs overrides, SOHIT_BUCKET_AVG)
+    "families_narrow_ranges": (2500, 250, 91, dict(), "64"),          # many subject ranges, small buckets
+    "families_wide_ranges": (2500, 250, 92, dict(), "100000"),       # one range per chunk: buckets above BG_CAP -> sub-passes
+    "multichunk": (1800, 200, 93, dict(chk=700), "256"),
+    "uniform": (1500, 300, 94, dict(uniform=True, ht=50021), "512"),  # colliding buckets, no homologs
+    "nofilter_thr": (1200, 180, 95, dict(flt="F", thr=7, max_miss=0.5, v=3), "256"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BUCKET_CASES))
+def test_bucketed_binning_forced_vs_oracle(fs, oracle, tmp_path, monkeypatch, name):
+    """The sort-free diagonal binning (k_bucket.hip: count / scan / scatter into (query, subject range) buckets, bucket-local LDS
+    sort) forced on regardless of the pass-size heuristic, at several range widths; rows, candidates and counters equal the
+    oracle's, and the profile shows that the bucketed kernels really ran."""
+    from swiftortho_amd import synthprot
+    n, ln, seed, over, avg = BUCKET_CASES[name]
+    over = dict(over)
+    fa = (synthprot.uniform_proteins if over.pop("uniform", False) else synthprot.synthprot)(n, ln, seed)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=120000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    kw.update(over)
+    monkeypatch.setenv("SOHIT_BUCKET_MIN", "0")
+    monkeypatch.setenv("SOHIT_BUCKET_AVG", avg)
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+    s = fs.Searcher(profile=True, **kw)
+    s.load_ref_bytes(fa)
+    s.load_queries_bytes(fa)
+    s.search().close()
+    assert "group.bucket_group" in s.timing() and "group.sort_keys" not in s.timing()
+    s.close()
+    monkeypatch.setenv("SOHIT_BUCKET", "0")   # and the sorted path is still there
+    s = fs.Searcher(profile=True, **kw)
+    s.load_ref_bytes(fa)
+    s.load_queries_bytes(fa)
+    s.search().close()
+    assert "group.sort_keys" in s.timing() and "group.bucket_group" not in s.timing()
+    s.close()
+
+
 def test_exact_threshold_replay(fs, oracle, monkeypatch):
     """the rare exact get_mu_sd replay path gives the same threshold as the integer-sum path"""
     from swiftortho_amd import synthprot
