@@ -146,22 +146,28 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void k_bkt_pass(const uint4* __re
     bk_wave_sync();
     u32 word[BK_ITERS], slot[BK_ITERS];  // slot: range | rank << 10; ~0u = no hit
     u32 carry = 0;
+    // all 16 index reads of the tile are issued before the first one is used (a dependent load -> LDS fetch-add chain per
+    // step would leave the wave waiting on L2 sixteen times)
 #pragma unroll
     for (int it = 0; it < BK_ITERS; ++it) {
         const u32 hl = it * 64 + lane;
         const u32 inc = bk_scan_max((u32)s_owner[hl]);
         const u32 a = max(inc, carry);
         carry = max(carry, (u32)__builtin_amdgcn_readlane((int)inc, 63));
-        slot[it] = 0xFFFFFFFFu;
-        word[it] = 0;
-        if (hl >= len) continue;
         const u32 base = (a < BK_SEEDS) ? s_base[a] : cs_base[k0 + a];
-        const u32 qpos = (a < BK_SEEDS) ? (u32)s_qpos[a] : ((u32)(cs_kbase[k0 + a] >> L.sh_qpos) & pmask);
-        const u32 c = dk32[base + lo + hl];
+        slot[it] = (a < BK_SEEDS) ? (u32)s_qpos[a] : ((u32)(cs_kbase[k0 + a] >> L.sh_qpos) & pmask);  // the seed's qpos, for now
+        word[it] = dk32[base + lo + min(hl, len - 1u)];                                            // the index addend, for now
+    }
+#pragma unroll
+    for (int it = 0; it < BK_ITERS; ++it) {
+        const u32 hl = it * 64 + lane;
+        const u32 c = word[it], qpos = slot[it];
+        slot[it] = 0xFFFFFFFFu;
         u32 r, wd;
-        if (!bk_hit(c, qpos, L, roff, r, wd)) continue;
-        word[it] = wd;
-        slot[it] = r | (atomicAdd(&s_hist[r], 1u) << 10);  // LDS fetch-add: a unique slot inside (tile, range)
+        if (hl < len && bk_hit(c, qpos, L, roff, r, wd)) {
+            word[it] = wd;
+            slot[it] = r | (atomicAdd(&s_hist[r], 1u) << 10);  // LDS fetch-add: a unique slot inside (tile, range)
+        }
     }
     bk_wave_sync();
     if (!SCATTER) {
