@@ -248,7 +248,7 @@ struct so_ctx {
     DevBuf<u8> d_sort_tmp;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t max_hits_per_pass = (size_t)1 << 30;
-    u32 max_batch = 16384;
+    u32 max_batch = 65536;  // queries per device batch (config 3: 16384 -> 124 ms, 32768 -> 111, 65536 -> 109, 131072 -> 115: fewer passes, still two batches to overlap row emission)
     // device SEG: tables, symbol folding of the loaded query set
     DevBuf<u8> d_segtab, d_symmap, d_upmap, d_segmask;
     bool seg_on_device = false;
