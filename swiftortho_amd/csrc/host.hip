@@ -1385,8 +1385,12 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
     const int nchunks = (int)c->chunks.size();
     if (const char* e = getenv("SOHIT_BATCH")) c->max_batch = (u32)std::max(1, atoi(e));
     if (const char* e = getenv("SOHIT_MAX_HITS")) c->max_hits_per_pass = (size_t)std::max(1ll, atoll(e));
-    for (i64 b0 = st; b0 < ed; b0 += c->max_batch) {
-        const i64 b1 = std::min<i64>(ed, b0 + c->max_batch);
+    // A batch's candidate store is indexed with 32 bits, and a query has at most one candidate per reference sequence:
+    // unless SOHIT_BATCH says otherwise, keep queries x reference sequences below 2^32 so that the store cannot overflow.
+    u32 batch_q = c->max_batch;
+    if (!getenv("SOHIT_BATCH")) batch_q = (u32)std::min<u64>(batch_q, std::max<u64>(1024, 0xE0000000ull / (u64)std::max<i64>(D, 1)));
+    for (i64 b0 = st; b0 < ed; b0 += batch_q) {
+        const i64 b1 = std::min<i64>(ed, b0 + batch_q);
         if (!c->batch) c->batch = std::make_shared<Batch>();
         Batch& b = *static_cast<Batch*>(c->batch.get());
         b.chunk_base.clear();
