@@ -932,7 +932,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         while (((u64)nseq_chunk + (1ull << wb_lo) - 1) >> wb_lo > BKT_RMAX) ++wb_lo;
         if (wb_hi < wb_lo || kl.bp > 16) return false;
         // widest subject range whose average bucket is a few hits per thread of the workgroup that groups it
-        const u32 target = getenv("SOHIT_BUCKET_AVG") ? (u32)std::max(1, atoi(getenv("SOHIT_BUCKET_AVG"))) : 1536u;
+        const u32 target = getenv("SOHIT_BUCKET_AVG") ? (u32)std::max(1, atoi(getenv("SOHIT_BUCKET_AVG"))) : 2560u;
         int wb = wb_hi;
         // sparse passes (long seeds: a few hundred hits per query) would leave the grouping kernel walking mostly empty
         // buckets: the sorted path handles those well (its segments are short)

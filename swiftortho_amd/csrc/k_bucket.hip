@@ -194,11 +194,15 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void k_bkt_pass(const uint4* __re
 // every lane reading the same LDS word (broadcast).  Hit words of one query are distinct (an index entry meets a query window
 // once), so ranks are unique.  A bucket above BG_CAP hits is done in sub-passes over sub-ranges of its subjects.
 #define BG_THREADS 512
-#define BG_CAP 3072       // hits sorted at a time (6 per thread, kept in registers between the phases)
+#ifndef BG_CAP
+#define BG_CAP 4096       // hits sorted at a time (8 per thread, kept in registers between the phases)
+#endif
+#ifndef BG_BINS
 #define BG_BINS 1024      // subjects per range (wb <= 10)
+#endif
 #define BG_SMALL 16       // segments up to this size are ranked by their own hits' threads
 #define BG_NBIG 256       // longer segments per bucket handled by whole waves (more: the slow way, still exact)
-#define BG_SUB 2048       // sub-passes of an oversized bucket are sized for this many hits on average
+#define BG_SUB (BG_CAP * 2 / 3)   // sub-passes of an oversized bucket are sized for this many hits on average
 #define BG_NONE 0xFFFFFFFFu
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt: every barrier would then wait for the key stores
