@@ -85,6 +85,8 @@ typedef struct so_counters {
     int64_t align_launches;
     double align_ms;
     double index_ms, seed_ms, group_ms, phase2_ms, total_ms; /* host-side stage wall times */
+    int64_t count_launches;            /* launches of the lookup kernel's COUNT pass (bucketed binning) */
+    double count_ms;                   /* their summed duration; lookup_* then describe its SCATTER pass */
 } so_counters;
 
 /* Lifetime.  Replaces: spawning `fsearch-c` with its flags (find_hit.py:119-123). */

@@ -960,8 +960,12 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         const size_t nm = (size_t)L.R * NT;
         b.bmat.ensure(nm + 4);
         HIP_CHECK(hipMemsetAsync(b.bmat.p, 0, (nm + 4) * sizeof(u32), c->st));
-        launch_bkt_pass(false, b.btd.p, qseg, NT, b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, ch.dk32.p, c->ref.d_off.p + ch.seq_lo, L, b.bmat.p, nullptr,
-                        c->st);
+        {
+            ProfTimer pt(c, &c->cnt.count_ms, &c->cnt.count_launches);
+            launch_bkt_pass(false, b.btd.p, qseg, NT, b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, ch.dk32.p, c->ref.d_off.p + ch.seq_lo, L, b.bmat.p,
+                            nullptr, c->st);
+            pt.stop();
+        }
         c->d_scan_tmp.ensure(scan_u32_temp_elems(nm + 1) + 8);
         const u32 Hv = d2h_u32(c, scan_u32(b.bmat.p, b.bmat.p, nm + 1, false, c->d_scan_tmp.p, c->st));  // hits kept (all but the dropped offset-0 ones)
         sc.lap("seed.bucket_count");
