@@ -111,6 +111,7 @@ int so_load_queries_mem(so_ctx *ctx, const char *fasta_bytes, int64_t nbytes);
 int64_t so_num_queries(const so_ctx *ctx);
 int64_t so_num_refs(const so_ctx *ctx);
 int64_t so_query_len(const so_ctx *ctx, int64_t qidx);
+int64_t so_ref_len(const so_ctx *ctx, int64_t sidx); /* residues of reference sequence sidx (the index exporter's `soas`) */
 
 /* The search.  Replaces: blastp(qry, ref, ..., st=-l, ed=-u) (fsearch.py:2968-3121):
  * queries [q_lo, q_hi) of the loaded query file against the loaded reference; rows come

@@ -38,7 +38,7 @@ EXPORTS = ["so_abi_version", "so_create", "so_destroy", "so_last_error", "so_loa
            "so_load_queries", "so_load_queries_mem", "so_num_queries", "so_num_refs", "so_query_len", "so_search_loaded",
            "so_search", "so_free_hits", "so_write_sc", "so_format_hit", "so_get_counters", "so_reset_counters", "so_timing_report",
            "so_chunk_threshold", "so_chunk_entries", "so_chunk_download", "so_masked_query", "so_query_candidates", "so_set_profile",
-           "so_bucket_count", "so_search_device", "so_device_hits_copy", "so_query_work"]
+           "so_bucket_count", "so_ref_len", "so_search_device", "so_device_hits_copy", "so_query_work"]
 
 _lib = None
 
@@ -94,6 +94,8 @@ def load():
         getattr(L, f).argtypes = [vp]
     L.so_query_len.restype = i64
     L.so_query_len.argtypes = [vp, i64]
+    L.so_ref_len.restype = i64
+    L.so_ref_len.argtypes = [vp, i64]
     L.so_search_loaded.argtypes = [vp, i64, i64, C.POINTER(C.POINTER(SoHit)), C.POINTER(i64)]
     L.so_search.argtypes = [vp, cp, i64, i64, C.POINTER(C.POINTER(SoHit)), C.POINTER(i64)]
     L.so_free_hits.argtypes = [C.POINTER(SoHit)]

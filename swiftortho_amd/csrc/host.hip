@@ -1662,6 +1662,7 @@ int so_load_queries_mem(so_ctx* c, const char* bytes, int64_t n) {
 
 int64_t so_num_queries(const so_ctx* c) { return c && c->qry_loaded ? c->qry.N : -1; }
 int64_t so_num_refs(const so_ctx* c) { return c && c->ref_loaded ? c->ref.N : -1; }
+int64_t so_ref_len(const so_ctx* c, int64_t j) { return (c && c->ref_loaded && j >= 0 && j < c->ref.N) ? (int64_t)c->ref.len(j) : -1; }
 int64_t so_query_len(const so_ctx* c, int64_t q) { return (c && c->qry_loaded && q >= 0 && q < c->qry.N) ? (int64_t)c->qry.len(q) : -1; }
 
 int so_search_loaded(so_ctx* c, int64_t q_lo, int64_t q_hi, so_hit** hits, int64_t* n_hits) {

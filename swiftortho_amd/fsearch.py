@@ -84,6 +84,10 @@ class Searcher:
         n = self.num_queries
         return np.array([self.L.so_query_len(self.h, i) for i in range(n)], dtype=np.int64)
 
+    def ref_lengths(self):
+        n = self.num_refs
+        return np.array([self.L.so_ref_len(self.h, i) for i in range(n)], dtype=np.int64)
+
     # search -----------------------------------------------------------------------------------
     def search(self, st=-1, ed=-1):
         """Queries [st, ed) of the loaded query file -> Hits (owning wrapper)."""
@@ -256,6 +260,45 @@ def blastp(qry, ref, expect=1e-5, v=500, max_miss=1e-3, st=-1, ed=-1, rst=-1, re
         hits.close()
     finally:
         s.close()
+
+
+def makedb(ref, space='11111111', nr=AA9, step=1, ht=-1, chk=500000, device=0):
+    """fsearch.py:2809-2814 + Fasta.makedb / Fasta.write (2283-2352): build the chunk indexes of `ref` (on the GPU) and write them
+    in the reference's on-disk format, `<ref>.<k>.idx` (locus: int32 per index entry, a bucket's entries in the reference's
+    slot order = descending insertion order), `<ref>.<k>.soas` (prefix lengths of the chunk's sequences) and `<ref>.<k>.bin`
+    (start[NC] + the trailer `offset;offend;max weight;threshold;NC;seeds;alphabet` + one length byte).  Nothing in the
+    reference's own entry point reads these files back (`entry_point` accepts `-p blastp` only and `blastp` always indexes in
+    memory); they are written for tools that consume the format.  Returns the list of (start, end) chunk ranges."""
+    s = Searcher(ssd=space, nr=nr, ht=ht, chk=chk, step=step, device=device)
+    out = []
+    try:
+        s.load_ref(ref)
+        s.build_index()
+        lens = s.ref_lengths()
+        N = len(lens)
+        mw = max(sp.count('1') for sp in space.split(','))
+        NC = s.nc
+        for k, i in enumerate(range(0, N, chk)):
+            st, ed = i, min(i + chk, N)
+            start, ent = s.chunk_index(k)
+            soas = np.concatenate([[0], np.cumsum(lens[st:ed])]).astype(np.int64)
+            E = len(ent)
+            bucket = np.repeat(np.arange(NC, dtype=np.int64), np.diff(start.astype(np.int64)))
+            order = np.lexsort((np.iinfo(np.uint64).max - ent, bucket))   # bucket ascending, entry descending inside a bucket
+            e = ent[order]
+            locus = soas[(e >> np.uint64(32)).astype(np.int64)] + (e & np.uint64(0xFFFFFF)).astype(np.int64)
+            assert len(bucket) == E
+            name = '%s.%d' % (ref, i // chk)
+            locus.astype('<i4').tofile(name + '.idx')
+            soas.astype('<i4').tofile(name + '.soas')
+            trailer = '%d;%d;%d;%d;%d;%s;%s' % (st, ed + 1, mw, s.chunk_threshold(k), NC, space, nr)
+            with open(name + '.bin', 'wb') as f:
+                start[:NC].astype('<i4').tofile(f)
+                f.write(trailer.encode('latin-1') + bytes([len(trailer) & 0xFF]))
+            out.append((st, ed))
+    finally:
+        s.close()
+    return out
 
 
 def manual_print(out=None):

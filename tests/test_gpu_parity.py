@@ -339,6 +339,20 @@ def test_bucketed_binning_forced_vs_oracle(fs, oracle, tmp_path, monkeypatch, na
     s.close()
 
 
+def test_makedb_writes_the_reference_index_files(fs, tmp_path):
+    """fsearch.makedb: the chunk indexes built on the GPU, written in the reference's on-disk format (.idx / .soas / .bin,
+    fsearch.py:2283-2352), are byte-identical to the files the REAL reference wrote (tests/golden/idx_toy.*: three chunks, two
+    seed patterns, colliding buckets)."""
+    import shutil
+    meta = json.load(open(os.path.join(GOLD, "idx_toy.json")))
+    ref = str(tmp_path / "ref.fsa")
+    shutil.copyfile(os.path.join(GOLD, "idx_toy.ref.fsa"), ref)
+    chunks = fs.makedb(ref, **meta["args"])
+    assert len(chunks) == 3
+    for suffix in meta["files"]:
+        assert open(ref + suffix, "rb").read() == open(os.path.join(GOLD, "idx_toy" + suffix), "rb").read(), suffix
+
+
 def test_exact_threshold_replay(fs, oracle, monkeypatch):
     """the rare exact get_mu_sd replay path gives the same threshold as the integer-sum path"""
     from swiftortho_amd import synthprot

@@ -148,3 +148,21 @@ def test_launcher_golden(oracle, name, tmp_path):
         assert len(outs) > 2
         fh.merge_parts(sorted(outs), p["bv"], out)
     assert open(out, "rb").read() == open(os.path.join(GOLD, name + ".sc"), "rb").read()
+
+
+def test_index_files_golden(oracle):
+    """The reference's on-disk index files (tests/golden/idx_toy.*, written by the real Fasta.makedb / Fasta.write) against the
+    oracle's chunk indexes: locus, soas, start and the parameter trailer, byte for byte."""
+    meta = json.load(open(os.path.join(GOLD, "idx_toy.json")))
+    a = meta["args"]
+    fa = open(os.path.join(GOLD, "idx_toy.ref.fsa"), "rb").read()
+    n = fa.count(b">")
+    mw = max(sp.count("1") for sp in a["space"].split(","))
+    for k, st in enumerate(range(0, n, a["chk"])):
+        ed = min(st + a["chk"], n)
+        ix = oracle.Index(fa, a["space"], a["nr"], a["step"], a["ht"], st, ed)
+        assert ix.locus().astype("<i4").tobytes() == open(os.path.join(GOLD, "idx_toy.%d.idx" % k), "rb").read()
+        assert ix.soas().astype("<i4").tobytes() == open(os.path.join(GOLD, "idx_toy.%d.soas" % k), "rb").read()
+        trailer = "%d;%d;%d;%d;%d;%s;%s" % (st, ed + 1, mw, ix.threshold, a["ht"], a["space"], a["nr"])
+        want = ix.start().astype("<i4").tobytes() + trailer.encode() + bytes([len(trailer)])
+        assert want == open(os.path.join(GOLD, "idx_toy.%d.bin" % k), "rb").read()

@@ -362,6 +362,20 @@ def main():
     run_find_hit("fh_more_queries", first_records(whole, 30), whole, fh)
     run_find_hit("fh_blocks", first_records(whole, 30), whole, fh + ["-a", "3", "-l", "5", "-u", "48"])
     run_find_hit("fh_split", whole, first_records(whole, 40), fh + ["-v", "1"], max_chr=3000)
+    # on-disk index files (Fasta.makedb / Fasta.write, fsearch.py:2283-2352) as the reference writes them
+    if FORCE or not os.path.isfile(os.path.join(GOLD, "idx_toy.json")):
+        tmp = tempfile.mkdtemp(prefix="gold_")
+        fa = synthprot.synthprot(60, 100, 3)
+        p = os.path.join(tmp, "ref.fsa")
+        open(p, "wb").write(fa)
+        args = dict(space="111111,1101011", nr=AA9, step=1, ht=5003, chk=25)
+        m.makedb(p, **args)
+        open(os.path.join(GOLD, "idx_toy.ref.fsa"), "wb").write(fa)
+        files = sorted(f for f in os.listdir(tmp) if f.startswith("ref.fsa."))
+        for f in files:
+            open(os.path.join(GOLD, "idx_toy" + f[len("ref.fsa"):]), "wb").write(open(os.path.join(tmp, f), "rb").read())
+        json.dump({"args": args, "files": [f[len("ref.fsa"):] for f in files]}, open(os.path.join(GOLD, "idx_toy.json"), "w"), indent=1)
+        print("idx_toy", files)
     stage_dump(m, "stage_default", synthprot.synthprot(99, 150, 21), "111111", AA9, 1000003)
     stage_dump(m, "stage_multi", synthprot.synthprot(60, 100, 3), "111111,1101011", AA9 + "/" + AA10B, 200003)
 
