@@ -247,6 +247,10 @@ __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ ta
     int i = bi, j = bj, AL = 0, matches = 0, fm1 = 0, f0 = 0, f1 = 0;
     int wkey = -1;  // (8-row block, lane) of the cached trace word
     u32 wv = 0;
+    // residues through 8-byte register windows (one load per 8 steps instead of one per step: the walk is a chain of dependent
+    // loads at one wave per SIMD); the residue arrays are padded, so a window may reach past its sequence
+    int cwin = -1, rwin = -1;
+    u64 cw8 = 0, rw8 = 0;
     while (i > 0 || j > 0) {
         int tc;
         if (i == 0) tc = 2;
@@ -262,7 +266,17 @@ __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ ta
         }
         if (tc == 0) break;
         ++AL;
-        const int a0 = tc == 3 ? '-' : (int)craw[j - 1], a1 = tc == 2 ? '-' : (int)rraw[i - 1];  // the column's two characters (1419-1432)
+        int a0 = '-', a1 = '-';  // the column's two characters (1419-1432)
+        if (tc != 3) {
+            const int k = j - 1;
+            if ((k >> 3) != cwin) cwin = k >> 3, __builtin_memcpy(&cw8, craw + (k & ~7), 8);
+            a0 = (int)((cw8 >> ((k & 7) << 3)) & 0xFFu);
+        }
+        if (tc != 2) {
+            const int k = i - 1;
+            if ((k >> 3) != rwin) rwin = k >> 3, __builtin_memcpy(&rw8, rraw + (k & ~7), 8);
+            a1 = (int)((rw8 >> ((k & 7) << 3)) & 0xFFu);
+        }
         matches += (a0 == a1) ? 1 : 0;
         const bool g0 = a0 == '-', g1 = a1 == '-';
         const int nm1 = g0 ? 1 + f0 : (g1 ? 1 + f1 : fm1), n0 = g1 ? 1 + f1 : fm1, n1 = g0 ? 1 + f0 : fm1;
