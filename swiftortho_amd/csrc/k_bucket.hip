@@ -129,9 +129,16 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void k_bkt_pass(const uint4* __re
     const u32 len = min((u32)BK_HITS, __builtin_amdgcn_readfirstlane(qseg[q + 1]) - lo);
     const u32 ns = k1 - k0 + 1;
     const u32 pmask = (1u << L.bp) - 1u;
+    // The per-range counters are LDS fetch-adds; with a dozen ranges, 64 lanes pile onto a dozen addresses and the LDS serialises
+    // them (SQ_LDS_ADDR_CONFLICT: 84 % of the LDS cycles).  So the histogram is replicated: lane l uses copy l mod ncopy, as many
+    // copies as fit the BKT_RMAX words (8 for up to 64 ranges); the copies are summed / prefixed when the tile is flushed.
+    int cshift = 0;
+    while ((1u << cshift) < L.R) ++cshift;
+    const u32 ncopy = min(8u, (u32)BKT_RMAX >> cshift);
+    const u32 cbase = (lane & (ncopy - 1u)) << cshift;
 #pragma unroll
     for (u32 i = 0; i < BK_ITERS / 4; ++i) reinterpret_cast<uint2*>(s_owner)[i * 64 + lane] = make_uint2(0, 0);
-    for (u32 r = lane; r < L.R; r += 64) s_hist[r] = 0;
+    for (u32 r = lane; r < (ncopy << cshift); r += 64) s_hist[r] = 0;
     bk_wave_sync();
     for (u32 i = lane; i < ns; i += 64) {
         if (i < BK_SEEDS) {
@@ -166,18 +173,26 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void k_bkt_pass(const uint4* __re
         u32 r, wd;
         if (hl < len && bk_hit(c, qpos, L, roff, r, wd)) {
             word[it] = wd;
-            slot[it] = r | (atomicAdd(&s_hist[r], 1u) << 10);  // LDS fetch-add: a unique slot inside (tile, range)
+            slot[it] = (cbase | r) | (atomicAdd(&s_hist[cbase | r], 1u) << 10);  // LDS fetch-add: a unique slot inside (tile, range, copy)
         }
     }
     bk_wave_sync();
     if (!SCATTER) {
         for (u32 r = lane; r < L.R; r += 64) {
-            const u32 n = s_hist[r];
+            u32 n = 0;
+            for (u32 cpy = 0; cpy < ncopy; ++cpy) n += s_hist[(cpy << cshift) | r];
             if (n) mat[(size_t)r * NT + t] = n;
         }
         return;
     }
-    for (u32 r = lane; r < L.R; r += 64) s_hist[r] = mat[(size_t)r * NT + t];
+    for (u32 r = lane; r < L.R; r += 64) {  // counts -> global start of every (range, copy) share
+        u32 run = mat[(size_t)r * NT + t];
+        for (u32 cpy = 0; cpy < ncopy; ++cpy) {
+            const u32 n = s_hist[(cpy << cshift) | r];
+            s_hist[(cpy << cshift) | r] = run;
+            run += n;
+        }
+    }
     bk_wave_sync();
 #pragma unroll
     for (int it = 0; it < BK_ITERS; ++it)
