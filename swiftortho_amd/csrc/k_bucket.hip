@@ -219,6 +219,7 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void k_bkt_pass(const uint4* __re
 #define BG_NBIG 256       // longer segments per bucket handled by whole waves (more: the slow way, still exact)
 #define BG_SUB (BG_CAP * 2 / 3)   // sub-passes of an oversized bucket are sized for this many hits on average
 #define BG_NONE 0xFFFFFFFFu
+static_assert(BG_CAP <= 4096 && BG_BINS % BG_THREADS == 0 && BG_CAP % BG_THREADS == 0, "s_big packs start in 12 bits and size in 13");
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt: every barrier would then wait for the key stores
 // of the previous phase and for the next bucket's prefetched hits.  All data the phases exchange lives in LDS; global loads are
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(BG_THREADS, 4) void k_bkt_group(const u32* __restri
                                                             BktLayout L, KeyLayout kl, u64* __restrict__ keys, u32* __restrict__ fallback) {
     __shared__ u32 s_srt[BG_CAP];          // the hits, grouped by subject
     __shared__ u32 s_bin[BG_BINS + 1];     // per subject: count -> scatter cursor (= end of its segment afterwards)
-    __shared__ u32 s_big[BG_NBIG];         // work units of long segments: start | size << 12 | 64-member block << 24
+    __shared__ u32 s_big[BG_NBIG];         // work units of long segments: start | size << 12 | 64-member block << 25
     __shared__ u32 s_wsum[BG_THREADS / 64];
     __shared__ u32 s_ctl[4];               // [0] hits of the sub-pass, [1] long segments, [2] refused
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(BG_THREADS, 4) void k_bkt_group(const u32* __restri
                     if (c[k] > BG_SMALL) {  // a long segment: whole waves rank it, 64 members per work unit
                         const u32 nu = (c[k] + 63u) >> 6;
                         const u32 i = atomicAdd(&s_ctl[1], nu);
-                        for (u32 u = 0; u < nu && i + u < BG_NBIG; ++u) s_big[i + u] = run | (c[k] << 12) | (u << 24);
+                        for (u32 u = 0; u < nu && i + u < BG_NBIG; ++u) s_big[i + u] = run | (c[k] << 12) | (u << 25);  // 12 + 13 + 7 bits
                     }
                     run += c[k];
                 }
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(BG_THREADS, 4) void k_bkt_group(const u32* __restri
             }
             if (!big_all) {
                 for (u32 i = (u32)w; i < nbig; i += BG_THREADS / 64) {  // a wave per unit; every lane reads the same word (broadcast)
-                    const u32 a = s_big[i] & 0xFFFu, sz = (s_big[i] >> 12) & 0xFFFu, mi = (s_big[i] >> 24) * 64u + (u32)lane;
+                    const u32 a = s_big[i] & 0xFFFu, sz = (s_big[i] >> 12) & 0x1FFFu, mi = (s_big[i] >> 25) * 64u + (u32)lane;
                     const u32 x = s_srt[a + min(mi, sz - 1u)];
                     u32 rank = 0;
                     for (u32 k = 0; k < sz; k += 4) {

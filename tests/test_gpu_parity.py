@@ -353,6 +353,18 @@ def test_makedb_writes_the_reference_index_files(fs, tmp_path):
         assert open(ref + suffix, "rb").read() == open(os.path.join(GOLD, "idx_toy" + suffix), "rb").read(), suffix
 
 
+@pytest.mark.parametrize("n,ln,avg", [(40, 4300, "100000"), (24, 5200, "64"), (300, 900, "100000")])
+def test_bucketed_binning_long_sequences_vs_oracle(fs, oracle, tmp_path, monkeypatch, n, ln, avg):
+    """Forced bucketed binning on long proteins: a self hit brings thousands of hits on one diagonal to ONE subject -- segments of
+    up to BG_CAP hits ranked by whole waves, and above BG_CAP the kernel refuses and the pass is redone on the sorted path."""
+    from swiftortho_amd import synthprot
+    fa = synthprot.synthprot(n, ln, 1234 + n)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=50000, step=1, v=500, expect=1e-5, flt="F")
+    monkeypatch.setenv("SOHIT_BUCKET_MIN", "0")
+    monkeypatch.setenv("SOHIT_BUCKET_AVG", avg)
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+
+
 def test_exact_threshold_replay(fs, oracle, monkeypatch):
     """the rare exact get_mu_sd replay path gives the same threshold as the integer-sum path"""
     from swiftortho_amd import synthprot
