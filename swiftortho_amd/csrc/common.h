@@ -113,6 +113,27 @@ struct BktLayout {
     u32 maxslen;              // KeyLayout::diag_off
 };
 
+#ifdef __HIPCC__
+// First-touch key of a group whose only / first hit has key k0 (one alphabet x one pattern: the hits of a group are ordered by query
+// position, so the minimum over the group is the head's): (as, qpos, ~j, ~tag, ~pos) -- emission order, then index slot order ==
+// descending (j, tag, pos).  An entry that sits at the end of subject j is the offset-0 entry of chunk sequence j + 1 (see k_lookup).
+__device__ __forceinline__ u64 ft_key_of_head(u64 k0, const KeyLayout& kl, int ft_bits_entry, int bsp, const u32* __restrict__ roff) {
+    const u64 pmask = (1ull << kl.bp) - 1ull, amask = (1ull << kl.ba) - 1ull;
+    const u64 jmax = (1ull << (kl.bs + 1)) - 1ull, pmax = (1ull << bsp) - 1ull;
+    const u32 gsubj = (u32)((k0 >> kl.sh_subj) & ((1ull << kl.bs) - 1ull));
+    const i64 gdiag = (i64)((k0 >> kl.sh_diag) & ((1ull << kl.bd) - 1ull)) - kl.diag_off;  // qpos - sst
+    const int sl = (int)(roff[gsubj + 1] - roff[gsubj]);
+    const int qpos = (int)((k0 >> kl.sh_qpos) & pmask);
+    const u32 as = kl.ba ? (u32)((k0 >> kl.sh_as) & amask) : 0u;
+    const u32 tag = kl.ba ? (u32)(k0 & amask) : 0u;
+    const int sst = (int)((i64)qpos - gdiag);
+    u32 j = gsubj, pos = (u32)sst;
+    if (sst == sl) j = gsubj + 1, pos = 0;
+    const u64 inv = ((jmax - j) << (kl.ba + bsp)) | ((amask - tag) << bsp) | (pmax - pos);
+    return ((((u64)as << kl.bp) | (u64)qpos) << ft_bits_entry) | inv;
+}
+#endif
+
 // One alignment task / result (phase 2).
 struct AlnTask {
     u32 q;        // query index local to the batch

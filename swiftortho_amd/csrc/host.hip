@@ -658,7 +658,7 @@ struct Batch {
     DevBuf<unsigned long long> qhits;
     DevBuf<u64> cs_kbase;
     DevBuf<u64> keys, keys2;
-    DevBuf<u32> hits32, bmat, bt0, btd, bext, bflag;  // bucketed binning (k_bucket.hip)
+    DevBuf<u32> hits32, bmat, bt0, btd, bext, bflag, bcnt, bccnt;  // bucketed binning (k_bucket.hip)
     DevBuf<u32> flags, gidx, ghead;
     DevBuf<u64> p_qs, p_sd, p_ft, p_qs2, tmp64, q_qs, q_sd, q_ft;
     DevBuf<u32> shard;
@@ -914,6 +914,10 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     b.stepshard.ensure(UG_SHARDS);
     b.bflag.ensure(4);
     double t1 = wall();
+    bool bbest = false;   // set by group_bucketed: pass records were flushed per bucket, k_bkt_best reduces them
+    BktLayout bL;
+    u32 bnb = 0;
+    memset(&bL, 0, sizeof bL);
     auto reset_pass_lists = [&] {
         HIP_CHECK(hipMemsetAsync(b.shard.p, 0, (2 * UG_SHARDS + 8) * sizeof(u32), c->st));
         HIP_CHECK(hipMemsetAsync(b.stepshard.p, 0, UG_SHARDS * sizeof(unsigned long long), c->st));
@@ -991,8 +995,11 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
             return false;
         }
         if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] bucketed pass: wb %d ranges %u buckets %u tiles %u hits %u of %u\n", wb, L.R, nb, NT, Hv, H);
+        // best diagonal per subject bucket by bucket (k_bkt_best) when first-touch keys fit its 44-bit field; else the sorted path below
+        bbest = !(getenv("SOHIT_BUCKET_BEST") && atoi(getenv("SOHIT_BUCKET_BEST")) == 0) && !ft_walk && (kl.ba + kl.bp + ft_bits_entry <= 44);
         launch_ungap(b.keys2.p, Hv, kl, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.shard.p,
                      shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
+        bL = L, bnb = nb;
         return true;
     };
 
@@ -1034,65 +1041,99 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
 
     const bool lk_ablation = getenv("SOHIT_LK_VARIANT") && (atoi(getenv("SOHIT_LK_VARIANT")) == 1 || atoi(getenv("SOHIT_LK_VARIANT")) == 2);
     reset_pass_lists();
-    if (lk_ablation || !group_bucketed()) group_sorted();
+    if (lk_ablation || !group_bucketed()) {
+        bbest = false;
+        group_sorted();
+    }
     if (lk_ablation) return;  // ablation runs time the lookup only: keys are not valid
-    // contiguous pass list; the group counters and the pass total come back in one synchronisation
-    u32* shard_off = b.shard.p + UG_SHARDS;
-    launch_shard_scan(b.shard.p, shard_off, c->st);
-    u32 NP;
-    {
-        static_assert(UG_SHARDS * sizeof(unsigned long long) + sizeof(u32) <= 1024, "h_small too small");
-        unsigned long long* gc = (unsigned long long*)small_host(c);
-        u32* np = (u32*)(gc + UG_SHARDS);
-        HIP_CHECK(hipMemcpyAsync(gc, b.stepshard.p, UG_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
-        HIP_CHECK(hipMemcpyAsync(np, shard_off + UG_SHARDS, sizeof(u32), hipMemcpyDeviceToHost, c->st));
-        HIP_CHECK(hipStreamSynchronize(c->st));
-        for (int k = 0; k < UG_SHARDS; ++k) c->cnt.groups += (i64)gc[k];
-        NP = *np;
+    u64* c_ftp = nullptr;   // candidates of the pass: first-touch key, query, [subject, score, qi, qj]
+    u32 *c_qp = nullptr, *c_recp = nullptr;
+    u32 NS = 0;
+    for (;;) {
+        // contiguous pass list; the group counters and the pass total come back in one synchronisation
+        u32* shard_off = b.shard.p + UG_SHARDS;
+        launch_shard_scan(b.shard.p, shard_off, c->st);
+        u32 NP;
+        {
+            static_assert(UG_SHARDS * sizeof(unsigned long long) + sizeof(u32) <= 1024, "h_small too small");
+            unsigned long long* gc = (unsigned long long*)small_host(c);
+            u32* np = (u32*)(gc + UG_SHARDS);
+            HIP_CHECK(hipMemcpyAsync(gc, b.stepshard.p, UG_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
+            HIP_CHECK(hipMemcpyAsync(np, shard_off + UG_SHARDS, sizeof(u32), hipMemcpyDeviceToHost, c->st));
+            HIP_CHECK(hipStreamSynchronize(c->st));
+            for (int k = 0; k < UG_SHARDS; ++k) c->cnt.groups += (i64)gc[k];
+            NP = *np;
+        }
+        sc.lap("group.ungap");
+        const u64 *q_qs = b.p_qs.p, *q_sd = b.p_sd.p, *q_ft = b.p_ft.p;  // one region: already contiguous
+        if (NP && UG_SHARDS > 1) {
+            b.q_qs.ensure((size_t)NP + 2), b.q_sd.ensure((size_t)NP + 2), b.q_ft.ensure((size_t)NP + 2);
+            launch_compact_shards(b.shard.p, shard_off, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.q_qs.p, b.q_sd.p, b.q_ft.p, c->st);
+            q_qs = b.q_qs.p, q_sd = b.q_sd.p, q_ft = b.q_ft.p;
+        }
+        if (bbest && NP) {
+            // pass records -> the hit buckets, then one LDS reduction per bucket (k_bucket.hip): no sort of the records
+            static_assert(UG_SHARDS == 1, "the bucketed best-diagonal path reads one contiguous pass list");
+            b.bcnt.ensure((size_t)bnb + 2), b.bccnt.ensure((size_t)bnb + 2), b.pidx.ensure((size_t)NP + 2);
+            b.q_qs.ensure((size_t)NP + 2), b.q_sd.ensure((size_t)NP + 2), b.q_ft.ensure((size_t)NP + 2);
+            c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)bnb + 2) + 8);
+            HIP_CHECK(hipMemsetAsync(b.bcnt.p, 0, ((size_t)bnb + 2) * sizeof(u32), c->st));
+            launch_rec_count(b.p_qs.p, NP, kl.bs, bL, b.bcnt.p, b.pidx.p, c->st);
+            scan_u32(b.bcnt.p, b.bcnt.p, (size_t)bnb + 1, false, c->d_scan_tmp.p, c->st);
+            launch_rec_scatter(b.p_qs.p, b.p_sd.p, b.p_ft.p, b.pidx.p, NP, kl, bL, ft_bits_entry, bsp, c->ref.d_off.p + ch.seq_lo, b.bcnt.p, b.q_qs.p,
+                               b.q_sd.p, b.q_ft.p, c->st);
+            HIP_CHECK(hipMemsetAsync(b.bccnt.p + bnb, 0, 2 * sizeof(u32), c->st));
+            launch_bkt_best(false, b.q_qs.p, b.q_sd.p, b.q_ft.p, b.bcnt.p, bnb, bL, kl.bs, (u32)ch.seq_lo, b.bccnt.p, nullptr, nullptr, nullptr, c->st);
+            NS = d2h_u32(c, scan_u32(b.bccnt.p, b.bccnt.p, (size_t)bnb + 1, false, c->d_scan_tmp.p, c->st));
+            if (getenv("SOHIT_DEBUG"))
+                fprintf(stderr, "[sohit] seed pass: queries %u..%u hits %u seeds %u pass records %u candidates %u (bucketed best)\n", qa, qb, H, K, NP, NS);
+            b.c_ft.ensure((size_t)NS + 2), b.c_q.ensure((size_t)NS + 2), b.c_rec.ensure(4 * (size_t)NS + 8);
+            c_ftp = b.c_ft.p, c_qp = b.c_q.p, c_recp = b.c_rec.p;
+            launch_bkt_best(true, b.q_qs.p, b.q_sd.p, b.q_ft.p, b.bcnt.p, bnb, bL, kl.bs, (u32)ch.seq_lo, b.bccnt.p, c_ftp, c_qp, c_recp, c->st);
+            break;
+        }
+        // first-touch keys of the passing groups (k_ungap left the head hit's key / position in the third array)
+        if (NP) launch_first_touch(ft_walk, b.keys2.p, H, kl, ft_bits_entry, bsp, c->ref.d_off.p + ch.seq_lo, const_cast<u64*>(q_ft), NP, c->st);
+        if (NP == 0) break;
+        // best diagonal per (query, subject): sort pass records by (q, subject)
+        b.pidx.ensure((size_t)NP + 2), b.pidx2.ensure((size_t)NP + 2), b.p_qs2.ensure((size_t)NP + 2);
+        launch_iota(b.pidx.p, NP, c->st);
+        ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(NP, 64));
+        sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, q_qs, b.p_qs2.p, b.pidx.p, b.pidx2.p, NP, kl.bs + kl.bq, c->st);
+        b.flags.ensure((size_t)NP + 4), b.gidx.ensure((size_t)NP + 4);
+        launch_seg_flags(b.p_qs2.p, NP, b.flags.p, c->st);
+        const u32* dS = scan_u32(b.flags.p, b.gidx.p, NP, false, c->d_scan_tmp.p, c->st);
+        NS = d2h_u32(c, dS);
+        b.shead.ensure((size_t)NS + 2);
+        if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] seed pass: queries %u..%u hits %u seeds %u pass records %u candidates %u\n", qa, qb, H, K, NP, NS);
+        launch_group_list(b.flags.p, b.gidx.p, NP, b.shead.p, c->st);
+        b.c_ft.ensure((size_t)NS + 2), b.c_q.ensure((size_t)NS + 2), b.c_rec.ensure(4 * (size_t)NS + 8);
+        c_ftp = b.c_ft.p, c_qp = b.c_q.p, c_recp = b.c_rec.p;
+        launch_best(b.p_qs2.p, b.pidx2.p, b.shead.p, NS, NP, q_sd, q_ft, (u32)ch.seq_lo, kl.bs, c_ftp, c_qp, c_recp, c->st);
+        break;
     }
-    sc.lap("group.ungap");
-    const u64 *q_qs = b.p_qs.p, *q_sd = b.p_sd.p, *q_ft = b.p_ft.p;  // one region: already contiguous
-    if (NP && UG_SHARDS > 1) {
-        b.q_qs.ensure((size_t)NP + 2), b.q_sd.ensure((size_t)NP + 2), b.q_ft.ensure((size_t)NP + 2);
-        launch_compact_shards(b.shard.p, shard_off, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.q_qs.p, b.q_sd.p, b.q_ft.p, c->st);
-        q_qs = b.q_qs.p, q_sd = b.q_sd.p, q_ft = b.q_ft.p;
-    }
-    // first-touch keys of the passing groups (k_ungap left the head hit's key / position in the third array)
-    if (NP) launch_first_touch(ft_walk, b.keys2.p, H, kl, ft_bits_entry, bsp, c->ref.d_off.p + ch.seq_lo, const_cast<u64*>(q_ft), NP, c->st);
-    if (NP == 0) {
+    if (NS == 0) {
         c->cnt.seed_ms += (t1 - t0) * 1e3;
         c->cnt.group_ms += (wall() - t1) * 1e3;
         return;
     }
-    // best diagonal per (query, subject): sort pass records by (q, subject)
-    b.pidx.ensure((size_t)NP + 2), b.pidx2.ensure((size_t)NP + 2), b.p_qs2.ensure((size_t)NP + 2);
-    launch_iota(b.pidx.p, NP, c->st);
-    ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(NP, 64));
-    sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, q_qs, b.p_qs2.p, b.pidx.p, b.pidx2.p, NP, kl.bs + kl.bq, c->st);
-    b.flags.ensure((size_t)NP + 4), b.gidx.ensure((size_t)NP + 4);
-    launch_seg_flags(b.p_qs2.p, NP, b.flags.p, c->st);
-    const u32* dS = scan_u32(b.flags.p, b.gidx.p, NP, false, c->d_scan_tmp.p, c->st);
-    const u32 NS = d2h_u32(c, dS);
-    b.shead.ensure((size_t)NS + 2);
-    if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] seed pass: queries %u..%u hits %u seeds %u pass records %u candidates %u\n", qa, qb, H, K, NP, NS);
-    launch_group_list(b.flags.p, b.gidx.p, NP, b.shead.p, c->st);
-    b.c_ft.ensure((size_t)NS + 2), b.c_ft2.ensure((size_t)NS + 2), b.c_q.ensure((size_t)NS + 2), b.c_rec.ensure(4 * (size_t)NS + 8);
-    launch_best(b.p_qs2.p, b.pidx2.p, b.shead.p, NS, NP, q_sd, q_ft, (u32)ch.seq_lo, kl.bs, b.c_ft.p, b.c_q.p, b.c_rec.p, c->st);
     // order candidates by (query, first-touch): one sort on (q << ftbits | ft) when that fits 64 bits,
     // else sort by first-touch and then stable-sort by query; only the populated bits are sorted
     const int ftbits = kl.ba + kl.bp + ft_bits_entry;
-    b.order.ensure((size_t)NS + 2), b.order2.ensure((size_t)NS + 2), b.tmp64.ensure((size_t)NS + 2);
+    b.order.ensure((size_t)NS + 2), b.order2.ensure((size_t)NS + 2), b.tmp64.ensure((size_t)NS + 2), b.c_ft2.ensure((size_t)NS + 2);
     launch_iota(b.order.p, NS, c->st);
     int qshift = 0;  // where the query sits in the final sort's key stream (b.c_ft2)
     if (ftbits + kl.bq <= 64) {
-        launch_combine_q_ft(b.c_q.p, b.c_ft.p, NS, ftbits, bsp, b.tmp64.p, c->st);
+        ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(NS, 64));
+        launch_combine_q_ft(c_qp, c_ftp, NS, ftbits, bsp, b.tmp64.p, c->st);
         sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, b.order.p, b.order2.p, NS, ftbits - bsp + 1 + kl.bq, c->st);
         std::swap(b.order.p, b.order2.p);
         std::swap(b.order.cap, b.order2.cap);
         qshift = ftbits - bsp + 1;
     } else {
-        sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.c_ft.p, b.c_ft2.p, b.order.p, b.order2.p, NS, ftbits, c->st);
-        launch_gather_u32_as_u64(b.c_q.p, b.order2.p, NS, b.tmp64.p, c->st);
+        ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(NS, 64));
+        sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, c_ftp, b.c_ft2.p, b.order.p, b.order2.p, NS, ftbits, c->st);
+        launch_gather_u32_as_u64(c_qp, b.order2.p, NS, b.tmp64.p, c->st);
         sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, b.order2.p, b.order.p, NS, kl.bq, c->st);
     }
     // append to the candidate store
@@ -1101,7 +1142,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
     b.cand_rec.ensure(4 * ((size_t)base + NS) + 16, true, c->st);
     b.segfirst.ensure((size_t)b.nq + 4);
-    launch_emit_cands(b.order.p, NS, b.c_ft2.p, qshift, b.c_rec.p, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, b.segfirst.p, c->st);
+    launch_emit_cands(b.order.p, NS, b.c_ft2.p, qshift, c_recp, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, b.segfirst.p, c->st);
     b.chunk_base.back() = base + NS;
     c->cnt.candidates += NS;
     HIP_CHECK(hipStreamSynchronize(c->st));

@@ -386,6 +386,136 @@ __global__ __launch_bounds__(BG_THREADS, 4) void k_bkt_group(const u32* __restri
     }
 }
 
+// ================================================================================================================
+// best diagonal per (query, subject), bucket by bucket (fsearch.py:2709-2719)
+// ================================================================================================================
+// The pass records k_ungap appended (a few per cent of the hits) are binned into the SAME (query, subject range) buckets -- count,
+// scan, scatter; the returning count atomic doubles as the record's rank inside its bucket, so the scatter needs none -- and the
+// first-touch key of every record is computed on the way (what k_first_touch does on the sorted path).  A bucket holds ONE query
+// and <= BG_BINS subjects, so "first group attaining the maximum per subject" is a reduction over an LDS table indexed by the
+// subject inside the range: a 64-bit max over (score, inverted first-touch key) picks the best group -- ties go to the group visited
+// first, the reference's strict `>` -- and a 64-bit min keeps the subject's earliest first-touch key (its place in the candidate
+// order).  The reduction runs twice: once to count the candidates per bucket, and after a scan of the counts once more to write them
+// densely (one global counter for all buckets serialises ~1e5 same-address atomics: 1.2 ms on config 2 against 0.1 ms for the
+// second reduction).  This replaces the radix sort of all pass records by (query, subject) + segment flags + scan + k_best.
+__device__ __forceinline__ u32 rec_bucket(u64 qs, int bs, const BktLayout& L) {
+    return (((u32)qs & ((1u << bs) - 1u)) >> L.wb) * L.nqp + ((u32)(qs >> bs) - L.qa);
+}
+
+__global__ __launch_bounds__(256) void k_rec_count(const u64* __restrict__ p_qs, u32 n, int bs, BktLayout L, u32* __restrict__ bcnt,
+                                                   u32* __restrict__ rnk) {
+    // neighbouring records come from one wave of k_ungap, i.e. from one or two buckets: one atomic per distinct bucket of the wave
+    // (a returning atomic per record serialises on those few addresses: 1.4 ms instead of 0.1 ms on config 2)
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool have = i < n;
+    const u32 bk = have ? rec_bucket(p_qs[i], bs, L) : 0xFFFFFFFFu;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned long long todo = __ballot(have);
+    u32 r = 0;
+    while (todo) {
+        const int leader = (int)__builtin_ctzll(todo);
+        const u32 b0 = __shfl(bk, leader);
+        const unsigned long long m = __ballot(have && bk == b0);
+        u32 base = 0;
+        if (lane == leader) base = atomicAdd(&bcnt[b0], (u32)__popcll(m));
+        base = __shfl(base, leader);
+        if (have && bk == b0) r = base + (u32)__popcll(m & lt);
+        todo &= ~m;
+    }
+    if (have) rnk[i] = r;
+}
+
+__global__ __launch_bounds__(256) void k_rec_scatter(const u64* __restrict__ p_qs, const u64* __restrict__ p_sd, const u64* __restrict__ p_ft,
+                                                     const u32* __restrict__ rnk, u32 n, KeyLayout kl, BktLayout L, int ft_bits_entry, int bsp,
+                                                     const u32* __restrict__ roff, const u32* __restrict__ boff, u64* __restrict__ q_qs,
+                                                     u64* __restrict__ q_sd, u64* __restrict__ q_ft) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const u64 qs = p_qs[i];
+    const u32 o = boff[rec_bucket(qs, kl.bs, L)] + rnk[i];
+    q_qs[o] = qs, q_sd[o] = p_sd[i], q_ft[o] = ft_key_of_head(p_ft[i], kl, ft_bits_entry, bsp, roff);
+}
+
+#define BB_THREADS 256
+template <bool WRITE>
+__global__ __launch_bounds__(BB_THREADS) void k_bkt_best(const u64* __restrict__ q_qs, const u64* __restrict__ q_sd, const u64* __restrict__ q_ft,
+                                                        const u32* __restrict__ boff /*nb + 1*/, u32 nb, BktLayout L, int bs, u32 seq_lo,
+                                                        u32* __restrict__ ccnt /*!WRITE: out; WRITE: scanned, in*/, u64* __restrict__ c_ft,
+                                                        u32* __restrict__ c_q, u32* __restrict__ c_rec) {
+    __shared__ unsigned long long s_best[BG_BINS], s_min[BG_BINS];
+    __shared__ u32 s_pref[BG_BINS];
+    __shared__ u32 s_wsum[BB_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const u32 W = 1u << L.wb;
+    const u64 FTM = (1ull << 44) - 1ull;  // first-touch keys fit 44 bits (host check), scores 20
+    constexpr int SPT = BG_BINS / BB_THREADS;
+    for (u32 b = blockIdx.x; b < nb; b += gridDim.x) {
+        const u32 b0 = boff[b], n = boff[b + 1] - b0;
+        if (n == 0) {
+            if (!WRITE && tid == 0) ccnt[b] = 0;
+            continue;
+        }
+        __syncthreads();
+        for (u32 i = (u32)tid; i < W; i += BB_THREADS) s_best[i] = 0ull, s_min[i] = ~0ull;
+        __syncthreads();
+        for (u32 i = (u32)tid; i < n; i += BB_THREADS) {
+            const u32 s = (u32)q_qs[b0 + i] & (W - 1u);
+            const u64 ft = q_ft[b0 + i];
+            atomicMax(&s_best[s], ((q_sd[b0 + i] >> 32) << 44) | (FTM - ft));
+            if (WRITE) atomicMin(&s_min[s], (unsigned long long)ft);
+        }
+        __syncthreads();
+        // subjects with a candidate -> dense positions (subject order inside the bucket)
+        u32 c[SPT], tot = 0;
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) {
+            const u32 i = (u32)tid * SPT + (u32)k;
+            c[k] = (i < W && s_best[i] != 0ull) ? 1u : 0u;
+            tot += c[k];
+        }
+        u32 inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 x = __shfl_up(inc, o);
+            if (lane >= o) inc += x;
+        }
+        if (lane == 63) s_wsum[w] = inc;
+        __syncthreads();
+        u32 run = inc - tot, total = 0;
+        for (int k = 0; k < BB_THREADS / 64; ++k) {
+            if (k < w) run += s_wsum[k];
+            total += s_wsum[k];
+        }
+        if (!WRITE) {
+            if (tid == 0) ccnt[b] = total;
+            continue;
+        }
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) {
+            const u32 i = (u32)tid * SPT + (u32)k;
+            if (i < W) s_pref[i] = run;
+            run += c[k];
+        }
+        __syncthreads();
+        const u32 base = ccnt[b];
+        const u32 gq = L.qa + (b - (b / L.nqp) * L.nqp);
+        for (u32 i = (u32)tid; i < n; i += BB_THREADS) {
+            const u64 qs = q_qs[b0 + i], sd = q_sd[b0 + i], ft = q_ft[b0 + i];
+            const u32 s = (u32)qs & (W - 1u);
+            if ((((sd >> 32) << 44) | (FTM - ft)) != s_best[s]) continue;  // not the subject's best group
+            const u32 o = base + s_pref[s];
+            const int bdist = (int)(u32)sd;
+            u32 qi, qj;
+            if (bdist > 0) qi = 0, qj = (u32)bdist;
+            else qi = (u32)(-bdist), qj = 0;
+            c_ft[o] = s_min[s];
+            c_q[o] = gq;
+            *reinterpret_cast<uint4*>(c_rec + 4 * (size_t)o) = make_uint4(((u32)qs & ((1u << bs) - 1u)) + seq_lo, (u32)(sd >> 32), qi, qj);
+        }
+    }
+}
+
 // ---- launch wrappers -------------------------------------------------------------------------------
 u32 bkt_tile_hits() { return BK_HITS; }
 
@@ -422,4 +552,24 @@ void launch_bkt_group(const u32* hits, const u32* bext, u32 nb, const BktLayout&
     // persistent workgroups striding over the buckets, range-major: the chip writes one subject range at a time
     const u32 grid = std::min<u32>(nb, 256u * 4u);
     hipLaunchKernelGGL(k_bkt_group, dim3(grid), dim3(BG_THREADS), 0, st, hits, bext, nb, L, kl, keys, fallback);
+}
+
+void launch_rec_count(const u64* p_qs, u32 n, int bs, const BktLayout& L, u32* bcnt, u32* rnk, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_rec_count, dim3((n + 255) / 256), dim3(256), 0, st, p_qs, n, bs, L, bcnt, rnk);
+}
+
+void launch_rec_scatter(const u64* p_qs, const u64* p_sd, const u64* p_ft, const u32* rnk, u32 n, const KeyLayout& kl, const BktLayout& L,
+                        int ft_bits_entry, int bsp, const u32* roff, const u32* boff, u64* q_qs, u64* q_sd, u64* q_ft, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_rec_scatter, dim3((n + 255) / 256), dim3(256), 0, st, p_qs, p_sd, p_ft, rnk, n, kl, L, ft_bits_entry, bsp, roff, boff,
+                       q_qs, q_sd, q_ft);
+}
+
+void launch_bkt_best(bool write, const u64* q_qs, const u64* q_sd, const u64* q_ft, const u32* boff, u32 nb, const BktLayout& L, int bs,
+                     u32 seq_lo, u32* ccnt, u64* c_ft, u32* c_q, u32* c_rec, hipStream_t st) {
+    if (!nb) return;
+    const u32 grid = std::min<u32>(nb, 256u * 8u);
+    if (write) hipLaunchKernelGGL(k_bkt_best<true>, dim3(grid), dim3(BB_THREADS), 0, st, q_qs, q_sd, q_ft, boff, nb, L, bs, seq_lo, ccnt, c_ft, c_q, c_rec);
+    else hipLaunchKernelGGL(k_bkt_best<false>, dim3(grid), dim3(BB_THREADS), 0, st, q_qs, q_sd, q_ft, boff, nb, L, bs, seq_lo, ccnt, c_ft, c_q, c_rec);
 }

@@ -127,3 +127,10 @@ int bkt_max_wb();
 void launch_bkt_extents(const u32* mat, const u32* t0, u32 NT, u32 nqp, u32 nb, u32* bext /*nb + 1*/, hipStream_t st);
 void launch_bkt_group(const u32* hits, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, u64* keys, u32* fallback,
                       hipStream_t st);
+// best diagonal per (query, subject), bucket by bucket: pass records binned into the hit buckets (count -> scan -> scatter, first-touch
+// keys computed on the way), then one LDS reduction per bucket, run once to count the candidates and once to write them
+void launch_rec_count(const u64* p_qs, u32 n, int bs, const BktLayout& L, u32* bcnt, u32* rnk, hipStream_t st);
+void launch_rec_scatter(const u64* p_qs, const u64* p_sd, const u64* p_ft, const u32* rnk, u32 n, const KeyLayout& kl, const BktLayout& L,
+                        int ft_bits_entry, int bsp, const u32* roff, const u32* boff, u64* q_qs, u64* q_sd, u64* q_ft, hipStream_t st);
+void launch_bkt_best(bool write, const u64* q_qs, const u64* q_sd, const u64* q_ft, const u32* boff, u32 nb, const BktLayout& L, int bs,
+                     u32 seq_lo, u32* ccnt, u64* c_ft, u32* c_q, u32* c_rec, hipStream_t st);

@@ -330,6 +330,10 @@ def test_bucketed_binning_forced_vs_oracle(fs, oracle, tmp_path, monkeypatch, na
     s.search().close()
     assert "group.bucket_group" in s.timing() and "group.sort_keys" not in s.timing()
     s.close()
+    # the per-bucket best-diagonal reduction (k_rec_count / k_rec_scatter / k_bkt_best) off: bucketed keys, sorted pass records
+    monkeypatch.setenv("SOHIT_BUCKET_BEST", "0")
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+    monkeypatch.delenv("SOHIT_BUCKET_BEST")
     monkeypatch.setenv("SOHIT_BUCKET", "0")   # and the sorted path is still there
     s = fs.Searcher(profile=True, **kw)
     s.load_ref_bytes(fa)
