@@ -1296,8 +1296,8 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             launch_round_idx(b.tcnt.p, b.roff.p, b.toff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.st_state.p, nq, b.ridx.p, c->st);
             // score-only: the stop rule needs the maximum alone; the reported rows are traced in a second pass below
             ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
-            launch_align(b.tasks.p, b.ridx.p, NR, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p, c->ref.d_off.p,
-                         c->d_b62c.p, nullptr, stride, b.ares.p, false, c->st);
+            launch_align(b.tasks.p, b.ridx.p, NR, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
+                         c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, b.ares.p, false, c->st);
             pt.stop();
         }
         launch_stop_round(b.tasks.p, b.ares.p, b.qcoff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.toff.p, b.rcnt.p, nq,
@@ -1323,8 +1323,8 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
             for (u32 t = 0; t < NO; t += slab) {
                 const u32 n = std::min(slab, NO - t);
-                launch_align(b.tasks.p, b.sel_idx.p + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
-                             c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, b.ares.p, true, c->st);
+                launch_align(b.tasks.p, b.sel_idx.p + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p,
+                             c->ref.d_scls.p, c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, b.ares.p, true, c->st);
             }
             pt.stop();
         }

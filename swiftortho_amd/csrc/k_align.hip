@@ -20,9 +20,14 @@
 
 #define KB 16  // kbound
 
-// neighbour lane's value inside the 16-lane DPP row; lanes without a source keep `oob`
-__device__ __forceinline__ int dpp_row_shr1(int oob, int v) { return __builtin_amdgcn_update_dpp(oob, v, 0x111, 0xF, 0xF, false); }
-__device__ __forceinline__ int dpp_row_shl1(int oob, int v) { return __builtin_amdgcn_update_dpp(oob, v, 0x101, 0xF, 0xF, false); }
+// DP values are kept BIASED by +11 (= -GO): a score b is held as b + 11 and a gap input (score + gap cost) as that + 11, so the
+// value every out-of-band / boundary neighbour contributes -- score 0 stepping out with an opened gap, 0 - 11 -- is the integer 0,
+// which is what a DPP move with bound_ctrl writes into the lane that has no source: no `old` operand to initialise per cell.
+// Equalities between the candidates of a cell (the trace priority) and the order of scores are unchanged by the bias.
+#define BIAS 11
+// neighbour lane's value inside the 16-lane DPP row; lanes without a source get 0 (the biased -11)
+__device__ __forceinline__ int dpp_row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_row_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true); }
 
 __device__ __forceinline__ u32 load4u(const u8* p) {  // unaligned 4-byte global load
     u32 w;
@@ -30,12 +35,12 @@ __device__ __forceinline__ u32 load4u(const u8* p) {  // unaligned 4-byte global
     return w;
 }
 
-// class bytes [idx, idx + 4) of a sequence; idx runs from -8 (band cells left of / above the matrix) to len + 30 (below /
-// right of it).  Bytes outside [0, len) are don't-care -- they only ever feed invalid cells, and any byte & 31 indexes
-// inside the score table -- so the load is unconditional: the class arrays carry 16 readable bytes in front and 64 behind,
-// and inside the array the neighbours are other sequences' residues.  (The bounds-checked version of this helper was 126 of
-// the 274 instructions of a four-row step.)
-__device__ __forceinline__ u32 win4(const u8* __restrict__ base, int idx, int /*len*/) { return load4u(base + idx); }
+// class bytes [idx, idx + 4) of a sequence; idx runs from -8 (band cells left of / above the matrix) to len + 37 (below /
+// right of it, one window prefetched).  Bytes outside [0, len) are don't-care -- they only ever feed invalid cells, and every
+// byte of a class array, pads included, is a class < SCLS_N (or 4 x one) and indexes inside the score table -- so the load is
+// unconditional: the class arrays carry 16 readable bytes in front and 64 behind, and inside the array the neighbours are other
+// sequences' residues.  (The bounds-checked version of this helper was 126 of the 274 instructions of a four-row step.)
+__device__ __forceinline__ u32 win4(const u8* __restrict__ base, int idx) { return load4u(base + idx); }
 
 #define GO (-11)
 #define GE (-1)
@@ -48,9 +53,9 @@ __device__ __forceinline__ u32 win4(const u8* __restrict__ base, int idx, int /*
 typedef unsigned long long m64;
 #define ICMP_EQ 32
 #define ICMP_ULT 36
-__device__ __forceinline__ int sel0(int x, m64 m) {  // m ? x : 0
+__device__ __forceinline__ int sel_bias(int x, m64 m) {  // m ? x : BIAS (the biased score 0)
     int r;
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
+    asm("v_cndmask_b32_e64 %0, 11, %1, %2" : "=v"(r) : "v"(x), "s"(m));
     return r;
 }
 __device__ __forceinline__ int gapcost(m64 ext) {  // ext ? GE (-1) : GO (-11)
@@ -64,14 +69,8 @@ __device__ __forceinline__ u32 shl1_in(u32 x, m64 bit) {  // 2 * x + bit
     asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(cout) : "v"(x), "s"(bit));
     return r;
 }
-__device__ __forceinline__ int inc_if(int x, m64 bit) {  // x + bit
-    int r;
-    m64 cout;
-    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(cout) : "v"(x), "s"(bit));
-    return r;
-}
 
-// One band cell.  I / D arrive ready-made from the producing cells (their score plus the gap cost
+// One band cell, all values biased (see BIAS).  I / D arrive ready-made from the producing cells (their score plus the gap cost
 // that applies when stepping out of them: extend iff their own trace is that gap direction, else
 // open); Bd = diagonal neighbour's score.  Publishes B, Iout (for the cell to the right),
 // Dout (for the cell below) and the two bits of the trace code  0 '*', 1 '\\', 2 '-', 3 '|'
@@ -80,12 +79,12 @@ __device__ __forceinline__ int inc_if(int x, m64 bit) {  // x + bit
 template <bool EDGE>
 __device__ __forceinline__ void dp_cell(m64 valid, int I, int D, int Bd, int s, int& B, int& Iout, int& Dout, m64& t0, m64& t1) {
     const int M = Bd + s;
-    const int b0 = max(max(I, D), max(M, 0));
+    const int b0 = max(max(I, D), max(M, BIAS));
     m64 isM = __builtin_amdgcn_sicmp(b0, M, ICMP_EQ), eI = __builtin_amdgcn_sicmp(b0, I, ICMP_EQ), eD = __builtin_amdgcn_sicmp(b0, D, ICMP_EQ);
     if (EDGE) isM &= valid, eI &= valid, eD &= valid;
     eI &= ~isM;
     eD &= ~(isM | eI);
-    const int b = EDGE ? sel0(b0, valid) : b0;
+    const int b = EDGE ? sel_bias(b0, valid) : b0;
     B = b;
     t0 = isM | eD;
     t1 = eI | eD;
@@ -93,20 +92,23 @@ __device__ __forceinline__ void dp_cell(m64 valid, int I, int D, int Bd, int s, 
     Dout = b + gapcost(eD);
 }
 
+// LDS score table addressed by ONE v_perm per cell: byte offset (row class << 8) | (column class * 4), the column classes read
+// from the pre-scaled copy of the class array (k_scls).  Row stride 256 B; the * 4 spreads the 24 column classes over 24 banks.
+#define AL_TAB (SCLS_N * 256)
+
 // trace codes: 0 '*' (stop), 1 '\\' (diag), 2 '-' (left), 3 '|' (up)
 // TRACE = false: score-only run (maximum and its cell): the early-stop rule (k_stop_round) needs nothing else, and only the
 // few alignments that end up reported are run again with TRACE = true for the traceback.
 template <bool TRACE>
 __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 ntasks,
-                                               const u8* __restrict__ q_res, const u8* __restrict__ q_scls,
-                                               const u32* __restrict__ qoff, const u8* __restrict__ r_res,
-                                               const u8* __restrict__ r_scls, const u32* __restrict__ roff,
+                                               const u8* __restrict__ q_scls, const u8* __restrict__ q_scls4, const u32* __restrict__ qoff,
+                                               const u8* __restrict__ r_scls, const u8* __restrict__ r_scls4, const u32* __restrict__ roff,
                                                const signed char* __restrict__ b62g, u32* __restrict__ trace, u32 trace_stride,
                                                AlnRes* __restrict__ out) {
-    __shared__ signed char s_b62[32 * 36];  // rows of 36 bytes: any two 5-bit classes index inside; rows rotate over the banks
-    for (int i = threadIdx.x; i < 32 * 36; i += 256) {
-        const int a = i / 36, b = i % 36;
-        s_b62[i] = (a < SCLS_N && b < SCLS_N) ? b62g[a * SCLS_N + b] : (signed char)-4;
+    __shared__ signed char s_b62[AL_TAB];
+    for (int i = threadIdx.x; i < SCLS_N * 64; i += 256) {
+        const int a = i >> 6, b = i & 63;
+        s_b62[a * 256 + b * 4] = b < SCLS_N ? b62g[a * SCLS_N + b] : (signed char)-4;
     }
     __syncthreads();
     const u32 tid = blockIdx.x * 16u + (threadIdx.x >> 4);
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     const int la = lq - qi, lb = ls - qj;
     const bool swp = !(la < lb);  // abs(qed - qst) < abs(sed - sst) -> no swap (1364-1369)
     const int ncols = swp ? lb : la, nrows = swp ? la : lb;
-    const u8* ccls = swp ? (r_scls + sb + qj) : (q_scls + qb + qi);
+    const u8* ccls = swp ? (r_scls4 + sb + qj) : (q_scls4 + qb + qi);  // column classes * 4
     const u8* rcls = swp ? (q_scls + qb + qi) : (r_scls + sb + qj);
     const int R = min(nrows, ncols + KB);  // rows beyond ncols + 16 have an empty band
     u32* tr = trace + (size_t)tid * trace_stride;
@@ -130,13 +132,17 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     // even: left = lane l-1's odd cell of iteration m-1, up = own odd cell of m-1, diag = own even cell of m-1
     // odd : left = own even cell of m,               up = lane l+1's even cell of m, diag = own odd cell of m-1
     // Per iteration a lane consumes one new row class (row i) and one new column class (column j0 + 1;
-    // column j0's class is last iteration's).  Both stream through 4-byte register windows that are
-    // refilled every 4th iteration on a wave-uniform schedule.
-    int Be = 0, Bo = 0, Io_out = GO, Do_out = GO;  // results of iteration m-1
-    u32 keyE = 0, keyO = 0;                        // best even / odd cell: score << 13 | (8191 - i)
-    int ncell = 0;
+    // column j0's class is last iteration's).  Both stream through 4-byte register windows, fetched one
+    // four-iteration group ahead.
+    // A cell (i, d) exists for i in [max(1, 17 - d), min(R, ncols + 16 - d)]: in iteration terms m - l in that range, one
+    // unsigned compare per cell against per-lane constants (first iteration, count).
+    const int lo_e = max(1, 17 - 2 * l), lo_o = max(1, 16 - 2 * l);
+    const int cnt_e = max(0, min(R, ncols + 16 - 2 * l) - lo_e + 1), cnt_o = max(0, min(R, ncols + 15 - 2 * l) - lo_o + 1);
+    const int m_e = l + lo_e, m_o = l + lo_o;  // first iteration with a valid even / odd cell
+    int Be = BIAS, Bo = BIAS, Io_out = 0, Do_out = 0;  // results of iteration m-1 (biased)
+    u32 keyE = TRACE ? ((u32)BIAS << 13) : (u32)BIAS, keyO = keyE;  // best even / odd cell: score << 13 | (8191 - i)
     u32 tw = 0;
-    u32 cc0 = 0;
+    u32 cwp = 0;  // the previous group's column window (its last byte = column j0 of the group's first iteration)
     const int m_end = R + 15;
     // four iterations; EDGE = false when every cell of every active lane is inside its band and matrix
     auto four = [&](int m0, u32 rw, u32 cw, auto edge) {
@@ -145,24 +151,21 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
         for (int k = 0; k < 4; ++k) {
             const int m = m0 + k;
             const int i = m - l;
-            const int j0 = m + l - KB;
-            const u32 rc = rw & 31u, cc1 = cw & 31u;
-            rw >>= 8;
-            cw >>= 8;
-            m64 row_ok = ~0ull, ve = ~0ull, vo = ~0ull;
+            m64 ve = ~0ull, vo = ~0ull;
             if (EDGE) {
-                row_ok = __builtin_amdgcn_uicmp((u32)(i - 1), (u32)R, ICMP_ULT);
-                ve = row_ok & __builtin_amdgcn_uicmp((u32)(j0 - 1), (u32)ncols, ICMP_ULT);
-                vo = row_ok & __builtin_amdgcn_uicmp((u32)j0, (u32)ncols, ICMP_ULT);
+                ve = __builtin_amdgcn_uicmp((u32)(m - m_e), (u32)cnt_e, ICMP_ULT);
+                vo = __builtin_amdgcn_uicmp((u32)(m - m_o), (u32)cnt_o, ICMP_ULT);
             }
-            const int s0 = s_b62[rc * 36u + cc0], s1 = s_b62[rc * 36u + cc1];
-            cc0 = cc1;
+            // (row class << 8) | column class * 4: bytes 1 and 0 picked by one v_perm (selector bytes 0-3: second source)
+            const u32 a0 = k == 0 ? __builtin_amdgcn_perm(rw, cwp, 0x0C0C0403u)
+                                  : __builtin_amdgcn_perm(rw, cw, 0x0C0C0000u | ((u32)(4 + k) << 8) | (u32)(k - 1));
+            const u32 a1 = __builtin_amdgcn_perm(rw, cw, 0x0C0C0000u | ((u32)(4 + k) << 8) | (u32)k);
+            const int s0 = s_b62[a0], s1 = s_b62[a1];
             int nBe, Ie_out, De_out, nBo, nIo, nDo;
             m64 te0, te1, to0, to1;
-            dp_cell<EDGE>(ve, dpp_row_shr1(GO, Io_out), Do_out, Be, s0, nBe, Ie_out, De_out, te0, te1);
-            dp_cell<EDGE>(vo, Ie_out, dpp_row_shl1(GO, De_out), Bo, s1, nBo, nIo, nDo, to0, to1);
+            dp_cell<EDGE>(ve, dpp_row_shr1(Io_out), Do_out, Be, s0, nBe, Ie_out, De_out, te0, te1);
+            dp_cell<EDGE>(vo, Ie_out, dpp_row_shl1(De_out), Bo, s1, nBo, nIo, nDo, to0, to1);
             Be = nBe, Bo = nBo, Io_out = nIo, Do_out = nDo;
-            if (EDGE) ncell = inc_if(inc_if(ncell, ve), vo);
             // first strict maximum in row-major order == largest (score, 8191 - i) key; keys of invalid cells are < any valid one
             if (TRACE) {
                 const u32 rk = (u32)(8191 - i) & 8191u;
@@ -181,19 +184,20 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
                 }
             }
         }
-        if (!EDGE) ncell += 8;
+        cwp = cw;
     };
     const int int_hi = min(R, ncols) - 3;  // groups m0 in [17, int_hi] are interior for this alignment (all 16 lanes, all 4 steps)
+    u32 rw = win4(rcls, 8 - l - 1), cw = win4(ccls, 8 + l - KB);
     for (int m0 = 8; m0 <= m_end; m0 += 4) {
-        const u32 rw = win4(rcls, m0 - l - 1, nrows);
-        const u32 cw = win4(ccls, m0 + l - KB, ncols);
+        const u32 nrw = win4(rcls, m0 + 4 - l - 1), ncw = win4(ccls, m0 + 4 + l - KB);  // the next group's windows
         if (__all(m0 >= 17 && m0 <= int_hi)) four(m0, rw, cw, std::false_type{});
         else four(m0, rw, cw, std::true_type{});
+        rw = nrw, cw = ncw;
     }
     // lane best: max score, then smallest i, then the even cell (smaller j)
     int best, bi, bj;
     {
-        const int sE = TRACE ? (int)(keyE >> 13) : (int)keyE, sO = TRACE ? (int)(keyO >> 13) : 0;
+        const int sE = (TRACE ? (int)(keyE >> 13) : (int)keyE) - BIAS, sO = TRACE ? (int)(keyO >> 13) - BIAS : 0;
         const int iE = 8191 - (int)(keyE & 8191u), iO = 8191 - (int)(keyO & 8191u);
         const bool takeO = (sO > sE) || (sO == sE && iO < iE);
         best = takeO ? sO : sE;
@@ -201,7 +205,9 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
         bj = bi + 2 * l - KB + (takeO ? 1 : 0);
         if (best == 0) bi = 0, bj = 0;  // nothing scored: (i_max, j_max) stay (0, 0) (1391)
     }
-    // reduce (best, bi, bj) over the 16 lanes: max score, then smallest i, then smallest j
+    // reduce (best, bi, bj) over the 16 lanes: max score, then smallest i, then smallest j; the cells evaluated (a counter the
+    // oracle keeps too) are the lane's two band offsets' row ranges
+    int ncell = cnt_e + cnt_o;
     for (int msk = 8; msk > 0; msk >>= 1) {
         const int ob = __shfl_xor(best, msk, 16), oi = __shfl_xor(bi, msk, 16), oj = __shfl_xor(bj, msk, 16);
         const int oc = __shfl_xor(ncell, msk, 16);
@@ -300,16 +306,16 @@ u32 align_trace_stride(int max_cols_plus) {
 }
 
 // with_traceback = false: scores only (trace may be null); true: traces + traceback statistics
-void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u32* qoff, const u8* r_res,
-                  const u8* r_scls, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, AlnRes* out,
-                  bool with_traceback, hipStream_t st) {
+void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u8* q_scls4, const u32* qoff,
+                  const u8* r_res, const u8* r_scls, const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride,
+                  AlnRes* out, bool with_traceback, hipStream_t st) {
     if (!ntasks) return;
     if (!with_traceback) {
-        hipLaunchKernelGGL((k_align<false>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_res, q_scls, qoff, r_res, r_scls,
+        hipLaunchKernelGGL((k_align<false>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4,
                            roff, b62g, trace, trace_stride, out);
         return;
     }
-    hipLaunchKernelGGL((k_align<true>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_res, q_scls, qoff, r_res, r_scls, roff,
+    hipLaunchKernelGGL((k_align<true>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff,
                        b62g, trace, trace_stride, out);
     hipLaunchKernelGGL(k_traceback, dim3((ntasks + 63) / 64), dim3(64), 0, st, tasks, ridx, ntasks, q_res, qoff, r_res, roff, trace,
                        trace_stride, out);

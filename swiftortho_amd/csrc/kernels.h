@@ -86,9 +86,9 @@ void launch_emit_cands(const u32* order, u32 n, const u64* sorted_key /*the fina
 
 // k_align.hip
 u32 align_trace_stride(int max_rows);
-void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u32* qoff, const u8* r_res,
-                  const u8* r_scls, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, AlnRes* out, bool with_traceback,
-                  hipStream_t st);
+void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u8* q_scls4, const u32* qoff,
+                  const u8* r_res, const u8* r_scls, const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride,
+                  AlnRes* out, bool with_traceback, hipStream_t st);
 
 // k_phase2.hip
 void launch_gather_cands(const u32* src_q, const u32* src_rec, u32 n, const u32* cqoff, const u32* prior, const u32* qcoff,
