@@ -34,9 +34,14 @@ __device__ __forceinline__ u32 load4u(const u8* p) {  // unaligned 4-byte global
     __builtin_memcpy(&w, p, 4);
     return w;
 }
+__device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global load
+    u64 w;
+    __builtin_memcpy(&w, p, 8);
+    return w;
+}
 
-// class bytes [idx, idx + 4) of a sequence; idx runs from -8 (band cells left of / above the matrix) to len + 37 (below /
-// right of it, one window prefetched).  Bytes outside [0, len) are don't-care -- they only ever feed invalid cells, and every
+// class bytes [idx, idx + 4) of a sequence; idx runs from -9 (band cells left of / above the matrix) to len + 37 (below /
+// right of it).  Bytes outside [0, len) are don't-care -- they only ever feed invalid cells, and every
 // byte of a class array, pads included, is a class < SCLS_N (or 4 x one) and indexes inside the score table -- so the load is
 // unconditional: the class arrays carry 16 readable bytes in front and 64 behind, and inside the array the neighbours are other
 // sequences' residues.  (The bounds-checked version of this helper was 126 of the 274 instructions of a four-row step.)
@@ -132,8 +137,8 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     // even: left = lane l-1's odd cell of iteration m-1, up = own odd cell of m-1, diag = own even cell of m-1
     // odd : left = own even cell of m,               up = lane l+1's even cell of m, diag = own odd cell of m-1
     // Per iteration a lane consumes one new row class (row i) and one new column class (column j0 + 1;
-    // column j0's class is last iteration's).  Both stream through 4-byte register windows, fetched one
-    // four-iteration group ahead.
+    // column j0's class is last iteration's).  Both stream through register windows loaded once per
+    // four-iteration group (4 row bytes, 8 column bytes starting one column early).
     // A cell (i, d) exists for i in [max(1, 17 - d), min(R, ncols + 16 - d)]: in iteration terms m - l in that range, one
     // unsigned compare per cell against per-lane constants (first iteration, count).
     const int lo_e = max(1, 17 - 2 * l), lo_o = max(1, 16 - 2 * l);
@@ -142,10 +147,11 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     int Be = BIAS, Bo = BIAS, Io_out = 0, Do_out = 0;  // results of iteration m-1 (biased)
     u32 keyE = TRACE ? ((u32)BIAS << 13) : (u32)BIAS, keyO = keyE;  // best even / odd cell: score << 13 | (8191 - i)
     u32 tw = 0;
-    u32 cwp = 0;  // the previous group's column window (its last byte = column j0 of the group's first iteration)
     const int m_end = R + 15;
-    // four iterations; EDGE = false when every cell of every active lane is inside its band and matrix
-    auto four = [&](int m0, u32 rw, u32 cw, auto edge) {
+    // four iterations; EDGE = false when every cell of every active lane is inside its band and matrix.
+    // rw = the row classes of the four iterations; cw0 / cw1 = column classes * 4 starting ONE column early (five are used:
+    // iteration k's even cell sits in column byte k, its odd cell in byte k + 1)
+    auto four = [&](int m0, u32 rw, u32 cw0, u32 cw1, auto edge) {
         constexpr bool EDGE = decltype(edge)::value;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -157,9 +163,9 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
                 vo = __builtin_amdgcn_uicmp((u32)(m - m_o), (u32)cnt_o, ICMP_ULT);
             }
             // (row class << 8) | column class * 4: bytes 1 and 0 picked by one v_perm (selector bytes 0-3: second source)
-            const u32 a0 = k == 0 ? __builtin_amdgcn_perm(rw, cwp, 0x0C0C0403u)
-                                  : __builtin_amdgcn_perm(rw, cw, 0x0C0C0000u | ((u32)(4 + k) << 8) | (u32)(k - 1));
-            const u32 a1 = __builtin_amdgcn_perm(rw, cw, 0x0C0C0000u | ((u32)(4 + k) << 8) | (u32)k);
+            const u32 a0 = __builtin_amdgcn_perm(rw, cw0, 0x0C0C0000u | ((u32)(4 + k) << 8) | (u32)k);
+            const u32 a1 = k < 3 ? __builtin_amdgcn_perm(rw, cw0, 0x0C0C0000u | ((u32)(4 + k) << 8) | (u32)(k + 1))
+                                 : __builtin_amdgcn_perm(rw, cw1, 0x0C0C0700u);
             const int s0 = s_b62[a0], s1 = s_b62[a1];
             int nBe, Ie_out, De_out, nBo, nIo, nDo;
             m64 te0, te1, to0, to1;
@@ -184,15 +190,27 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
                 }
             }
         }
-        cwp = cw;
     };
     const int int_hi = min(R, ncols) - 3;  // groups m0 in [17, int_hi] are interior for this alignment (all 16 lanes, all 4 steps)
-    u32 rw = win4(rcls, 8 - l - 1), cw = win4(ccls, 8 + l - KB);
-    for (int m0 = 8; m0 <= m_end; m0 += 4) {
-        const u32 nrw = win4(rcls, m0 + 4 - l - 1), ncw = win4(ccls, m0 + 4 + l - KB);  // the next group's windows
-        if (__all(m0 >= 17 && m0 <= int_hi)) four(m0, rw, cw, std::false_type{});
-        else four(m0, rw, cw, std::true_type{});
-        rw = nrw, cw = ncw;
+    // every ACTIVE lane's group m0 is interior: one compare against the exec mask (m0 is wave-uniform)
+    auto all_interior = [&](int m0) {
+        return m0 >= 17 && __builtin_amdgcn_sicmp(m0, int_hi, 41 /*ICMP_SLE*/) == __builtin_amdgcn_read_exec();
+    };
+    const u8* rp = rcls + (8 - l - 1);       // row classes of the group's four iterations
+    const u8* cp = ccls + (8 + l - KB - 1);  // column classes, one column early
+    // (fetching the windows one group ahead was measured and is slower: 35.1 against 33.4 ms of align rounds on config 3)
+    for (int m0 = 8; m0 <= m_end; m0 += 4, rp += 4, cp += 4) {
+        if (all_interior(m0)) {
+            // the interior groups of the wave's active alignments run in a loop of their own (one code path: no copies where the
+            // two variants of a group would join); an interior group is at least 18 iterations away from its alignment's last
+            do {
+                const u64 cw = load8u(cp);
+                four(m0, load4u(rp), (u32)cw, (u32)(cw >> 32), std::false_type{});
+                m0 += 4, rp += 4, cp += 4;
+            } while (all_interior(m0));
+        }
+        const u64 cw = load8u(cp);
+        four(m0, load4u(rp), (u32)cw, (u32)(cw >> 32), std::true_type{});
     }
     // lane best: max score, then smallest i, then the even cell (smaller j)
     int best, bi, bj;
