@@ -156,7 +156,6 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int m = m0 + k;
-            const int i = m - l;
             m64 ve = ~0ull, vo = ~0ull;
             if (EDGE) {
                 ve = __builtin_amdgcn_uicmp((u32)(m - m_e), (u32)cnt_e, ICMP_ULT);
@@ -172,23 +171,28 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
             dp_cell<EDGE>(ve, dpp_row_shr1(Io_out), Do_out, Be, s0, nBe, Ie_out, De_out, te0, te1);
             dp_cell<EDGE>(vo, Ie_out, dpp_row_shl1(De_out), Bo, s1, nBo, nIo, nDo, to0, to1);
             Be = nBe, Bo = nBo, Io_out = nIo, Do_out = nDo;
-            // first strict maximum in row-major order == largest (score, 8191 - i) key; keys of invalid cells are < any valid one
+            // first strict maximum in row-major order == largest (score, 8191 - i) key; inside a lane i = m - l, so the lane keeps
+            // (score, 8191 - m) -- the second half is wave-uniform, an SGPR -- and converts at the end; keys of invalid cells
+            // (score 0) are < any scoring one
             if (TRACE) {
-                const u32 rk = (u32)(8191 - i) & 8191u;
+                const u32 rk = (u32)(8191 - m);
                 keyE = max(keyE, ((u32)nBe << 13) | rk);
                 keyO = max(keyO, ((u32)nBo << 13) | rk);
             } else {  // score-only: the position of the maximum is not needed
                 keyE = max(keyE, max((u32)nBe, (u32)nBo));
             }
-            // the row's 4 trace bits (odd cell: bits 3-2, even cell: bits 1-0) are shifted into the trace word, one v_addc
-            // per bit; rows outside [1, R] shift in zeros.  Row r of an 8-row word ends up in nibble 7 - (r & 7).
-            if (TRACE) {
-                tw = shl1_in(shl1_in(shl1_in(shl1_in(tw, to1), to0), te1), te0);
-                if ((!EDGE || (u32)(i - 1) < (u32)R) && ((((u32)(i - 1)) & 7u) == 7u || i == R)) {
-                    tr[((u32)(i - 1) >> 3) * 16u + (u32)l] = tw << ((7u - ((u32)(i - 1) & 7u)) << 2);  // left-align a partial last word
-                    tw = 0;
-                }
-            }
+            // the iteration's 4 trace bits (odd cell: bits 3-2, even cell: bits 1-0) are shifted into the trace word, one v_addc
+            // per bit; invalid cells shift in zeros
+            if (TRACE) tw = shl1_in(shl1_in(shl1_in(shl1_in(tw, to1), to0), te1), te0);
+        }
+        // Trace words are laid out by ITERATION, not by row: word [(m >> 3) - 1][lane] holds the lane's cells of iterations
+        // 8 (m >> 3) .. + 7, iteration m in nibble 7 - (m & 7) -- so all lanes store together, every second group (a row-aligned
+        // layout has two lanes of every row storing in EVERY iteration: a masked store sequence per iteration, 40 of the 158
+        // VALU of a traced group).  A lane's last group may end half a word: stored left-aligned.
+        if (TRACE) {
+            const bool full = (m0 & 4) != 0;
+            if (full || m0 + 4 > m_end) tr[(u32)((m0 >> 3) - 1) * 16u + (u32)l] = full ? tw : (tw << 16);
+            if (full) tw = 0;
         }
     };
     const int int_hi = min(R, ncols) - 3;  // groups m0 in [17, int_hi] are interior for this alignment (all 16 lanes, all 4 steps)
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     int best, bi, bj;
     {
         const int sE = (TRACE ? (int)(keyE >> 13) : (int)keyE) - BIAS, sO = TRACE ? (int)(keyO >> 13) - BIAS : 0;
-        const int iE = 8191 - (int)(keyE & 8191u), iO = 8191 - (int)(keyO & 8191u);
+        const int iE = 8191 - (int)(keyE & 8191u) - l, iO = 8191 - (int)(keyO & 8191u) - l;  // m -> i (score-only: unused)
         const bool takeO = (sO > sE) || (sO == sE && iO < iE);
         best = takeO ? sO : sE;
         bi = takeO ? iO : iE;
@@ -283,9 +287,10 @@ __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ ta
             const int d = j - i + KB;
             if (d < 0) tc = 3;  // left boundary cell (i, i-17): '|'
             else {
-                const int key = ((i - 1) >> 3) * 16 + (d >> 1);
+                const int m = i + (d >> 1);  // the iteration that computed the cell in lane d >> 1 (k_align's trace layout)
+                const int key = ((m >> 3) - 1) * 16 + (d >> 1);
                 if (key != wkey) wkey = key, wv = tr[key];
-                tc = (int)((wv >> (((7 - ((i - 1) & 7)) << 2) + ((d & 1) << 1))) & 3u);
+                tc = (int)((wv >> (((7 - (m & 7)) << 2) + ((d & 1) << 1))) & 3u);
             }
         }
         if (tc == 0) break;
@@ -318,8 +323,8 @@ __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ ta
 }
 
 u32 align_trace_stride(int max_cols_plus) {
-    // words per task: ceil(R / 8) * 16, R <= max_cols_plus; rounded to 32 words (128 B)
-    u32 w = (u32)((max_cols_plus + 7) / 8) * 16u;
+    // words per task: 16 per block of 8 iterations, iterations 8 .. R + 15, R <= max_cols_plus; rounded to 32 words (128 B)
+    u32 w = (u32)((max_cols_plus + 15) / 8 + 1) * 16u;
     return (w + 31u) & ~31u;
 }
 
