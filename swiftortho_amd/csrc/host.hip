@@ -17,7 +17,9 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <malloc.h>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 
@@ -1151,11 +1153,52 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     c->cnt.group_ms += (wall() - t1) * 1e3;
 }
 
-// growable result array handed to the caller as-is (so_free_hits == free): no zero-fill, no final copy
+// One released result array is kept for the next search (process-wide, SOHIT_HIT_CACHE=0 turns it off): a config-3 result is 130 MB,
+// and handing that back to the kernel page by page and faulting it in again costs more than 17 ms per search -- a fifth of the step.
+// Only arrays above 1 MiB are kept; the larger of (cached, released) survives, so_destroy() drops it.
+struct HitCache {
+    std::mutex mu;
+    so_hit* p = nullptr;
+    size_t bytes = 0;
+    static bool enabled() {
+        const char* e = getenv("SOHIT_HIT_CACHE");
+        return !(e && atoi(e) == 0);
+    }
+    so_hit* take(size_t& cap_rows) {
+        std::lock_guard<std::mutex> g(mu);
+        so_hit* r = p;
+        cap_rows = bytes / sizeof(so_hit);
+        p = nullptr, bytes = 0;
+        return r;
+    }
+    void give(so_hit* q) {
+        if (!q) return;
+        const size_t b = malloc_usable_size(q);
+        if (!enabled() || b < ((size_t)1 << 20)) {
+            free(q);
+            return;
+        }
+        so_hit* drop = q;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (b > bytes) drop = p, p = q, bytes = b;
+        }
+        free(drop);
+    }
+    void clear() {
+        size_t n;
+        free(take(n));
+    }
+};
+HitCache g_hit_cache;
+
+// growable result array handed to the caller as-is: no zero-fill, no final copy
 struct HitBuf {
     so_hit* p = nullptr;
     size_t n = 0, cap = 0;
     void grow(size_t extra) {
+        if (n + extra <= cap) return;
+        if (!p) p = g_hit_cache.take(cap);  // the previous search's array, pages still mapped
         if (n + extra <= cap) return;
         size_t nc = std::max<size_t>(n + extra, cap + cap / 2 + 1024);
         so_hit* np_ = (so_hit*)realloc(p, nc * sizeof(so_hit));
@@ -1169,7 +1212,7 @@ struct HitBuf {
         n = cap = 0;
         return r;
     }
-    ~HitBuf() { free(p); }
+    ~HitBuf() { g_hit_cache.give(p); }
 };
 
 struct HostRow {
@@ -1657,6 +1700,7 @@ void so_destroy(so_ctx* c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->st) (void)hipStreamDestroy(c->st);
     delete c;
+    g_hit_cache.clear();
 }
 
 const char* so_last_error(const so_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
@@ -1724,7 +1768,7 @@ int so_search(so_ctx* c, const char* qry_path, int64_t q_lo, int64_t q_hi, so_hi
     return so_search_loaded(c, q_lo, q_hi, hits, n_hits);
 }
 
-void so_free_hits(so_hit* hits) { free(hits); }
+void so_free_hits(so_hit* hits) { g_hit_cache.give(hits); }
 
 int so_search_device(so_ctx* c, int64_t q_lo, int64_t q_hi, const so_hit** d_hits, int64_t* n_hits) {
     return guarded(c, [&] {
