@@ -676,7 +676,7 @@ struct Batch {
     DevBuf<u32> ccnt;                         // [nchunks][nq] per-query counts
     DevBuf<u64> gx;
     DevBuf<u32> gL, gR;
-    DevBuf<u32> segfirst, st_state, rcnt, tcnt, roff, ridx, ntile, roffc, rk_slot, order_tmp;
+    DevBuf<u32> segfirst, st_state, rcnt, tcnt, roff, ridx, ridx2, ntile, roffc, rk_slot, order_tmp;
     DevBuf<u32> cqoff, prior, qtot, qcoff, fin_rec, perm, ntask, toff, sel, nout, ooff;
     DevBuf<AlnTask> tasks;
     DevBuf<AlnRes> ares;
@@ -1313,6 +1313,17 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     HIP_CHECK(hipMemsetAsync(b.ares.p, 0, ((size_t)NT + 4) * sizeof(AlnRes), c->st));  // unaligned slots count 0 cells
     launch_mktasks(b.fin_rec.p, b.qcoff.p, b.perm.p, b.ntask.p, b.roffc.p, b.toff.p, nq, b.dev.d_off.p, c->ref.d_off.p, b.tasks.p,
                    b.rk_slot.p, c->st);
+    // k_align runs four alignments per wave and a wave lasts as long as its longest one: every launch list is ordered by band rows,
+    // longest first (one 13-bit radix sort; config 3: align rounds 33.6 -> 28.4 ms, sort included).  SOHIT_ALIGN_SORT=0: as listed.
+    const bool align_sort = !(getenv("SOHIT_ALIGN_SORT") && atoi(getenv("SOHIT_ALIGN_SORT")) == 0);
+    auto sort_by_rows = [&](const u32* list, u32 n) -> const u32* {
+        if (!align_sort || n < 4096) return list;
+        b.tmp64.ensure((size_t)n + 2), b.c_ft2.ensure((size_t)n + 2), b.ridx2.ensure((size_t)n + 2);
+        ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(n, 64));
+        launch_task_rows(b.tasks.p, list, n, b.dev.d_off.p, c->ref.d_off.p, b.tmp64.p, c->st);
+        sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, list, b.ridx2.p, n, 13, c->st);
+        return b.ridx2.p;
+    };
     // banded alignments in rounds (see k_round_counts / k_stop_round)
     const u32 maxwin_q = std::min<u32>(b.maxqlen, LONG_SEQ), maxwin_s = std::min<u32>(c->ref.maxlen, LONG_SEQ);
     const int maxrows = (int)std::min<u32>(std::max(maxwin_q, maxwin_s), std::min(maxwin_q, maxwin_s) + 16);
@@ -1338,8 +1349,9 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         if (NR) {
             launch_round_idx(b.tcnt.p, b.roff.p, b.toff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.st_state.p, nq, b.ridx.p, c->st);
             // score-only: the stop rule needs the maximum alone; the reported rows are traced in a second pass below
+            const u32* rlist = sort_by_rows(b.ridx.p, NR);
             ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
-            launch_align(b.tasks.p, b.ridx.p, NR, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
+            launch_align(b.tasks.p, rlist, NR, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
                          c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, b.ares.p, false, c->st);
             pt.stop();
         }
@@ -1364,9 +1376,10 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         b.trace.ensure((size_t)std::min(slab, NO) * stride + 64);
         {
             ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
+            const u32* slist = b.sel_idx.p;  // (ordering this pass by rows too costs more than it saves: 9.1 -> 9.9 ms on config 3)
             for (u32 t = 0; t < NO; t += slab) {
                 const u32 n = std::min(slab, NO - t);
-                launch_align(b.tasks.p, b.sel_idx.p + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p,
+                launch_align(b.tasks.p, slist + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p,
                              c->ref.d_scls.p, c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, b.ares.p, true, c->st);
             }
             pt.stop();
