@@ -1364,7 +1364,8 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     sc.lap("phase2.align_rounds");
     c->cnt.alignments += aligned_total;
     b.nout.ensure((size_t)nq + 4), b.ooff.ensure((size_t)nq + 4);
-    HIP_CHECK(hipMemsetAsync(b.nout.p, 0, ((size_t)nq + 4) * sizeof(u32), c->st));
+    HIP_CHECK(hipMemsetAsync(b.nout.p, 0xFF, (size_t)nq * sizeof(u32), c->st));  // 0xFFFFFFFF = not selected yet
+    HIP_CHECK(hipMemsetAsync(b.nout.p + nq, 0, 4 * sizeof(u32), c->st));
     launch_final_select(b.toff.p, nq, c->v, b.sel.p, b.st_state.p, b.bits.p, b.nout.p, c->st);
     const u32* dNO = scan_u32(b.nout.p, b.ooff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
     const u32 NO = d2h_u32(c, dNO);

@@ -263,12 +263,43 @@ __global__ __launch_bounds__(64) void k_stop_round(const AlnTask* __restrict__ t
     S[0] = r, S[1] = (u32)unmch, S[2] = (u32)bv, S[3] = nsel, S[4] = done ? 1u : 0u;
 }
 
-// qsort_u(m8s, key=-bit) (3108) + first v (3109)
+// qsort_u(m8s, key=-bit) (3108) + first v (3109).  A wave per query replays the reference quicksort on (inverted bit score, list
+// position) words in LDS (lists of up to FSEL_CAP rows: -v 500 keeps them there); longer lists take the one-thread replay.  (One
+// thread per query was 9 ms per batch on the 1 M-protein run, where every query reports its full 500 rows: 2.4 s of 121.)
+#define FSEL_CAP 1024
+#define FSEL_BITMAX ((1 << 20) - 1)
+__global__ __launch_bounds__(64) void k_final_select_lds(const u32* __restrict__ toff, u32 nq, i64 v, u32* __restrict__ sel,
+                                                         const u32* __restrict__ st_state, const int* __restrict__ bits,
+                                                         u32* __restrict__ nout) {
+    __shared__ u32 s_x[FSEL_CAP], s_v[FSEL_CAP];
+    __shared__ u16 s_L[FSEL_CAP], s_R[FSEL_CAP];
+    __shared__ int s_leaf[2 * WQS_LEAF];
+    const u32 q = blockIdx.x;
+    const u32 t0 = toff[q];
+    const int n = (int)st_state[5 * (size_t)q + 3];
+    if (n > FSEL_CAP) return;  // k_final_select
+    bool fits = true;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const u32 r = sel[t0 + i];
+        const int b = bits[t0 + r];
+        fits = fits && b >= 0 && b <= FSEL_BITMAX;
+        s_v[i] = r;
+        s_x[i] = ((u32)(FSEL_BITMAX - b) << 12) | (u32)i;
+    }
+    // a bit score outside 20 bits cannot be packed: such a list (none exists with integer alignment scores) is left to the serial kernel
+    if (!__all(fits)) return;
+    __syncthreads();
+    wave_ref_qsort(s_x, n, [](u32 w) { return (int)(w >> 12); }, 0x7fffffff, s_L, s_R, s_leaf);
+    for (int i = threadIdx.x; i < n; i += 64) sel[t0 + i] = s_v[s_x[i] & 0xFFFu];
+    const i64 vv = v > 0 ? v : 0;
+    if (threadIdx.x == 0) nout[q] = (i64)n < vv ? (u32)n : (u32)vv;
+}
+
 __global__ __launch_bounds__(64) void k_final_select(const u32* __restrict__ toff, u32 nq, i64 v, u32* __restrict__ sel,
                                                      const u32* __restrict__ st_state, const int* __restrict__ bits,
-                                                     u32* __restrict__ nout) {
+                                                     u32* nout, const u32* done /*== nout*/) {
     const u32 q = blockIdx.x * 64u + threadIdx.x;
-    if (q >= nq) return;
+    if (q >= nq || done[q] != 0xFFFFFFFFu) return;  // the wave kernel wrote this query's count
     const u32 t0 = toff[q];
     const u32 nsel = st_state[5 * (size_t)q + 3];
     const int* b = bits + t0;
@@ -399,7 +430,9 @@ void launch_stop_round(const AlnTask* tasks, const AlnRes* res, const u32* qcoff
 
 void launch_final_select(const u32* toff, u32 nq, i64 v, u32* sel, const u32* st_state, const int* bits, u32* nout, hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_final_select, dim3((nq + 63) / 64), dim3(64), 0, st, toff, nq, v, sel, st_state, bits, nout);
+    // nout arrives filled with 0xFFFFFFFF: the wave kernel writes the count of every query it handles, the serial one takes the rest
+    hipLaunchKernelGGL(k_final_select_lds, dim3(nq), dim3(64), 0, st, toff, nq, v, sel, st_state, bits, nout);
+    hipLaunchKernelGGL(k_final_select, dim3((nq + 63) / 64), dim3(64), 0, st, toff, nq, v, sel, st_state, bits, nout, nout);
 }
 
 void launch_selected_idx(const u32* toff, const u32* sel, const u32* nout, const u32* ooff, u32 nq, u32* idx, hipStream_t st) {

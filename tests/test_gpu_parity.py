@@ -205,6 +205,38 @@ def test_query_subrange_and_small_batches(fs, oracle, tmp_path, monkeypatch):
     oracle_vs_gpu(fs, oracle, synthprot.synthprot(500, 120, 82), kw, tmp_path, sub=(100, 333))
 
 
+def test_aligner_launch_order_and_result_cache_do_not_change_rows(fs, oracle, tmp_path, monkeypatch):
+    """The score-only aligner launches are ordered by band rows (k_task_rows + radix sort, lists of >= 4096 tasks) and a released
+    result array is reused by the next search (so_free_hits keeps one): with both switched off, and over repeated searches on one
+    context (the second search starts from the first one's array), rows stay the oracle's."""
+    from swiftortho_amd import synthprot
+    fa = synthprot.synthprot(3000, 220, 97)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=4000037, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+    want = open(str(tmp_path / "o.sc"), "rb").read()
+    big = synthprot.synthprot(12000, 300, 98)   # ~2 MB of result records: above the cache's 1 MiB floor
+    s = fs.Searcher(**kw)
+    s.load_ref_bytes(big)
+    s.load_queries_bytes(big)
+    first = None
+    for _ in range(3):
+        h = s.search()
+        rows = b"".join(h.rows())
+        assert len(h) * 80 > (1 << 20)
+        first = first or rows
+        assert rows == first
+        h.close()
+    s.load_ref_bytes(fa)          # a smaller result written into the kept (larger) array
+    s.load_queries_bytes(fa)
+    h = s.search()
+    assert b"".join(h.rows()) == want
+    h.close()
+    s.close()
+    monkeypatch.setenv("SOHIT_ALIGN_SORT", "0")
+    monkeypatch.setenv("SOHIT_HIT_CACHE", "0")
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+
+
 def test_no_filter_threshold_override_small_v(fs, oracle, tmp_path):
     """-F F (no SEG masking), -t override of the seed-frequency threshold, -v 3, -m 0.5, lower-case residues"""
     from swiftortho_amd import synthprot
