@@ -452,8 +452,13 @@ __global__ __launch_bounds__(BB_THREADS) void k_bkt_best(const u64* __restrict__
     constexpr int SPT = BG_BINS / BB_THREADS;
     for (u32 b = blockIdx.x; b < nb; b += gridDim.x) {
         const u32 b0 = boff[b], n = boff[b + 1] - b0;
+        // candidates are laid out QUERY-major (the buckets are range-major): a query's candidates of all ranges sit together, so
+        // the gather that follows the candidate-order sort (k_emit_cands) stays inside a few KB per query instead of fetching one
+        // 128-byte line per 16-byte record
+        const u32 qrel = b - (b / L.nqp) * L.nqp;
+        const u32 ci = qrel * L.R + b / L.nqp;
         if (n == 0) {
-            if (!WRITE && tid == 0) ccnt[b] = 0;
+            if (!WRITE && tid == 0) ccnt[ci] = 0;
             continue;
         }
         __syncthreads();
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(BB_THREADS) void k_bkt_best(const u64* __restrict__
             total += s_wsum[k];
         }
         if (!WRITE) {
-            if (tid == 0) ccnt[b] = total;
+            if (tid == 0) ccnt[ci] = total;
             continue;
         }
 #pragma unroll
@@ -498,8 +503,8 @@ __global__ __launch_bounds__(BB_THREADS) void k_bkt_best(const u64* __restrict__
             run += c[k];
         }
         __syncthreads();
-        const u32 base = ccnt[b];
-        const u32 gq = L.qa + (b - (b / L.nqp) * L.nqp);
+        const u32 base = ccnt[ci];
+        const u32 gq = L.qa + qrel;
         for (u32 i = (u32)tid; i < n; i += BB_THREADS) {
             const u64 qs = q_qs[b0 + i], sd = q_sd[b0 + i], ft = q_ft[b0 + i];
             const u32 s = (u32)qs & (W - 1u);
