@@ -1147,8 +1147,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     launch_emit_cands(b.order.p, NS, b.c_ft2.p, qshift, c_recp, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, b.segfirst.p, c->st);
     b.chunk_base.back() = base + NS;
     c->cnt.candidates += NS;
-    HIP_CHECK(hipStreamSynchronize(c->st));
-    sc.lap("group.best_order");
+    sc.lap("group.best_order");  // (synchronises when profiling; otherwise the next pass is queued behind this one)
     c->cnt.seed_ms += (t1 - t0) * 1e3;
     c->cnt.group_ms += (wall() - t1) * 1e3;
 }
@@ -1289,11 +1288,17 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     HIP_CHECK(hipMemsetAsync(b.ntile.p, 0, ((size_t)nq + 4) * sizeof(u32), c->st));
     {
         // queries with more candidates than the LDS sort holds need global scratch for the wave sort
-        std::vector<u32> qt(nq);
-        HIP_CHECK(hipMemcpyAsync(qt.data(), b.qtot.p, (size_t)nq * sizeof(u32), hipMemcpyDeviceToHost, c->st));
+        // (through the pinned per-query buffer of the seed stage: a pageable read of nq words costs more than the kernels around it)
+        if (c->h_qhits_cap < nq) {
+            if (c->h_qhits) (void)hipHostFree(c->h_qhits);
+            c->h_qhits_cap = (size_t)nq + 1024;
+            HIP_CHECK(hipHostMalloc((void**)&c->h_qhits, c->h_qhits_cap * sizeof(unsigned long long), hipHostMallocDefault));
+        }
+        const u32* qt = reinterpret_cast<const u32*>(c->h_qhits);
+        HIP_CHECK(hipMemcpyAsync(c->h_qhits, b.qtot.p, (size_t)nq * sizeof(u32), hipMemcpyDeviceToHost, c->st));
         HIP_CHECK(hipStreamSynchronize(c->st));
         u32 mx = 0;
-        for (u32 v : qt) mx = std::max(mx, v);
+        for (u32 i = 0; i < nq; ++i) mx = std::max(mx, qt[i]);
         u64* gx = nullptr;
         u32 *gL = nullptr, *gR = nullptr;
         if ((int)mx > csort_lds_max()) {
