@@ -272,6 +272,11 @@ def test_huge_family_over_4096_candidates_per_query(fs, oracle, tmp_path):
     kw = dict(ssd="111111", nr=oracle.AA9, ht=3000017, chk=50000, step=1, v=500, expect=1e-5, flt="T", thr=100000)
     c, _ = oracle_vs_gpu(fs, oracle, "".join(recs).encode(), kw, tmp_path, sub=(17, 23))
     assert c["candidates"] > 6 * 4096
+    # -v 2500: every query reports > 1024 rows, so the final selection takes the one-thread quicksort replay instead of the
+    # LDS wave one (k_final_select_lds serves lists of up to 1024 rows)
+    kw["v"] = 2500
+    c, _ = oracle_vs_gpu(fs, oracle, "".join(recs).encode(), kw, tmp_path, sub=(40, 43))
+    assert c["rows"] > 3 * 1024
 
 
 def test_wide_addends_and_device_wide_sort_paths(fs, oracle, tmp_path, monkeypatch):
