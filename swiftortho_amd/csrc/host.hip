@@ -203,6 +203,8 @@ struct ChunkIndex {
     DevBuf<u64> hval;
     int hshift = 31;
     u32 hmask = 0;
+    DevBuf<u64> dir;      // bitmap + rank directory (k_dir_build) used instead of the map when NC <= 2^28
+    bool use_dir = false;
     DevBuf<u64> dkeys;    // E: per-entry key addends for the layout (d_sh_subj, d_sh_diag) -- k_encode_delta
     DevBuf<u32> dk32;     // E: compact addends for field widths (d_ba, d_bd) -- k_encode_delta32
     int d_sh_subj = -1, d_sh_diag = -1, d_ba = -1, d_bd = -1;
@@ -579,6 +581,10 @@ void build_index(so_ctx* c) {
         ch->p_hi = c->ref.off[ch->seq_hi] + (u32)ch->seq_hi;
         ch->maxslen = 0;
         for (i64 j = ch->seq_lo; j < ch->seq_hi; ++j) ch->maxslen = std::max(ch->maxslen, c->ref.len(j));
+        {
+            const char* e = getenv("SOHIT_DIR_MAX");  // largest -M served by the bitmap + rank directory (NC / 4 bytes per chunk)
+            ch->use_dir = (u64)NC <= (e ? (u64)atoll(e) : (1ull << 28));
+        }
         // 1. windows per position -> exclusive scan -> (bucket, entry) pairs in position order
         const u32 npos = ch->p_hi - ch->p_lo;
         c->ix_pcount.ensure((size_t)npos + 4);
@@ -617,16 +623,28 @@ void build_index(so_ctx* c) {
             HIP_CHECK(hipStreamSynchronize(c->st));
             s2 = stats[1];
             const u32 last_lo = *last_lo_h;
-            // 5. open-addressed directory, load factor <= 1/2
-            u32 cap = 1024;
-            int lg = 10;
-            while (cap < 2 * U) cap <<= 1, ++lg;
-            ch->hkey.ensure(cap), ch->hval.ensure(cap);
-            ch->hshift = 32 - lg, ch->hmask = cap - 1;
-            HIP_CHECK(hipMemsetAsync(ch->hkey.p, 0xFF, (size_t)cap * sizeof(u32), c->st));
-            launch_htab_insert(ch->ub.p, ch->ubeg.p, U, ch->hkey.p, ch->hval.p, ch->hshift, ch->hmask, c->st);
+            // 5. bucket directory: bitmap + rank table over the NC bucket ids, or (very large -M) an open-addressed map, load <= 1/2
+            if (ch->use_dir) {
+                const size_t nd = (size_t)NC / 32 + 2;
+                ch->dir.ensure(nd);
+                HIP_CHECK(hipMemsetAsync(ch->dir.p, 0, nd * sizeof(u64), c->st));
+                launch_dir_build(ch->ub.p, U, ch->dir.p, c->st);
+            } else {
+                u32 cap = 1024;
+                int lg = 10;
+                while (cap < 2 * U) cap <<= 1, ++lg;
+                ch->hkey.ensure(cap), ch->hval.ensure(cap);
+                ch->hshift = 32 - lg, ch->hmask = cap - 1;
+                HIP_CHECK(hipMemsetAsync(ch->hkey.p, 0xFF, (size_t)cap * sizeof(u32), c->st));
+                launch_htab_insert(ch->ub.p, ch->ubeg.p, U, ch->hkey.p, ch->hval.p, ch->hshift, ch->hmask, c->st);
+            }
             // 6. the reference never reads the last locus slot: park the last bucket's smallest entry there
             launch_index_fixlast(ch->entries.p, last_lo, E, c->st);
+        } else if (ch->use_dir) {
+            const size_t nd = (size_t)NC / 32 + 2;
+            ch->dir.ensure(nd);
+            ch->ubeg.ensure(4);
+            HIP_CHECK(hipMemsetAsync(ch->dir.p, 0, nd * sizeof(u64), c->st));
         } else {
             ch->hkey.ensure(1024), ch->hval.ensure(1024);
             ch->hshift = 22, ch->hmask = 1023;
@@ -815,7 +833,8 @@ const unsigned long long* chunk_qhits(so_ctx* c, Batch& b, int ci) {
     const u32 Ppad = b.dev.Ppad, NC = (u32)c->nc;
     {
         ProfTimer pt(c, &c->cnt.bounds_ms, &c->cnt.bounds_launches);
-        launch_bounds(b.qbucket.p, Ppad, AS, ch.hkey.p, ch.hval.p, ch.hshift, ch.hmask, NC, ch.E, b.sbeg.p, b.scnt.p, b.pcnt.p, c->st);
+        launch_bounds(b.qbucket.p, Ppad, AS, ch.hkey.p, ch.hval.p, ch.hshift, ch.hmask, ch.use_dir ? ch.dir.p : nullptr, ch.ubeg.p, NC, ch.E, b.sbeg.p,
+                      b.scnt.p, b.pcnt.p, c->st);
         pt.stop();
         if (c->profile) c->cnt.bounds_bytes += (i64)8 * AS * (i64)b.h_off[b.nq];
     }

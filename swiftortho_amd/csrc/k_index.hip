@@ -103,6 +103,20 @@ __global__ __launch_bounds__(256) void k_htab_insert(const u32* __restrict__ ub,
     hval[h] = (u64)ubeg[k] | ((u64)(ubeg[k + 1] - ubeg[k]) << 32);
 }
 
+// ---- bitmap + rank directory: bucket id -> position in the occupied-bucket list --------------------------------
+// dir[w] (one 8-byte word per 32 bucket ids) = occupancy bits of buckets 32w .. 32w + 31 (low half) | number of occupied buckets
+// below 32w (high half); bucket b is occupied iff its bit is set, and its place in ub / ubeg is high + popcount(bits below b).
+// NC / 4 bytes (30 MB at -M 120000000: Infinity-Cache resident) against 12 bytes x 2 x U for the open-addressed map, and the build
+// is one coalesced pass over the ascending list (the map's 15 M random compare-and-swaps were 1.2 ms of the 2.5 ms a config-3
+// chunk takes to index).  Used when NC <= 2^28 (SOHIT_DIR_MAX); larger -M keep the map.
+__global__ __launch_bounds__(256) void k_dir_build(const u32* __restrict__ ub, u32 U, u32* __restrict__ dir32) {
+    const u32 k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= U) return;
+    const u32 b = ub[k], w = b >> 5;
+    atomicOr(&dir32[2 * (size_t)w], 1u << (b & 31u));
+    if (k == 0 || (ub[k - 1] >> 5) != w) dir32[2 * (size_t)w + 1] = k;  // the word's first occupied bucket: ub is ascending
+}
+
 // sum c, sum c^2, #non-empty, largest non-empty bucket id over counts[0..NC)
 __global__ __launch_bounds__(256) void k_index_stats(const u32* __restrict__ counts, u32 NC, u64* __restrict__ stats /*[gridDim.x][4] partials*/) {
     u64 s1 = 0, s2 = 0;
@@ -274,6 +288,10 @@ void launch_run_list(const u32* bkt, const u32* flags, const u32* ridx, u32 E, u
     hipLaunchKernelGGL(k_run_list, dim3((E + 255) / 256), dim3(256), 0, st, bkt, flags, ridx, E, U, ub, ubeg);
     hipLaunchKernelGGL(k_run_counts, dim3((U + 255) / 256), dim3(256), 0, st, ubeg, U, cnt);
 }
+void launch_dir_build(const u32* ub, u32 U, u64* dir, hipStream_t st) {
+    if (U) hipLaunchKernelGGL(k_dir_build, dim3((U + 255) / 256), dim3(256), 0, st, ub, U, reinterpret_cast<u32*>(dir));
+}
+
 void launch_htab_insert(const u32* ub, const u32* ubeg, u32 U, u32* hkey, u64* hval, int hshift, u32 hmask, hipStream_t st) {
     if (U) hipLaunchKernelGGL(k_htab_insert, dim3((U + 255) / 256), dim3(256), 0, st, ub, ubeg, U, hkey, hval, hshift, hmask);
 }

@@ -28,10 +28,13 @@ __global__ __launch_bounds__(TILE_POS) void k_qhash(const u32* __restrict__ word
 
 // ---- bucket bounds against one chunk index (get_bin_mem, fsearch.py:2530-2541) -------------------
 // sbeg/scnt[as][p]: first slot and clamped size of the bucket; pcnt[p] = sum over as (hist[qst][2]).
-// The bucket directory is the chunk's open-addressed map (k_index.hip): one probe sequence per window.
+// The bucket directory is the chunk's bitmap + rank table (DIR; k_index.hip: one 8-byte read, then the bucket's two slot bounds) or,
+// for very large -M, its open-addressed map (one probe sequence per window).
+template <bool DIR>
 __global__ __launch_bounds__(256) void k_bounds(const u32* __restrict__ qbucket, u32 Ppad, int AS, const u32* __restrict__ hkey,
-                                                const u64* __restrict__ hval, int hshift, u32 hmask, u32 NC, u32 E,
-                                                u32* __restrict__ sbeg, u32* __restrict__ scnt, u32* __restrict__ pcnt) {
+                                                const u64* __restrict__ hval, int hshift, u32 hmask, const uint2* __restrict__ dir,
+                                                const u32* __restrict__ ubeg, u32 NC, u32 E, u32* __restrict__ sbeg,
+                                                u32* __restrict__ scnt, u32* __restrict__ pcnt) {
     const u32 p = blockIdx.x * 256u + threadIdx.x;
     if (p >= Ppad) return;
     const i64 L = (i64)E - 1;  // self.L = len(self.locus) - 1
@@ -41,19 +44,31 @@ __global__ __launch_bounds__(256) void k_bounds(const u32* __restrict__ qbucket,
         const u32 b = qbucket[(size_t)as * Ppad + p];
         u32 beg = 0, cnt = 0;
         if (b != 0xFFFFFFFFu && b + 1u < NC) {  // bucket NC-1: `except: st = ed` (always empty)
-            u32 h = (b * 2654435761u) >> hshift;
-            for (;;) {
-                const u32 k = hkey[h];
-                if (k == b) {
-                    const u64 v = hval[h];
-                    const i64 st = (i64)(u32)v;
-                    i64 ed = st + (i64)(u32)(v >> 32);  // == start[b + 1]
+            if (DIR) {
+                const uint2 d = dir[b >> 5];
+                const u32 bit = b & 31u;
+                if ((d.x >> bit) & 1u) {
+                    const u32 k = d.y + (u32)__popc(d.x & ((1u << bit) - 1u));
+                    const i64 st = (i64)ubeg[k];
+                    i64 ed = (i64)ubeg[k + 1];  // == start[b + 1]
                     ed = ed < L ? ed : L;
                     if (ed > st) beg = (u32)st, cnt = (u32)(ed - st);
-                    break;
                 }
-                if (k == HTAB_EMPTY) break;
-                h = (h + 1u) & hmask;
+            } else {
+                u32 h = (b * 2654435761u) >> hshift;
+                for (;;) {
+                    const u32 k = hkey[h];
+                    if (k == b) {
+                        const u64 v = hval[h];
+                        const i64 st = (i64)(u32)v;
+                        i64 ed = st + (i64)(u32)(v >> 32);  // == start[b + 1]
+                        ed = ed < L ? ed : L;
+                        if (ed > st) beg = (u32)st, cnt = (u32)(ed - st);
+                        break;
+                    }
+                    if (k == HTAB_EMPTY) break;
+                    h = (h + 1u) & hmask;
+                }
             }
         }
         sbeg[t] = beg;
@@ -395,11 +410,13 @@ void launch_qhash(const u32* words, u32 Ppad, const SeedCfg& cfg, const HashLut&
     hipLaunchKernelGGL(k_qhash, dim3((Ppad + TILE_POS - 1) / TILE_POS), dim3(TILE_POS), 0, st, words, Ppad, cfg, lut, qbucket);
 }
 
-void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* hkey, const u64* hval, int hshift, u32 hmask, u32 NC, u32 E, u32* sbeg,
-                   u32* scnt, u32* pcnt, hipStream_t st) {
+void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* hkey, const u64* hval, int hshift, u32 hmask, const u64* dir, const u32* ubeg,
+                   u32 NC, u32 E, u32* sbeg, u32* scnt, u32* pcnt, hipStream_t st) {
     if (!Ppad) return;
-    hipLaunchKernelGGL(k_bounds, dim3((Ppad + 255) / 256), dim3(256), 0, st, qbucket, Ppad, AS, hkey, hval, hshift, hmask, NC, E, sbeg, scnt,
-                       pcnt);
+    if (dir) hipLaunchKernelGGL(k_bounds<true>, dim3((Ppad + 255) / 256), dim3(256), 0, st, qbucket, Ppad, AS, hkey, hval, hshift, hmask,
+                                reinterpret_cast<const uint2*>(dir), ubeg, NC, E, sbeg, scnt, pcnt);
+    else hipLaunchKernelGGL(k_bounds<false>, dim3((Ppad + 255) / 256), dim3(256), 0, st, qbucket, Ppad, AS, hkey, hval, hshift, hmask,
+                            (const uint2*)nullptr, ubeg, NC, E, sbeg, scnt, pcnt);
 }
 
 void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, int mink, const signed char* b62c, int* ksc, u32* korder,

@@ -38,6 +38,7 @@ void launch_index_windows(bool emit, const u32* words, const u32* pseq, const u3
                           const SeedCfg& cfg, const HashLut& lut, u32 step, u32* pcount, u32* bkt, u64* ent, hipStream_t st);
 void launch_run_heads(const u32* bkt, u32 E, u32* flags, hipStream_t st);
 void launch_run_list(const u32* bkt, const u32* flags, const u32* ridx, u32 E, u32 U, u32* ub, u32* ubeg, u32* cnt, hipStream_t st);
+void launch_dir_build(const u32* ub, u32 U, u64* dir /*zeroed, NC / 32 + 1 words*/, hipStream_t st);
 void launch_htab_insert(const u32* ub, const u32* ubeg, u32 U, u32* hkey, u64* hval, int hshift, u32 hmask, hipStream_t st);
 void sort_pairs_u32_u64(void* temp, size_t temp_bytes, const u32* kin, u32* kout, const u64* vin, u64* vout, size_t n, int bits, hipStream_t st);
 size_t sort_pairs_u32_u64_temp_bytes(size_t n, int bits);
@@ -49,8 +50,8 @@ void launch_index_fixlast(u64* entries, u32 lo, u32 E, hipStream_t st);
 
 // k_seed.hip
 void launch_qhash(const u32* words, u32 Ppad, const SeedCfg& cfg, const HashLut& lut, u32* qbucket, hipStream_t st);
-void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* hkey, const u64* hval, int hshift, u32 hmask, u32 NC, u32 E, u32* sbeg,
-                   u32* scnt, u32* pcnt, hipStream_t st);
+void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* hkey, const u64* hval, int hshift, u32 hmask, const u64* dir /*or null: the map*/,
+                   const u32* ubeg, u32 NC, u32 E, u32* sbeg, u32* scnt, u32* pcnt, hipStream_t st);
 void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, int mink, const signed char* b62c, int* ksc, u32* korder,
                       hipStream_t st);
 void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark,

@@ -237,6 +237,15 @@ def test_aligner_launch_order_and_result_cache_do_not_change_rows(fs, oracle, tm
     oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
 
 
+def test_bucket_directory_map_fallback(fs, oracle, tmp_path, monkeypatch):
+    """The chunk's bucket directory is a bitmap + rank table up to -M 2^28 and an open-addressed map above (SOHIT_DIR_MAX moves
+    the limit): the map path, forced here, gives the same rows, candidates and counters; three chunks, colliding buckets."""
+    from swiftortho_amd import synthprot
+    monkeypatch.setenv("SOHIT_DIR_MAX", "0")
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=50021, chk=300, step=1, v=500, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, synthprot.synthprot(800, 200, 99), kw, tmp_path)
+
+
 def test_no_filter_threshold_override_small_v(fs, oracle, tmp_path):
     """-F F (no SEG masking), -t override of the seed-frequency threshold, -v 3, -m 0.5, lower-case residues"""
     from swiftortho_amd import synthprot
