@@ -100,32 +100,36 @@ struct SegTab {
     double lgn[13][32];
     double log2v;
 };
-#define SEG_TILE 512
-#define SEG_STAGE_MAX 4096  // queries up to this length keep their residues and mask in LDS (STAGE = true)
+#define SEG_STAGE_SMALL 1024  // instance for queries up to this length: 6 KB of LDS per block, so a CU keeps ~26 of them resident
+#define SEG_STAGE_MAX 4096    // queries up to this length keep their residues and mask in LDS (CAP > 0)
 
-// STAGE: the sequential parts (addition replay, output walk) are chains of dependent loads; from LDS a step costs
-// ~100 cycles, from global memory ~600.
-template <bool STAGE>
+// CAP > 0: the query's residues and mask live in LDS -- the sequential parts (addition replay, output walk) are chains of dependent
+// loads; from LDS a step costs ~100 cycles, from global memory ~600.  CAP = 0: no staging (queries longer than SEG_STAGE_MAX).
+// One wave per query, and the sequential parts run on one lane: throughput is the number of queries resident per CU, i.e. LDS per
+// block -- hence the small instance (CAP 1024, 128-step tiles: 6 KB) for the typical protein next to the 4096 / 512 one (17 KB).
+template <int CAP, int TILE>
 __global__ __launch_bounds__(64) void k_seg(const u8* __restrict__ raw, const u32* __restrict__ src_off, u32 q_lo, u32 nq,
                                             const u32* __restrict__ dst_off, const u8* __restrict__ symmap /*256: upper-cased byte*/,
                                             const u8* __restrict__ upmap /*256*/, const SegTab* __restrict__ tab, u8* __restrict__ mk,
                                             u8* __restrict__ out, int min_len /*this instance serves lengths > min_len*/) {
+    constexpr bool STAGE = CAP > 0;
+    constexpr int SEG_TILE = TILE;
     __shared__ u8 s_sym[256], s_up[256];
     __shared__ int s_off[64];  // reference counter - occurrences in the window, per symbol
     __shared__ double s_t1[SEG_TILE], s_t2[SEG_TILE];
-    __shared__ u8 s_S[STAGE ? SEG_STAGE_MAX : 4], s_m[STAGE ? SEG_STAGE_MAX : 4];
+    __shared__ u8 s_S[STAGE ? CAP : 4], s_m[STAGE ? CAP : 4];
     const int lane = threadIdx.x;
+    const u32 q = blockIdx.x;
+    if (q >= nq) return;
+    const int n = (int)(src_off[q_lo + q + 1] - src_off[q_lo + q]);
+    if (n <= 0) return;
+    if ((STAGE && n > CAP) || n <= min_len) return;  // another instance serves this length
     for (int i = lane; i < 256; i += 64) s_sym[i] = symmap[i], s_up[i] = upmap[i];
     s_off[lane] = 0;
     __syncthreads();
-    const u32 q = blockIdx.x;
-    if (q >= nq) return;
     const u8* Sg = raw + src_off[q_lo + q];
-    const int n = (int)(src_off[q_lo + q + 1] - src_off[q_lo + q]);
     u8* o = out + dst_off[q];
     u8* mg = mk + dst_off[q];
-    if (n <= 0) return;
-    if ((STAGE && n > SEG_STAGE_MAX) || n <= min_len) return;  // the host launches the unstaged instance for longer queries
     if (STAGE) {
         for (int i = lane; i < n; i += 64) s_S[i] = Sg[i];
         __syncthreads();
@@ -196,11 +200,23 @@ __global__ __launch_bounds__(64) void k_seg(const u8* __restrict__ raw, const u3
         __syncthreads();
         // ---- the additions, in the reference's order ----
         if (lane == 0) {
-            for (int r = 0; r < cntp; ++r) {
+            // eight steps' addends are fetched before the dependent chain of additions consumes them (same additions, same order)
+            int r = 0;
+            for (; r + 8 <= cntp; r += 8) {
+                double a[8], b[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] = s_t1[r + k], b[k] = s_t2[r + k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    ent += a[k];
+                    ent += b[k];
+                    m[i0 + r + k] = (u8)(ent < minent ? 1 : 0);
+                }
+            }
+            for (; r < cntp; ++r) {
                 ent += s_t1[r];
                 ent += s_t2[r];
-                prev = ent < minent ? 1 : 0;
-                m[i0 + r] = (u8)prev;
+                m[i0 + r] = (u8)(ent < minent ? 1 : 0);
             }
         }
         __syncthreads();
@@ -230,9 +246,14 @@ __global__ __launch_bounds__(256) void k_copy_range(const u8* __restrict__ src, 
 void launch_seg(const u8* raw, const u32* src_off, u32 q_lo, u32 nq, const u32* dst_off, const u8* symmap, const u8* upmap,
                 const void* tab, u8* mk, u8* out, u32 max_len, hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL((k_seg<true>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk, out, 0);
+    // three instances over the same grid, each serving its length range: (0, 1024], (1024, 4096] staged in LDS, longer ones unstaged
+    hipLaunchKernelGGL((k_seg<SEG_STAGE_SMALL, 128>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk,
+                       out, 0);
+    if (max_len > SEG_STAGE_SMALL)
+        hipLaunchKernelGGL((k_seg<SEG_STAGE_MAX, 512>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, nq, dst_off, symmap, upmap, (const SegTab*)tab,
+                           mk, out, SEG_STAGE_SMALL);
     if (max_len > SEG_STAGE_MAX)
-        hipLaunchKernelGGL((k_seg<false>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk, out,
+        hipLaunchKernelGGL((k_seg<0, 512>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk, out,
                            SEG_STAGE_MAX);
 }
 
