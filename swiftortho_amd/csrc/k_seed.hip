@@ -422,7 +422,9 @@ void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* hkey, const 
 void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, int mink, const signed char* b62c, int* ksc, u32* korder,
                       hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL((k_ksc_order_lds<1024, 0>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
+    // (one wave per query: the instance for the typical protein keeps 4 KB of LDS so that a CU holds 32 of them)
+    hipLaunchKernelGGL((k_ksc_order_lds<512, 0>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
+    hipLaunchKernelGGL((k_ksc_order_lds<1024, 512>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
     hipLaunchKernelGGL((k_ksc_order_lds<LDS_SORT_MAX, 1024>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
     hipLaunchKernelGGL(k_ksc_order, dim3((nq + 63) / 64), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, ksc, korder);
 }
