@@ -251,6 +251,9 @@ struct so_ctx {
     DevBuf<u8> d_pcls;
     DevBuf<u8> d_sort_tmp;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t st_rows = nullptr;  // result rows leave on their own stream: the download of one batch overlaps the next batch's kernels
+    hipEvent_t ev_rows = nullptr, ev_rows_done = nullptr;
+    bool rows_in_flight = false;
     size_t max_hits_per_pass = (size_t)1 << 30;
     u32 max_batch = 65536;  // queries per device batch (config 3: 16384 -> 124 ms, 32768 -> 111, 65536 -> 109, 131072 -> 115: fewer passes, still two batches to overlap row emission)
     // device SEG: tables, symbol folding of the loaded query set
@@ -1411,6 +1414,10 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         }
         sc.lap("phase2.trace_pass");
         b.outrec.ensure(12 * (size_t)NO + 16);
+        if (c->rows_in_flight) {  // the previous batch's rows may still be on their way out of b.outrec
+            HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_rows_done, 0));
+            c->rows_in_flight = false;
+        }
         launch_emit_hits(b.tasks.p, b.ares.p, b.toff.p, b.sel.p, b.nout.p, b.ooff.p, b.bits.p, nq, b.outrec.p, c->st);
         if (c->dev_out) {
             // device-resident results: the so_hit records are built in HBM and appended to the ctx's result buffer
@@ -1438,8 +1445,14 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         }
         const HostRow* rows = (const HostRow*)c->pinned;
         sc.lap("phase2.emit_alloc");
-        HIP_CHECK(hipMemcpyAsync(c->pinned, b.outrec.p, 12 * (size_t)NO * sizeof(int), hipMemcpyDeviceToHost, c->st));
-        HIP_CHECK(hipStreamSynchronize(c->st));
+        // the rows are downloaded on a second stream, behind the kernel that wrote them; the worker below waits for the copy, the main
+        // thread goes on to the next batch (whose row kernel in turn waits for this copy before it overwrites the device rows)
+        HIP_CHECK(hipEventRecord(c->ev_rows, c->st));
+        HIP_CHECK(hipStreamWaitEvent(c->st_rows, c->ev_rows, 0));
+        HIP_CHECK(hipMemcpyAsync(c->pinned, b.outrec.p, 12 * (size_t)NO * sizeof(int), hipMemcpyDeviceToHost, c->st_rows));
+        HIP_CHECK(hipEventRecord(c->ev_rows_done, c->st_rows));
+        c->rows_in_flight = true;
+        if (c->profile) HIP_CHECK(hipEventSynchronize(c->ev_rows_done));
         sc.lap("phase2.emit_d2h");
         const i64 D = c->ref.N;
         // pow(2, -bit) (bit2e, fsearch.py:1086) tabulated once with libm: exact powers of two, 0 past the subnormals
@@ -1460,6 +1473,8 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         c->emit.active = true;
         c->emit.th = std::thread([c, rows, dst, NO, D, expect, q_lo, p2p] {
             try {
+                HIP_CHECK(hipSetDevice(c->device));
+                HIP_CHECK(hipEventSynchronize(c->ev_rows_done));  // the rows have arrived in the pinned buffer
                 parallel_for((i64)NO, [&](i64 i) {
                     const int* v = rows[i].v;
                     so_hit h;
@@ -1717,6 +1732,9 @@ so_ctx* so_create(int device, const so_params* params) {
         HIP_CHECK(hipStreamCreate(&c->st));
         HIP_CHECK(hipEventCreate(&c->ev0));
         HIP_CHECK(hipEventCreate(&c->ev1));
+        HIP_CHECK(hipStreamCreateWithFlags(&c->st_rows, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&c->ev_rows_done, hipEventDisableTiming));
         upload_constants(c);
         g_create_err.clear();
         return c;
@@ -1736,6 +1754,9 @@ void so_destroy(so_ctx* c) {
     if (c->h_qhits) (void)hipHostFree(c->h_qhits);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
+    if (c->ev_rows_done) (void)hipEventDestroy(c->ev_rows_done);
+    if (c->st_rows) (void)hipStreamDestroy(c->st_rows);
     if (c->st) (void)hipStreamDestroy(c->st);
     delete c;
     g_hit_cache.clear();
