@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_bkt_extents(const u32* __restrict__ mat
     bext[b] = mat[(size_t)r * NT + t0[qrel]];   // b == nb: r = R, qrel = 0 -> mat[R * NT] = total
 }
 
-__global__ __launch_bounds__(BG_THREADS, 4) void k_bkt_group(const u32* __restrict__ hits, const u32* __restrict__ bext /*nb + 1*/, u32 nb,
+__global__ __launch_bounds__(BG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bkt_group(const u32* __restrict__ hits, const u32* __restrict__ bext /*nb + 1*/, u32 nb,
                                                             BktLayout L, KeyLayout kl, u64* __restrict__ keys, u32* __restrict__ fallback) {
     __shared__ u32 s_srt[BG_CAP];          // the hits, grouped by subject
     __shared__ u32 s_bin[BG_BINS + 1];     // per subject: count -> scatter cursor (= end of its segment afterwards)

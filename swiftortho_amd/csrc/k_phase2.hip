@@ -44,9 +44,10 @@ template <int CAP, int LO>
 __global__ __launch_bounds__(64) void k_csort_lds(const u32* __restrict__ rec, const u32* __restrict__ qcoff, u32 nq, u32 vmax,
                                                   const u32* __restrict__ qoff, const u32* __restrict__ roff, u32* __restrict__ perm,
                                                   u32* __restrict__ ntask, u32* __restrict__ ntile) {
+    constexpr int LEAFCAP = CAP <= 512 ? 128 : CAP <= 1024 ? 256 : WQS_LEAF;  // leaf list sized with the instance (LDS = residency)
     __shared__ u32 s_x[CAP];
     __shared__ u16 s_L[CAP], s_R[CAP];
-    __shared__ int s_leaf[2 * WQS_LEAF];
+    __shared__ int s_leaf[2 * LEAFCAP];
     const u32 q = blockIdx.x;
     const u32 c0 = qcoff[q];
     const int n = (int)(qcoff[q + 1] - c0);
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(64) void k_csort_lds(const u32* __restrict__ rec, c
         s_x[i] = ((SCORE_CAP - sc) << 12) | (u32)i;
     }
     __syncthreads();
-    wave_ref_qsort(s_x, n, [](u32 v) { return (int)(v >> 12); }, (int)vmax, s_L, s_R, s_leaf);
+    wave_ref_qsort<LEAFCAP>(s_x, n, [](u32 v) { return (int)(v >> 12); }, (int)vmax, s_L, s_R, s_leaf);
     const int m = n < (int)vmax ? n : (int)vmax;
     const u32 lq = qoff[q + 1] - qoff[q];
     u32 tiles = 0;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(64) void k_final_select_lds(const u32* __restrict__
                                                          u32* __restrict__ nout) {
     __shared__ u32 s_x[FSEL_CAP], s_v[FSEL_CAP];
     __shared__ u16 s_L[FSEL_CAP], s_R[FSEL_CAP];
-    __shared__ int s_leaf[2 * WQS_LEAF];
+    __shared__ int s_leaf[2 * 256];
     const u32 q = blockIdx.x;
     const u32 t0 = toff[q];
     const int n = (int)st_state[5 * (size_t)q + 3];
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(64) void k_final_select_lds(const u32* __restrict__
     // a bit score outside 20 bits cannot be packed: such a list (none exists with integer alignment scores) is left to the serial kernel
     if (!__all(fits)) return;
     __syncthreads();
-    wave_ref_qsort(s_x, n, [](u32 w) { return (int)(w >> 12); }, 0x7fffffff, s_L, s_R, s_leaf);
+    wave_ref_qsort<256>(s_x, n, [](u32 w) { return (int)(w >> 12); }, 0x7fffffff, s_L, s_R, s_leaf);
     for (int i = threadIdx.x; i < n; i += 64) sel[t0 + i] = s_v[s_x[i] & 0xFFFu];
     const i64 vv = v > 0 ? v : 0;
     if (threadIdx.x == 0) nout[q] = (i64)n < vv ? (u32)n : (u32)vv;

@@ -90,9 +90,10 @@ template <int CAP, int LO>  // serves queries with LO < windows <= CAP
 __global__ __launch_bounds__(64) void k_ksc_order_lds(const u8* __restrict__ q_scls, const u32* __restrict__ qoff, u32 nq, int mink,
                                                       const signed char* __restrict__ b62c, u32* __restrict__ korder) {
     __shared__ signed char s_self[SCLS_N];
+    constexpr int LEAFCAP = CAP <= 512 ? 128 : CAP <= 1024 ? 256 : WQS_LEAF;  // leaf list sized with the instance (LDS = residency)
     __shared__ u32 s_x[CAP];
     __shared__ u16 s_L[CAP], s_R[CAP];
-    __shared__ int s_leaf[2 * WQS_LEAF];
+    __shared__ int s_leaf[2 * LEAFCAP];
     if (threadIdx.x < SCLS_N) s_self[threadIdx.x] = b62c[threadIdx.x * SCLS_N + threadIdx.x];
     __syncthreads();
     const u32 q = blockIdx.x;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(64) void k_ksc_order_lds(const u8* __restrict__ q_s
         s_x[i] = ((u32)(KSC_BIAS - sc) << 12) | (u32)i;
     }
     __syncthreads();
-    wave_ref_qsort(s_x, nk, [](u32 v) { return (int)(v >> 12); }, 0x7fffffff, s_L, s_R, s_leaf);
+    wave_ref_qsort<LEAFCAP>(s_x, nk, [](u32 v) { return (int)(v >> 12); }, 0x7fffffff, s_L, s_R, s_leaf);
     for (int i = threadIdx.x; i < nk; i += 64) korder[base + i] = s_x[i] & 0xFFFu;
 }
 

@@ -90,7 +90,9 @@ __device__ inline void ref_qsort_dev(T* x, int n, KeyFn key, int limit = 0x7ffff
 
 // T = element type (u32 words in LDS, or u64 words in global memory for segments that do not fit),
 // PT = position type of the misfit lists (u16 / u32).
-template <class T, class PT, class KeyFn>
+// LEAFCAP = capacity of the leaf list (2 ints each); when it fills up, further ranges are sorted on the spot by one lane (slow, exact):
+// the small instances of the callers trade that rare case for LDS (a 300-element list produces 20-40 leaves).
+template <int LEAFCAP = WQS_LEAF, class T, class PT, class KeyFn>
 __device__ inline void wave_ref_qsort(T* x, int n, KeyFn key, int limit, PT* Lpos, PT* Rpos, int* leaf) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -102,8 +104,8 @@ __device__ inline void wave_ref_qsort(T* x, int n, KeyFn key, int limit, PT* Lpo
         const int r = stk[--sp], l = stk[--sp];
         if (r <= l || l >= limit) continue;
         const int gap = r - l + 1;
-        if (gap < WQS_PAR || nleaf >= WQS_LEAF - 1) {
-            if (gap < WQS_PAR && nleaf < WQS_LEAF) {
+        if (gap < WQS_PAR || nleaf >= LEAFCAP - 1) {
+            if (gap < WQS_PAR && nleaf < LEAFCAP) {
                 if (lane == 0) leaf[2 * nleaf] = l, leaf[2 * nleaf + 1] = r;
                 ++nleaf;
             } else {  // leaf list full (cannot happen for n <= 4096): sort it right here on one lane
