@@ -124,19 +124,39 @@ __device__ inline void wave_ref_qsort(T* x, int n, KeyFn key, int limit, PT* Lpo
         __syncthreads();
         const auto p = key(x[l]);
         int cntL = 0, cntR = 0;
-        for (int base = l + 1; base <= r; base += 64) {
-            const int t = base + lane;
-            const bool f = (t <= r) && !(key(x[t <= r ? t : r]) < p);
-            const unsigned long long bal = __ballot(f);
-            if (f) Lpos[cntL + __popcll(bal & lt)] = (PT)(t - l);
-            cntL += __popcll(bal);
+        // the two scans read four 64-element steps ahead of the ballots that consume them (a load -> ballot -> store chain per step
+        // leaves the wave waiting on memory once per step: the global-memory instance spent ~1 us per 64 elements)
+        for (int base = l + 1; base <= r; base += 4 * 64) {
+            T v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = base + u * 64 + lane;
+                v[u] = x[t <= r ? t : r];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = base + u * 64 + lane;
+                const bool f = (t <= r) && !(key(v[u]) < p);
+                const unsigned long long bal = __ballot(f);
+                if (f) Lpos[cntL + __popcll(bal & lt)] = (PT)(t - l);
+                cntL += __popcll(bal);
+            }
         }
-        for (int base = r; base >= l; base -= 64) {
-            const int t = base - lane;
-            const bool f = (t >= l) && !(key(x[t >= l ? t : l]) > p);
-            const unsigned long long bal = __ballot(f);
-            if (f) Rpos[cntR + __popcll(bal & lt)] = (PT)(t - l);
-            cntR += __popcll(bal);
+        for (int base = r; base >= l; base -= 4 * 64) {
+            T v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = base - u * 64 - lane;
+                v[u] = x[t >= l ? t : l];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = base - u * 64 - lane;
+                const bool f = (t >= l) && !(key(v[u]) > p);
+                const unsigned long long bal = __ballot(f);
+                if (f) Rpos[cntR + __popcll(bal & lt)] = (PT)(t - l);
+                cntR += __popcll(bal);
+            }
         }
         __syncthreads();
         const int K = cntL < cntR ? cntL : cntR;
