@@ -119,7 +119,7 @@ int64_t so_ref_len(const so_ctx *ctx, int64_t sidx); /* residues of reference se
  * so_search() = so_load_queries() + so_build_index() (if needed) + so_search_loaded(). */
 int so_search_loaded(so_ctx *ctx, int64_t q_lo, int64_t q_hi, so_hit **hits, int64_t *n_hits);
 int so_search(so_ctx *ctx, const char *qry_fasta_path, int64_t q_lo, int64_t q_hi, so_hit **hits, int64_t *n_hits);
-/* Releases a result array.  The library may keep ONE released array (the largest, > 1 MiB) for the next search of this process
+/* Releases a result array.  The library may keep ONE released array (the largest between 1 MiB and 2 GiB) for the next search of this process
  * instead of returning its pages to the system -- a 100k-protein result is 130 MB and unmapping + refaulting it costs ~17 ms per
  * search; so_destroy() drops it, SOHIT_HIT_CACHE=0 disables it. */
 void so_free_hits(so_hit *hits);

@@ -1176,7 +1176,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
 
 // One released result array is kept for the next search (process-wide, SOHIT_HIT_CACHE=0 turns it off): a config-3 result is 130 MB,
 // and handing that back to the kernel page by page and faulting it in again costs more than 17 ms per search -- a fifth of the step.
-// Only arrays above 1 MiB are kept; the larger of (cached, released) survives, so_destroy() drops it.
+// Only arrays between 1 MiB and 2 GiB are kept; the larger of (cached, released) survives, so_destroy() drops it.
 struct HitCache {
     std::mutex mu;
     so_hit* p = nullptr;
@@ -1195,7 +1195,7 @@ struct HitCache {
     void give(so_hit* q) {
         if (!q) return;
         const size_t b = malloc_usable_size(q);
-        if (!enabled() || b < ((size_t)1 << 20)) {
+        if (!enabled() || b < ((size_t)1 << 20) || b > ((size_t)2 << 30)) {  // a 1 M-protein result (24 GB) is not worth holding on to
             free(q);
             return;
         }
