@@ -498,6 +498,24 @@ def test_gather_records_over_rccl(tmp_path):
     assert "RCCL_GATHER_OK 1.5" in p.stdout
 
 
+def test_bench_plain_command_two_ranks():
+    """The driver's command shape `python bench.py --gpus N ...` with no torch.distributed environment: bench.py starts its
+    own ranks.  Two ranks over gloo sharing GPU 0 (the box has one GPU: functional check of the N > 1 flow, not a timing):
+    one JSON line with n_gpus 2 and the same row count as the N = 1 line of the same workload."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(SOHIT_BENCH_BACKEND="gloo", SOHIT_BENCH_ONE_GPU="1")
+    outs = {}
+    for n in (1, 2):
+        p = _cli(["bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "0", "--workload", "c2", "--no-cpu-baseline"], env=env)
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout.decode()[-2000:]
+        outs[n] = json.loads(lines[0])
+        assert outs[n]["n_gpus"] == n and outs[n]["value"] > 0 and outs[n]["scaling"] == "strong"
+    assert outs[1]["config"]["rows"] == outs[2]["config"]["rows"] > 10000
+    assert outs[1]["config"]["workload"] == outs[2]["config"]["workload"]
+
+
 @pytest.mark.parametrize("poison", ["0xFF", "0x5A"])
 def test_results_do_not_depend_on_stale_device_memory(poison):
     """Every fresh device allocation is filled with a byte pattern (SOHIT_POISON) and a short randomised differential
@@ -692,6 +710,37 @@ def test_config4_shape_sampled(fs, oracle, tmp_path):
     p = str(tmp_path / "c4.fsa")
     open(p, "wb").write(fa)
     _sampled_oracle(s, oracle, p, kw, [(123450, 123458), (199990, 199998)])
+    s.close()
+
+
+def test_config4_full_size(fs, oracle, tmp_path):
+    """BASELINE config 4 at its own size: 1 M proteins x 300 aa (300 M aa), seed 111111, twenty resident 50k chunks.
+    A 512-query range against all 1 M references: size-independent properties, idempotence, sub-range invariance; two
+    8-query ranges (first and last taxa of the set) against `oracle/sohit_cpu -l/-u` over the whole reference: identical
+    bytes.  (The whole 1 M x 1 M job is 2e12 seed hits -- two minutes of GPU, weeks of CPU: tools/diag/run_config.py.)"""
+    from swiftortho_amd import synthprot
+    fa = synthprot.synthprot(1000000, 300)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=120000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    s = fs.Searcher(**kw)
+    s.load_ref_bytes(fa)
+    s.load_queries_bytes(fa)
+    s.reset_counters()
+    h = s.search(500000, 500512)
+    c = s.counters()
+    assert c["n_chunks"] == 20 and c["ref_seqs"] == 1000000
+    assert c["seed_hits"] > 512 * 20 * 50000   # > 5e4 index entries visited per query and chunk
+    g = h.array()
+    assert len(g) > 50000
+    _properties(g)
+    assert len(np.unique(g["qidx"][g["qidx"] == g["sidx"]])) >= 0.99 * 512
+    h2 = s.search(500100, 500164)   # per-query results do not depend on the query partition
+    assert h2.array().tobytes() == g[(g["qidx"] >= 500100) & (g["qidx"] < 500164)].tobytes()
+    h2.close()
+    h.close()
+    p = str(tmp_path / "c4.fsa")
+    open(p, "wb").write(fa)
+    del fa
+    _sampled_oracle(s, oracle, p, kw, [(1234, 1242), (999990, 999998)])
     s.close()
 
 

@@ -142,3 +142,15 @@ def test_two_rank_gloo_gather(tmp_path, empty1):
         assert line[3] == "True" and int(line[1]) < 100
     else:
         assert line[1:] == ["100", str(sum(range(100))), "True"]
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed environment starts the two ranks itself (child torchrun, before
+    anything touches the GPU) and relays the exit code.  Here there is no GPU, so both ranks must fail loudly -- "needs a GPU:
+    libsohit has no CPU path" -- and the launcher must report failure; the same command on the GPU box is in test_gpu_parity.py."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "c2",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode != 0
+    assert p.stderr.count("bench.py needs a GPU") >= 2, p.stderr[-3000:]
+    assert '"metric"' not in p.stdout
