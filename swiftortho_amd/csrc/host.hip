@@ -922,7 +922,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     if (compact) {
         if (ch.d_ba != kl.ba || ch.d_bd != kl.bd) {
             ch.dk32.ensure((size_t)ch.E + 4);
-            launch_encode_delta32(ch.entries.p, ch.E, kl.ba, kl.bd, ch.maxslen, ch.dk32.p, c->st);
+            launch_encode_delta32(ch.entries.p, ch.E, kl.ba, kl.bd, ch.maxslen, c->ref.d_off.p + ch.seq_lo, ch.dk32.p, c->st);
             ch.d_ba = kl.ba, ch.d_bd = kl.bd;
         }
     } else if (ch.d_sh_subj != kl.sh_subj || ch.d_sh_diag != kl.sh_diag) {

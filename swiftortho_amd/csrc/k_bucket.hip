@@ -82,36 +82,65 @@ __global__ __launch_bounds__(256) void k_bkt_tiledesc(const u32* __restrict__ qs
     td[t] = make_uint4(q, first, k0, a);
 }
 
-// One hit: index addend c (k_encode_delta32 with ba == 0: subject << bd | (maxslen - pos), all-ones diagonal field for an
-// entry at offset 0 of its sequence) + the seed's query position -> subject range and 32-bit word.  Returns false for a
-// dropped hit (offset 0 with no non-empty sequence before it in the chunk: the reference resolves it to index -1,
-// fsearch.py:2685-2688).
-__device__ __forceinline__ bool bk_hit(u32 c, u32 qpos, const BktLayout& L, const u32* __restrict__ roff, u32& range, u32& word) {
+// One hit: index addend c (k_encode_delta32 with ba == 0: subject << bd | (maxslen - pos); entries at offset 0 of their sequence
+// come resolved to the previous non-empty sequence, or with an all-ones diagonal field when the reference drops them,
+// fsearch.py:2685-2688) + the seed's query position -> subject range and 32-bit word.  Branch-free: the kernels' scalar unit,
+// shared by the four SIMDs of a CU, was saturated by the exec-mask bookkeeping of a per-hit slow path (round 2: 1100 scalar
+// against 800 vector instructions per tile).
+__device__ __forceinline__ bool bk_hit(u32 c, u32 qpos, const BktLayout& L, u32& range, u32& word) {
     const u32 dmask = (1u << L.bd) - 1u;
-    u32 j = c >> L.bd, dp = c & dmask;
-    if (dp == dmask) {  // rare: strict `soas[j] < x` puts it at the end of the previous non-empty sequence
-        while (j > 0 && roff[j] == roff[j - 1]) --j;
-        if (j == 0) return false;
-        j -= 1;
-        dp = L.maxslen - (roff[j + 1] - roff[j]);
-    }
+    const u32 j = c >> L.bd, dp = c & dmask;
     range = j >> L.wb;
     word = ((j & ((1u << L.wb) - 1u)) << (L.bd + L.bp)) | ((qpos + dp) << L.bp) | qpos;
-    return true;
+    return dp != dmask;
 }
+
+// Per-wave LDS histogram of the tile's hits per range, REPLICATED: lane l counts in copy l mod ncopy.  Hits of one seed arrive
+// ordered by subject, so neighbouring lanes mostly hit the SAME range: one counter per range would serialise them on one
+// address (SQ_LDS_ADDR_CONFLICT 84 % of the LDS cycles), and copies a power-of-two stride apart would still share the bank.
+// The copies therefore sit `cstride` = Rp + 32 / ncopy words apart: the ncopy counters of one range fall into ncopy different
+// banks spread evenly over the 32.
+#define BK_HIST_WORDS(staged) ((staged) ? 640 : 560)   // 560 + the 896 phase-A words: seven 4-wave workgroups per CU
+struct BkHist {
+    u32 ncopy, cstride;   // copies (power of two), words between two copies
+    u32 gbase;            // staged scatter: where the per-run global offsets live inside the histogram array
+};
+static BkHist bk_hist_layout(u32 R, bool staged, bool skewed) {
+    u32 Rp = 1;
+    while (Rp < R) Rp <<= 1;
+    BkHist h;
+    if (!skewed) {   // round-2 layout (SOHIT_BK_SKEW=0): copies Rp words apart
+        h.ncopy = std::max(1u, std::min(8u, 512u / Rp));
+        h.cstride = Rp;
+    } else {
+        const u32 room = BK_HIST_WORDS(staged) - (staged ? Rp : 0u);
+        h.ncopy = 8;
+        while (h.ncopy > 1 && h.ncopy * (Rp + 32u / h.ncopy) > room) h.ncopy >>= 1;
+        h.cstride = h.ncopy > 1 ? Rp + 32u / h.ncopy : Rp;
+    }
+    h.gbase = h.ncopy * h.cstride;
+    return h;
+}
+#define BK_STAGE_RMAX 128   // the staged scatter keeps one global offset per non-empty run of the tile in LDS
 
 // SCATTER = false: mat[range * NT + tile] = hits of the tile in the range (mat zeroed by the host);
 // SCATTER = true : mat holds the exclusive scan of those counts = where the tile's hits of each range go in `out`.
-template <bool SCATTER>
-__global__ __launch_bounds__(64 * BK_WAVES, 4) void k_bkt_pass(const uint4* __restrict__ td, const u32* __restrict__ qseg, u32 NT,
+// STAGED (scatter only, R <= BK_STAGE_RMAX): the tile's words are first put in LDS ordered by range -- the per-range LDS
+// counters give every hit its place -- and then written out position by position: one store instruction covers 64
+// consecutive staged words = two to four runs of consecutive addresses, instead of 64 lanes landing in ~R different lines
+// (the texture-address path takes a cycle per distinct line per instruction: the round-2 kernel spent more time issuing
+// its sixteen scattered stores than reading the index).
+template <bool SCATTER, bool STAGED>
+__global__ __launch_bounds__(64 * BK_WAVES, 6) void k_bkt_pass(const uint4* __restrict__ td, const u32* __restrict__ qseg, u32 NT,
                                                               const u32* __restrict__ cs_hoff, const u32* __restrict__ cs_base,
                                                               const u64* __restrict__ cs_kbase, const u32* __restrict__ dk32,
-                                                              const u32* __restrict__ roff, BktLayout L, u32* __restrict__ mat,
+                                                              BktLayout L, BkHist HL, u32* __restrict__ mat,
                                                               u32* __restrict__ out) {
-    __shared__ u16 s_owner_all[BK_WAVES][BK_HITS];
-    __shared__ u32 s_base_all[BK_WAVES][BK_SEEDS];
-    __shared__ u16 s_qpos_all[BK_WAVES][BK_SEEDS];
-    __shared__ u32 s_hist_all[BK_WAVES][BKT_RMAX];
+    // phase A: owner marks (u16 x BK_HITS) | seed bases (u32 x BK_SEEDS) | seed qpos (u16 x BK_SEEDS); phase B (staged): the words
+    constexpr u32 MEMW = STAGED ? BK_HITS : BK_HITS / 2 + BK_SEEDS + BK_SEEDS / 2;
+    __shared__ u32 s_mem_all[BK_WAVES][MEMW];
+    __shared__ u32 s_hist_all[BK_WAVES][BK_HIST_WORDS(STAGED)];
+    static_assert(BK_HITS / 2 + BK_SEEDS + BK_SEEDS / 2 <= BK_HITS, "phase A arrays must fit the staging area");
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so XCD x takes the x-th contiguous eighth of the
     // tiles: the tiles of one query, and the output lines they fill, stay in one L2.
@@ -119,9 +148,10 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void k_bkt_pass(const uint4* __re
     const u32 lb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     const u32 t = __builtin_amdgcn_readfirstlane(lb * BK_WAVES + w);
     if (t >= NT) return;
-    u16* s_owner = s_owner_all[w];
-    u32* s_base = s_base_all[w];
-    u16* s_qpos = s_qpos_all[w];
+    u16* s_owner = reinterpret_cast<u16*>(s_mem_all[w]);
+    u32* s_base = s_mem_all[w] + BK_HITS / 2;
+    u16* s_qpos = reinterpret_cast<u16*>(s_mem_all[w] + BK_HITS / 2 + BK_SEEDS);
+    u32* s_stage = s_mem_all[w];
     u32* s_hist = s_hist_all[w];
     const uint4 d = td[t];
     const u32 q = __builtin_amdgcn_readfirstlane(d.x), lo = __builtin_amdgcn_readfirstlane(d.y);
@@ -129,16 +159,11 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void k_bkt_pass(const uint4* __re
     const u32 len = min((u32)BK_HITS, __builtin_amdgcn_readfirstlane(qseg[q + 1]) - lo);
     const u32 ns = k1 - k0 + 1;
     const u32 pmask = (1u << L.bp) - 1u;
-    // The per-range counters are LDS fetch-adds; with a dozen ranges, 64 lanes pile onto a dozen addresses and the LDS serialises
-    // them (SQ_LDS_ADDR_CONFLICT: 84 % of the LDS cycles).  So the histogram is replicated: lane l uses copy l mod ncopy, as many
-    // copies as fit the BKT_RMAX words (8 for up to 64 ranges); the copies are summed / prefixed when the tile is flushed.
-    int cshift = 0;
-    while ((1u << cshift) < L.R) ++cshift;
-    const u32 ncopy = min(8u, (u32)BKT_RMAX >> cshift);
-    const u32 cbase = (lane & (ncopy - 1u)) << cshift;
+    const u32 ncopy = HL.ncopy, cstride = HL.cstride;
+    const u32 cbase = (lane & (ncopy - 1u)) * cstride;
 #pragma unroll
     for (u32 i = 0; i < BK_ITERS / 4; ++i) reinterpret_cast<uint2*>(s_owner)[i * 64 + lane] = make_uint2(0, 0);
-    for (u32 r = lane; r < (ncopy << cshift); r += 64) s_hist[r] = 0;
+    for (u32 r = lane; r < HL.gbase; r += 64) s_hist[r] = 0;
     bk_wave_sync();
     for (u32 i = lane; i < ns; i += 64) {
         if (i < BK_SEEDS) {
@@ -151,52 +176,121 @@ __global__ __launch_bounds__(64 * BK_WAVES, 4) void k_bkt_pass(const uint4* __re
         }
     }
     bk_wave_sync();
-    u32 word[BK_ITERS], slot[BK_ITERS];  // slot: range | rank << 10; ~0u = no hit
+    u32 word[BK_ITERS], slot[BK_ITERS];  // slot: histogram word (copy, range) | rank << 10; ~0u = no hit
     u32 carry = 0;
     // all 16 index reads of the tile are issued before the first one is used (a dependent load -> LDS fetch-add chain per
-    // step would leave the wave waiting on L2 sixteen times)
+    // step would leave the wave waiting on L2 sixteen times).  Wave-uniform choice of where the seeds' bases come from: LDS
+    // when the tile's seeds fit the stage (a per-lane choice between an LDS and a global address compiles to flat loads).
+    if (ns <= BK_SEEDS) {
 #pragma unroll
-    for (int it = 0; it < BK_ITERS; ++it) {
-        const u32 hl = it * 64 + lane;
-        const u32 inc = bk_scan_max((u32)s_owner[hl]);
-        const u32 a = max(inc, carry);
-        carry = max(carry, (u32)__builtin_amdgcn_readlane((int)inc, 63));
-        const u32 base = (a < BK_SEEDS) ? s_base[a] : cs_base[k0 + a];
-        slot[it] = (a < BK_SEEDS) ? (u32)s_qpos[a] : ((u32)(cs_kbase[k0 + a] >> L.sh_qpos) & pmask);  // the seed's qpos, for now
-        word[it] = dk32[base + lo + min(hl, len - 1u)];                                            // the index addend, for now
+        for (int it = 0; it < BK_ITERS; ++it) {
+            const u32 hl = it * 64 + lane;
+            const u32 inc = bk_scan_max((u32)s_owner[hl]);
+            const u32 a = max(inc, carry);
+            carry = max(carry, (u32)__builtin_amdgcn_readlane((int)inc, 63));
+            slot[it] = (u32)s_qpos[a];                                    // the seed's qpos, for now
+            word[it] = dk32[s_base[a] + lo + min(hl, len - 1u)];          // the index addend, for now
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < BK_ITERS; ++it) {
+            const u32 hl = it * 64 + lane;
+            const u32 inc = bk_scan_max((u32)s_owner[hl]);
+            const u32 a = max(inc, carry);
+            carry = max(carry, (u32)__builtin_amdgcn_readlane((int)inc, 63));
+            slot[it] = (u32)(cs_kbase[k0 + a] >> L.sh_qpos) & pmask;
+            word[it] = dk32[cs_base[k0 + a] + lo + min(hl, len - 1u)];
+        }
     }
 #pragma unroll
     for (int it = 0; it < BK_ITERS; ++it) {
         const u32 hl = it * 64 + lane;
-        const u32 c = word[it], qpos = slot[it];
-        slot[it] = 0xFFFFFFFFu;
         u32 r, wd;
-        if (hl < len && bk_hit(c, qpos, L, roff, r, wd)) {
-            word[it] = wd;
-            slot[it] = (cbase | r) | (atomicAdd(&s_hist[cbase | r], 1u) << 10);  // LDS fetch-add: a unique slot inside (tile, range, copy)
-        }
+        const bool ok = bk_hit(word[it], slot[it], L, r, wd) && hl < len;
+        word[it] = wd;
+        slot[it] = 0xFFFFFFFFu;
+        if (ok) slot[it] = (cbase + r) | (atomicAdd(&s_hist[cbase + r], 1u) << 10);  // LDS fetch-add: a unique slot inside (tile, range, copy)
     }
     bk_wave_sync();
     if (!SCATTER) {
         for (u32 r = lane; r < L.R; r += 64) {
             u32 n = 0;
-            for (u32 cpy = 0; cpy < ncopy; ++cpy) n += s_hist[(cpy << cshift) | r];
+            for (u32 cpy = 0; cpy < ncopy; ++cpy) n += s_hist[cpy * cstride + r];
             if (n) mat[(size_t)r * NT + t] = n;
         }
         return;
     }
-    for (u32 r = lane; r < L.R; r += 64) {  // counts -> global start of every (range, copy) share
-        u32 run = mat[(size_t)r * NT + t];
-        for (u32 cpy = 0; cpy < ncopy; ++cpy) {
-            const u32 n = s_hist[(cpy << cshift) | r];
-            s_hist[(cpy << cshift) | r] = run;
-            run += n;
+    if (!STAGED) {
+        for (u32 r = lane; r < L.R; r += 64) {  // counts -> global start of every (range, copy) share
+            u32 run = mat[(size_t)r * NT + t];
+            for (u32 cpy = 0; cpy < ncopy; ++cpy) {
+                const u32 n = s_hist[cpy * cstride + r];
+                s_hist[cpy * cstride + r] = run;
+                run += n;
+            }
         }
+        bk_wave_sync();
+#pragma unroll
+        for (int it = 0; it < BK_ITERS; ++it)
+            if (slot[it] != 0xFFFFFFFFu) out[s_hist[slot[it] & 1023u] + (slot[it] >> 10)] = word[it];
+        return;
     }
-    bk_wave_sync();
+    // ---- staged scatter -------------------------------------------------------------------------------------------------
+    // counts -> place of every (range, copy) share inside the tile (ranges ascending), and for every non-empty run its
+    // global start minus its local start, listed in run order
+    u32 total = 0, nrun = 0;
+    u32 myhead[BK_STAGE_RMAX / 64];   // local start of this lane's range in round k (~0u: empty)
+#pragma unroll
+    for (u32 k = 0; k < BK_STAGE_RMAX / 64; ++k) {
+        const u32 r = k * 64 + lane;
+        myhead[k] = 0xFFFFFFFFu;
+        if (k * 64 >= L.R) continue;   // wave-uniform
+        u32 n = 0;
+        if (r < L.R)
+            for (u32 cpy = 0; cpy < ncopy; ++cpy) n += s_hist[cpy * cstride + r];
+        u32 inc = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 x = __shfl_up(inc, o);
+            if (lane >= (u32)o) inc += x;
+        }
+        const unsigned long long nz = __ballot(n != 0);
+        u32 run = total + inc - n;
+        if (n) {
+            const u32 j = nrun + __builtin_amdgcn_mbcnt_hi((u32)(nz >> 32), __builtin_amdgcn_mbcnt_lo((u32)nz, 0u));
+            s_hist[HL.gbase + j] = mat[(size_t)r * NT + t] - run;
+            myhead[k] = run;
+        }
+        if (r < L.R)
+            for (u32 cpy = 0; cpy < ncopy; ++cpy) {
+                const u32 c = s_hist[cpy * cstride + r];
+                s_hist[cpy * cstride + r] = run;
+                run += c;
+            }
+        total += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        nrun += (u32)__popcll(nz);
+    }
+    bk_wave_sync();   // (also: phase A's arrays are dead, the staging area may be written)
 #pragma unroll
     for (int it = 0; it < BK_ITERS; ++it)
-        if (slot[it] != 0xFFFFFFFFu) out[s_hist[slot[it] & 1023u] + (slot[it] >> 10)] = word[it];
+        if (slot[it] != 0xFFFFFFFFu) s_stage[s_hist[slot[it] & 1023u] + (slot[it] >> 10)] = word[it];
+    bk_wave_sync();
+    // words are < 2^31 (wb + bd + bp <= 31): bit 31 marks the first word of every run
+#pragma unroll
+    for (u32 k = 0; k < BK_STAGE_RMAX / 64; ++k)
+        if (myhead[k] != 0xFFFFFFFFu) s_stage[myhead[k]] |= 0x80000000u;
+    bk_wave_sync();
+    u32 jc = 0;   // runs that started before this step
+#pragma unroll
+    for (int it = 0; it < BK_ITERS; ++it) {
+        const u32 i = it * 64 + lane;
+        if ((u32)it * 64u >= total) break;   // wave-uniform
+        const u32 v = i < total ? s_stage[i] : 0u;
+        const unsigned long long hb = __ballot((v >> 31) != 0);
+        const u32 j = jc + __builtin_amdgcn_mbcnt_hi((u32)(hb >> 32), __builtin_amdgcn_mbcnt_lo((u32)hb, 0u)) + (v >> 31) - 1u;
+        if (i < total) out[s_hist[HL.gbase + j] + i] = v & 0x7FFFFFFFu;
+        jc += (u32)__popcll(hb);
+    }
 }
 
 // ================================================================================================================
@@ -537,8 +631,14 @@ void launch_bkt_pass(bool scatter, const void* td, const u32* qseg, u32 NT, cons
                      const u32* dk32, const u32* roff, const BktLayout& L, u32* mat, u32* out, hipStream_t st) {
     if (!NT) return;
     const dim3 g(((NT + BK_WAVES - 1) / BK_WAVES + 7u) & ~7u), bl(64 * BK_WAVES);  // multiple of 8: the XCD-aware tile order
-    if (scatter) hipLaunchKernelGGL((k_bkt_pass<true>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, roff, L, mat, out);
-    else hipLaunchKernelGGL((k_bkt_pass<false>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, roff, L, mat, out);
+    // SOHIT_BK_STAGED=0: direct scatter (round 2); SOHIT_BK_SKEW=0: histogram copies a power of two apart (round 2)
+    static const bool staged_on = !(getenv("SOHIT_BK_STAGED") && atoi(getenv("SOHIT_BK_STAGED")) == 0);
+    static const bool skewed = !(getenv("SOHIT_BK_SKEW") && atoi(getenv("SOHIT_BK_SKEW")) == 0);
+    const bool staged = scatter && staged_on && L.R <= BK_STAGE_RMAX;
+    const BkHist HL = bk_hist_layout(L.R, staged, skewed);
+    if (!scatter) hipLaunchKernelGGL((k_bkt_pass<false, false>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
+    else if (staged) hipLaunchKernelGGL((k_bkt_pass<true, true>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
+    else hipLaunchKernelGGL((k_bkt_pass<true, false>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
 }
 
 void launch_bkt_extents(const u32* mat, const u32* t0, u32 NT, u32 nqp, u32 nb, u32* bext, hipStream_t st) {

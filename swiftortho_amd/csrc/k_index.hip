@@ -246,21 +246,36 @@ __global__ __launch_bounds__(256) void k_encode_delta(const u64* __restrict__ en
 // Compact form, used whenever subject, diagonal and tag fields fit 32 bits together (bs + bd + ba <= 32: every
 // protein-sized input): c = (subject << (bd + ba)) | ((maxslen - pos) << ba) | tag, i.e. the three fields in
 // key order with the (qpos, as) gap squeezed out, so that   D = ((u64)(c >> ba) << sh_diag) + (c & amask)
-// and the lookup kernel reads 4 bytes per visited hit instead of 8.  Offset-0 entries carry an all-ones
-// diagonal field (never a real value: maxslen - pos <= maxslen < 2^bd - 1).
+// and the lookup kernel reads 4 bytes per visited hit instead of 8.
+// An entry at offset 0 of its sequence is resolved HERE, once per index entry instead of once per visiting hit: the
+// reference's strict `soas[j] < x` (fsearch.py:2685-2688) attributes it to the previous non-empty sequence of the chunk at
+// sst = that sequence's length, so the addend carries that subject and (maxslen - its length).  When there is no such
+// sequence the reference resolves index -1 and the hit never scores: those entries keep an all-ones diagonal field (never a
+// real value: maxslen - pos <= maxslen < 2^bd - 1), which the lookup kernels read as "drop".
 __global__ __launch_bounds__(256) void k_encode_delta32(const u64* __restrict__ entries, u32 E, int ba, int bd, u32 maxslen,
-                                                        u32* __restrict__ dk32) {
+                                                        const u32* __restrict__ roff /*chunk-local offsets*/, u32* __restrict__ dk32) {
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i >= E) return;
     const u64 e = entries[i];
-    const u32 j = (u32)(e >> 32), pos = (u32)e & 0xFFFFFFu, tag = (u32)(e >> 24) & 0xFFu;
+    u32 j = (u32)(e >> 32);
+    const u32 pos = (u32)e & 0xFFFFFFu, tag = (u32)(e >> 24) & 0xFFu;
     const u32 dmask = (1u << bd) - 1u;
-    dk32[i] = (j << (bd + ba)) | ((pos == 0 ? dmask : maxslen - pos) << ba) | tag;
+    u32 dp = maxslen - pos;
+    if (pos == 0) {
+        while (j > 0 && roff[j] == roff[j - 1]) --j;
+        if (j == 0) {
+            j = (u32)(e >> 32), dp = dmask;
+        } else {
+            j -= 1;
+            dp = maxslen - (roff[j + 1] - roff[j]);
+        }
+    }
+    dk32[i] = (j << (bd + ba)) | (dp << ba) | tag;
 }
 
-void launch_encode_delta32(const u64* entries, u32 E, int ba, int bd, u32 maxslen, u32* dk32, hipStream_t st) {
+void launch_encode_delta32(const u64* entries, u32 E, int ba, int bd, u32 maxslen, const u32* roff, u32* dk32, hipStream_t st) {
     if (!E) return;
-    hipLaunchKernelGGL(k_encode_delta32, dim3((E + 255) / 256), dim3(256), 0, st, entries, E, ba, bd, maxslen, dk32);
+    hipLaunchKernelGGL(k_encode_delta32, dim3((E + 255) / 256), dim3(256), 0, st, entries, E, ba, bd, maxslen, roff, dk32);
 }
 
 void launch_encode_delta(const u64* entries, u32 E, int sh_subj, int sh_diag, u32 maxslen, u64* dkeys, hipStream_t st) {

@@ -44,7 +44,7 @@ void sort_pairs_u32_u64(void* temp, size_t temp_bytes, const u32* kin, u32* kout
 size_t sort_pairs_u32_u64_temp_bytes(size_t n, int bits);
 #define INDEX_STATS_BLOCKS 2048
 void launch_index_stats(const u32* counts, u32 NC, u64* stats_buf /*4 + 4 * INDEX_STATS_BLOCKS*/, hipStream_t st);
-void launch_encode_delta32(const u64* entries, u32 E, int ba, int bd, u32 maxslen, u32* dk32, hipStream_t st);
+void launch_encode_delta32(const u64* entries, u32 E, int ba, int bd, u32 maxslen, const u32* roff /*chunk-local*/, u32* dk32, hipStream_t st);
 void launch_encode_delta(const u64* entries, u32 E, int sh_subj, int sh_diag, u32 maxslen, u64* dkeys, hipStream_t st);
 void launch_index_fixlast(u64* entries, u32 lo, u32 E, hipStream_t st);
 
