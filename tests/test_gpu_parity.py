@@ -498,6 +498,25 @@ def test_gather_records_over_rccl(tmp_path):
     assert "RCCL_GATHER_OK 1.5" in p.stdout
 
 
+def test_collapse_search_expand_chain(oracle, tmp_path):
+    """scripts/run_all_fast.py's search step (run_all_fast.py:109-118): nr_flt -> bin/find_hit.py on the GPU -> nr2full.  The
+    collapsed proteome is the golden made by the REAL nr_flt.py, the search rows equal the oracle's with the flags the wrapper
+    passes, and the expanded file equals the (golden-pinned) expansion of the oracle's rows."""
+    import shutil
+    from swiftortho_amd import nr
+    fas = str(tmp_path / "p.fsa")
+    shutil.copy(os.path.join(GOLD, "nr_dups.fsa"), fas)
+    full = nr.search_collapsed(fas, seed="111111", cpus="1", hits="500")
+    assert open(fas + "_nr.fsa").read() == open(os.path.join(GOLD, "nr_dups.nr.fsa")).read()
+    want_sc = str(tmp_path / "o.sc")
+    oracle.blastp(fas + "_nr.fsa", fas + "_nr.fsa", want_sc, ssd="111111", nr=oracle.AA9, expect=1e-5, v=500, step=1, flt="T", ht=120000000, chk=50000,
+                  max_miss=5e-2)
+    got_nr = open(os.path.join(fas + "_results", "p.fsa_nr.fsa.sc")).read()
+    assert got_nr.count("\n") > 100 and got_nr == open(want_sc).read()
+    assert open(full).read() == "".join(l + "\n" for l in nr.nr2full(open(want_sc)))
+    assert open(full).read().count("\n") > got_nr.count("\n")
+
+
 def test_bench_plain_command_two_ranks():
     """The driver's command shape `python bench.py --gpus N ...` with no torch.distributed environment: bench.py starts its
     own ranks.  Two ranks over gloo sharing GPU 0 (the box has one GPU: functional check of the N > 1 flow, not a timing):

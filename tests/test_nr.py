@@ -1,6 +1,7 @@
-"""Exact-duplicate collapse / expand helpers (swiftortho_amd/nr.py).  nr2full against stdout of the REAL reference script
-(tools/refharness/make_nr_goldens.py); nr_flt (whose reference needs Bio.SeqIO, absent from the image) by hand-written
-cases and the round trip.  CPU only."""
+"""Exact-duplicate collapse / expand helpers (swiftortho_amd/nr.py) against stdout of the REAL reference scripts
+(tools/refharness/make_nr_goldens.py): nr2full.py as it is; nr_flt.py run with a stand-in for its one Biopython call
+(Bio.SeqIO.parse of plain FASTA, where every parser agrees).  Hand-written cases and the round trip on top.  CPU only;
+the collapse -> GPU search -> expand chain is in test_gpu_parity.py."""
 import os
 import subprocess
 import sys
@@ -18,11 +19,24 @@ def test_nr2full_matches_reference_output():
     assert r.returncode == 0 and r.stdout == open(os.path.join(GOLD, "nr_dups.full.sc")).read()
 
 
+def test_nr_flt_matches_reference_output():
+    from swiftortho_amd import nr
+    want = open(os.path.join(GOLD, "nr_dups.nr.fsa")).read()
+    assert want.count(">") < open(os.path.join(GOLD, "nr_dups.fsa")).read().count(">")     # duplicates were merged
+    assert "\n".join(nr.nr_flt(open(os.path.join(GOLD, "nr_dups.fsa")))) + "\n" == want
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "nr_flt.py"), os.path.join(GOLD, "nr_dups.fsa")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == want
+
+
 def test_nr_flt_by_hand():
     from swiftortho_amd import nr
     fa = [">a|1 first protein\n", "MKV\n", "LLA\n", ">b|2\n", "GGG\n", ">c|3 same as a\n", "MKVLLA\n", ">d|4\n", "GGG\n", ">e|5\n", "MKVLLa\n"]
     assert nr.nr_flt(fa) == [">a|1;;;c|3", "MKVLLA", ">b|2;;;d|4", "GGG", ">e|5", "MKVLLa"]   # first-appearance order, ids only, case-sensitive
     assert nr.nr_flt([]) == []
+    # Biopython's documented record rules (not pinned by a run of Biopython): text before the first '>' is ignored, blanks and CR
+    # inside residue lines are dropped, trailing blanks of the title too, a bare '>' has the empty id
+    odd = ["junk\n", ">x|1  two  words \n", "MK V\r\n", "LL\n", ">\n", "MKVLL\n"]
+    assert nr.nr_flt(odd) == [">x|1;;;", "MKVLL"]
 
 
 def test_collapse_search_expand_round_trip():

@@ -2,10 +2,12 @@
 
     python tools/refharness/make_nr_goldens.py
 
-A proteome with exact duplicates is collapsed (swiftortho_amd.nr.nr_flt; the reference's nr_flt.py needs
-Bio.SeqIO, absent here), searched by oracle/sohit_cpu, and the REAL /root/reference/scripts/nr2full.py
-(stdlib only) expands the hits.  Fixtures: tests/golden/nr_dups.fsa (input proteome), nr_dups.nr.sc (collapsed
-search = input of nr2full), nr_dups.full.sc (expected stdout of nr2full).
+A proteome with exact duplicates is collapsed by the REAL /root/reference/scripts/nr_flt.py -- run with
+tools/refharness/biostub on PYTHONPATH, a stand-in for the one Biopython call it makes (Bio.SeqIO.parse of PLAIN FASTA, on
+which every FASTA parser agrees: the golden pins nr_flt.py's own grouping / ordering / joining, not Biopython) --,
+searched by oracle/sohit_cpu, and the REAL /root/reference/scripts/nr2full.py (stdlib only) expands the hits.
+Fixtures: tests/golden/nr_dups.fsa (input proteome), nr_dups.nr.fsa (expected stdout of nr_flt), nr_dups.nr.sc
+(collapsed search = input of nr2full), nr_dups.full.sc (expected stdout of nr2full).
 """
 import os
 import subprocess
@@ -39,8 +41,12 @@ def main():
     fasta = "".join("%s\n%s\n" % allrecs[i] for i in order)
     open(os.path.join(GOLD, "nr_dups.fsa"), "w").write(fasta)
     with tempfile.TemporaryDirectory() as d:
-        nrfa = os.path.join(d, "nr.fsa")
-        open(nrfa, "w").write("\n".join(nr.nr_flt(fasta.splitlines(True))) + "\n")
+        nrfa = os.path.join(GOLD, "nr_dups.nr.fsa")
+        env = dict(os.environ, PYTHONPATH=os.path.join(HERE, "biostub"))
+        r = subprocess.run([sys.executable, os.path.join(REFERENCE, "scripts", "nr_flt.py"), os.path.join(GOLD, "nr_dups.fsa")], stdout=subprocess.PIPE,
+                           check=True, env=env)
+        open(nrfa, "wb").write(r.stdout)
+        assert r.stdout.decode() == "\n".join(nr.nr_flt(fasta.splitlines(True))) + "\n", "counterpart differs from the reference script"
         sc = os.path.join(GOLD, "nr_dups.nr.sc")
         subprocess.run([oracle.EXE, "-p", "blastp", "-i", nrfa, "-d", nrfa, "-o", sc, "-e", "1e-5", "-v", "500", "-j", "1", "-F", "T", "-s", "111111",
                         "-M", "1000003", "-c", "50000"], check=True, stderr=subprocess.DEVNULL)
