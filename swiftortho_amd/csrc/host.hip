@@ -1355,6 +1355,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     const u32 maxwin_q = std::min<u32>(b.maxqlen, LONG_SEQ), maxwin_s = std::min<u32>(c->ref.maxlen, LONG_SEQ);
     const int maxrows = (int)std::min<u32>(std::max(maxwin_q, maxwin_s), std::min(maxwin_q, maxwin_s) + 16);
     const u32 stride = align_trace_stride(maxrows + 1);
+    const bool align_pk = !(getenv("SOHIT_ALIGN_PK") && atoi(getenv("SOHIT_ALIGN_PK")) == 0) && (int)std::min(maxwin_q, maxwin_s) <= align_pk_max_len();
     const size_t budget_words = (size_t)1 << 30;  // 4 GiB of trace scratch
     const u32 slab = (u32)std::max<size_t>(16, std::min<size_t>(std::max<u32>(NT, 1), budget_words / std::max<u32>(stride, 1)));
     b.st_state.ensure(5 * (size_t)nq + 8), b.rcnt.ensure((size_t)nq + 4), b.tcnt.ensure((size_t)nq + 4), b.roff.ensure((size_t)nq + 4);
@@ -1378,8 +1379,13 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             // score-only: the stop rule needs the maximum alone; the reported rows are traced in a second pass below
             const u32* rlist = sort_by_rows(b.ridx.p, NR);
             ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
-            launch_align(b.tasks.p, rlist, NR, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
-                         c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, b.ares.p, false, c->st);
+            // score-only: packed 16-bit kernel (two alignments per register) whenever the longest window's best possible score fits
+            if (align_pk)
+                launch_align_pk(b.tasks.p, rlist, NR, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_scls4.p, c->ref.d_off.p,
+                                c->d_b62c.p, b.ares.p, c->st);
+            else
+                launch_align(b.tasks.p, rlist, NR, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
+                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, b.ares.p, false, c->st);
             pt.stop();
         }
         launch_stop_round(b.tasks.p, b.ares.p, b.qcoff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.toff.p, b.rcnt.p, nq,

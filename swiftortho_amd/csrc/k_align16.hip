@@ -1,0 +1,214 @@
+// k_align16.hip -- score-only banded gapped extension in PACKED 16-bit arithmetic (kswat_st, fsearch.py:1357-1416).
+//
+// Same recurrence, same band and the same 16-lane anti-diagonal mapping as k_align.hip -- lane l of a DPP row owns row
+// i = m - l of iteration m and its two band cells d = 2l, 2l + 1 -- but every 32-bit register carries TWO alignments, one
+// per 16-bit half: a 16-lane row works on tasks (2g, 2g + 1) of the launch list, a wave on eight, and every DP instruction
+// is a `v_pk_*_i16` (or a bitwise / byte-permute op that is half-agnostic).  The early-stop rounds of phase 2 (the bulk of
+// the aligner's work on BASELINE config 3) only need each candidate's maximum, which is what this kernel returns; the rows
+// that end up reported are aligned again by k_align<true> with traces.
+//
+// A cell's value is TAGGED:  w = (score << 2 | tag) + 44,  tag = 3 diagonal, 2 left ('-'), 1 up ('|'), 0 stop ('*').
+//   * one max over the four candidates resolves the score AND the reference's trace priority diag > left > up > stop
+//     (fsearch.py:1404-1411): equal scores differ in the tag;
+//   * the gap cost a cell charges its right / lower neighbour depends on its own trace only (extend -1 iff it is that gap
+//     direction, else open -11): the two outgoing candidates are  w + cI[tag]  and  w + cD[tag]  with 4-entry byte tables
+//     held in a register and indexed by ONE v_perm for both halves;
+//   * the bias 44 = 11 << 2 makes "score -11, tag 0" the integer 0, i.e. what a DPP move with bound_ctrl hands a lane without
+//     a source -- exactly what an out-of-band neighbour contributes (score 0 stepping out with an opened gap) -- and it always
+//     loses against the stop candidate 44.
+// No validity predicates: residues outside a sequence read as a SENTINEL class whose scores are -100 against everything, so
+// a cell outside the matrix never takes its diagonal candidate, cells above / left of the matrix come out as score 0 with a
+// stop trace (the reference's boundary cells: 0 and a non-extending trace, 1379-1389), and whatever cells right of / below the
+// matrix hold is derived from in-matrix cells minus gap costs: it never reaches back into the matrix and never exceeds the
+// in-matrix maximum.  Only the first and last groups of an alignment need the sentinels (their windows are masked); interior
+// groups run on raw windows.
+// Range: (score << 2) + 47 must fit int16: 11 * min(rows, columns) <= 8179; launch_align_pk() is only used when the longest
+// possible window allows it (host.hip), longer inputs take the 32-bit kernel.
+// Per cell pair: 11 packed VALU + 1 DPP move + 2 address permutes + 1 pack of the two looked-up scores = 15, i.e. 7.5 per cell
+// against 13 in k_align<false>.
+#include "common.h"
+#include "kernels.h"
+#include <type_traits>
+
+#define KB 16
+#define PK_SENT_ROW 24          // sentinel row class
+#define PK_SENT_COL4 96         // sentinel column class * 4
+#define PK_TAB (25 * 256)       // bytes: 25 rows x 64 dwords, a 16-bit entry at (row << 8) | (col * 4)
+#define PK_STOP 0x002C002Cu     // score 0, tag 0 (+ 44) in both halves
+#define PK_TAG3 0x00030003u
+#define PK_CI 0xD3FCD5D6u       // low bytes of (candidate for the right neighbour) - w by tag: -42, -43, -4, -45
+#define PK_CD 0xD2D3FCD5u       // low bytes of (candidate for the lower neighbour) - w by tag: -43, -4, -45, -46
+
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 pk_add(u32 a, u32 b) {
+    const pk16 r = __builtin_bit_cast(pk16, a) + __builtin_bit_cast(pk16, b);
+    return __builtin_bit_cast(u32, r);
+}
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) {
+    const pk16 r = __builtin_elementwise_max(__builtin_bit_cast(pk16, a), __builtin_bit_cast(pk16, b));
+    return __builtin_bit_cast(u32, r);
+}
+__device__ __forceinline__ u32 pk_dpp_shr1(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); }
+__device__ __forceinline__ u32 pk_dpp_shl1(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true); }
+
+__device__ __forceinline__ u32 pk_load4u(const u8* p) {
+    u32 w;
+    __builtin_memcpy(&w, p, 4);
+    return w;
+}
+__device__ __forceinline__ u64 pk_load8u(const u8* p) {
+    u64 w;
+    __builtin_memcpy(&w, p, 8);
+    return w;
+}
+
+// bytes [lo, hi) of a 64-bit word set (0 <= lo, hi <= 8; empty when hi <= lo)
+__device__ __forceinline__ u64 pk_bytemask(int lo, int hi) {
+    const u64 a = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1ull);
+    const u64 b = lo >= 8 ? ~0ull : ((1ull << (8 * lo)) - 1ull);
+    return a & ~b;
+}
+
+// One cell pair.  I / D: the candidates the left / upper neighbours published; Wd3: the diagonal neighbour's value with its tag
+// bits forced to 3; S: 4 x substitution score per half.  Publishes w (value), the two outgoing candidates and w | 3.
+__device__ __forceinline__ void pk_cell(u32 I, u32 D, u32 Wd3, u32 S, u32& w, u32& Iout, u32& Dout, u32& W3) {
+    const u32 M = pk_add(Wd3, S);
+    w = pk_max(pk_max(I, D), pk_max(M, PK_STOP));
+    u32 sel;   // per half: byte 0 = the tag (picks a byte of the cost table), byte 1 = 0x0d (constant 0xff: the costs are negative)
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(w), "s"(PK_TAG3), "v"(0x0D000D00u));   // (one op; the compiler emits and + or with literals)
+    Iout = pk_add(w, __builtin_amdgcn_perm(0u, PK_CI, sel));
+    Dout = pk_add(w, __builtin_amdgcn_perm(0u, PK_CD, sel));
+    W3 = w | PK_TAG3;
+}
+
+struct PkSide {                 // one of the two alignments of a 16-lane row
+    const u8* rp;               // row classes of the current group's four iterations (this lane)
+    const u8* cp;               // column classes * 4, one column early
+    int nrows, ncols, R;
+    int ridx0, cidx0;           // index (into the sequence) of byte 0 of the two windows at m0 = 8
+    u32 slot;
+    int ncell;
+};
+
+__device__ __forceinline__ void pk_setup(PkSide& s, const AlnTask& tk, u32 slot, int l, const u8* __restrict__ q_scls,
+                                         const u8* __restrict__ q_scls4, const u32* __restrict__ qoff, const u8* __restrict__ r_scls,
+                                         const u8* __restrict__ r_scls4, const u32* __restrict__ roff) {
+    const u32 qb = qoff[tk.q], sb = roff[tk.subj];
+    const int lq = min((int)(qoff[tk.q + 1] - qb), (int)tk.qe), ls = min((int)(roff[tk.subj + 1] - sb), (int)tk.se);
+    const int qi = min((int)tk.qi, lq), qj = min((int)tk.qj, ls);
+    const int la = lq - qi, lb = ls - qj;
+    const bool swp = !(la < lb);  // abs(qed - qst) < abs(sed - sst) -> no swap (1364-1369)
+    s.ncols = swp ? lb : la, s.nrows = swp ? la : lb;
+    const u8* ccls = swp ? (r_scls4 + sb + qj) : (q_scls4 + qb + qi);
+    const u8* rcls = swp ? (q_scls + qb + qi) : (r_scls + sb + qj);
+    s.R = min(s.nrows, s.ncols + KB);
+    s.ridx0 = 8 - l - 1, s.cidx0 = 8 + l - KB - 1;
+    s.rp = rcls + s.ridx0, s.cp = ccls + s.cidx0;
+    s.slot = slot;
+    // cells the reference evaluates (a counter the oracle keeps too): the lane's two band offsets' row ranges
+    const int lo_e = max(1, 17 - 2 * l), lo_o = max(1, 16 - 2 * l);
+    s.ncell = max(0, min(s.R, s.ncols + 16 - 2 * l) - lo_e + 1) + max(0, min(s.R, s.ncols + 15 - 2 * l) - lo_o + 1);
+}
+
+__global__ __launch_bounds__(256) void k_align_pk(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 ntasks,
+                                                  const u8* __restrict__ q_scls, const u8* __restrict__ q_scls4, const u32* __restrict__ qoff,
+                                                  const u8* __restrict__ r_scls, const u8* __restrict__ r_scls4, const u32* __restrict__ roff,
+                                                  const signed char* __restrict__ b62g, AlnRes* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_tab[PK_TAB];
+    for (int i = threadIdx.x; i < 25 * 64; i += 256) {
+        const int a = i >> 6, b = i & 63;
+        const int v = (a < SCLS_N && b < SCLS_N) ? 4 * (int)b62g[a * SCLS_N + b] : (a == PK_SENT_ROW || b == PK_SENT_COL4 / 4) ? -400 : -16;
+        *reinterpret_cast<short*>(s_tab + a * 256 + b * 4) = (short)v;
+    }
+    __syncthreads();
+    const u32 g = blockIdx.x * 16u + (threadIdx.x >> 4);   // 16-lane row = task pair
+    const int l = threadIdx.x & 15;
+    if (2u * g >= ntasks) return;
+    const u32 tA = 2u * g, tB = min(2u * g + 1u, ntasks - 1u);  // odd tail: the pair is (last, last), written once
+    PkSide A, B;
+    {
+        const u32 sa = ridx ? ridx[tA] : tA, sb = ridx ? ridx[tB] : tB;
+        pk_setup(A, tasks[sa], sa, l, q_scls, q_scls4, qoff, r_scls, r_scls4, roff);
+        pk_setup(B, tasks[sb], sb, l, q_scls, q_scls4, qoff, r_scls, r_scls4, roff);
+    }
+    u32 W3e = PK_STOP | PK_TAG3, W3o = PK_STOP | PK_TAG3, Io_out = 0, Do_out = 0;  // results of iteration m - 1
+    u32 key = PK_STOP;
+    const int m_end = max(A.R, B.R) + 15;
+    const int int_hi = min(min(A.R, A.ncols), min(B.R, B.ncols)) - 3;  // groups m0 in [17, int_hi]: every window byte of both sides is inside its sequence
+
+    auto four = [&](int m0, auto edge) {
+        constexpr bool EDGE = decltype(edge)::value;
+        u32 rwA = pk_load4u(A.rp), rwB = pk_load4u(B.rp);
+        u64 cwA = pk_load8u(A.cp), cwB = pk_load8u(B.cp);
+        if (EDGE) {   // bytes outside [0, rows) / [0, columns) -> sentinel classes
+            const int ra = A.ridx0 + (m0 - 8), rb = B.ridx0 + (m0 - 8), ca = A.cidx0 + (m0 - 8), cb = B.cidx0 + (m0 - 8);
+            const u32 mra = (u32)pk_bytemask(max(-ra, 0), min(max(A.nrows - ra, 0), 4)), mrb = (u32)pk_bytemask(max(-rb, 0), min(max(B.nrows - rb, 0), 4));
+            const u64 mca = pk_bytemask(max(-ca, 0), min(max(A.ncols - ca, 0), 8)), mcb = pk_bytemask(max(-cb, 0), min(max(B.ncols - cb, 0), 8));
+            rwA = (rwA & mra) | (0x18181818u & ~mra), rwB = (rwB & mrb) | (0x18181818u & ~mrb);
+            cwA = (cwA & mca) | (0x6060606060606060ull & ~mca), cwB = (cwB & mcb) | (0x6060606060606060ull & ~mcb);
+        }
+        // all sixteen score lookups of the group first (two cells x four iterations x two alignments)
+        u32 S0[4], S1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // (row class << 8) | column class * 4: bytes 1 and 0 picked by one v_perm (selector bytes 0-3: second source)
+            const u32 selE = 0x0C0C0000u | ((u32)(4 + k) << 8) | (u32)k;
+            const u32 selO = 0x0C0C0000u | ((u32)(4 + k) << 8) | (u32)(k + 1);
+            const u32 a0A = __builtin_amdgcn_perm(rwA, (u32)cwA, selE), a0B = __builtin_amdgcn_perm(rwB, (u32)cwB, selE);
+            const u32 a1A = k < 3 ? __builtin_amdgcn_perm(rwA, (u32)cwA, selO) : __builtin_amdgcn_perm(rwA, (u32)(cwA >> 32), 0x0C0C0700u);
+            const u32 a1B = k < 3 ? __builtin_amdgcn_perm(rwB, (u32)cwB, selO) : __builtin_amdgcn_perm(rwB, (u32)(cwB >> 32), 0x0C0C0700u);
+            const u32 e0A = *reinterpret_cast<const unsigned short*>(s_tab + a0A), e0B = *reinterpret_cast<const unsigned short*>(s_tab + a0B);
+            const u32 e1A = *reinterpret_cast<const unsigned short*>(s_tab + a1A), e1B = *reinterpret_cast<const unsigned short*>(s_tab + a1B);
+            S0[k] = (e0B << 16) | e0A;
+            S1[k] = (e1B << 16) | e1A;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            u32 we, Ie_out, De_out, wo;
+            pk_cell(pk_dpp_shr1(Io_out), Do_out, W3e, S0[k], we, Ie_out, De_out, W3e);
+            pk_cell(Ie_out, pk_dpp_shl1(De_out), W3o, S1[k], wo, Io_out, Do_out, W3o);
+            key = pk_max(key, pk_max(we, wo));
+        }
+        A.rp += 4, A.cp += 4, B.rp += 4, B.cp += 4;
+    };
+    // every ACTIVE lane's group m0 is interior: one compare against the exec mask (m0 is wave-uniform)
+    auto all_interior = [&](int m0) {
+        return m0 >= 17 && __builtin_amdgcn_sicmp(m0, int_hi, 41 /*ICMP_SLE*/) == __builtin_amdgcn_read_exec();
+    };
+    for (int m0 = 8; m0 <= m_end; m0 += 4) {
+        if (all_interior(m0)) {
+            do {
+                four(m0, std::false_type{});
+                m0 += 4;
+            } while (all_interior(m0));
+        }
+        four(m0, std::true_type{});
+    }
+    // reduce over the 16 lanes: maximum per half; cells per side
+    int ncA = A.ncell, ncB = B.ncell;
+    for (int msk = 8; msk > 0; msk >>= 1) {
+        key = pk_max(key, (u32)__shfl_xor((int)key, msk, 16));
+        ncA += __shfl_xor(ncA, msk, 16);
+        ncB += __shfl_xor(ncB, msk, 16);
+    }
+    if (l != 0) return;
+    AlnRes r;
+    r.aln = 0, r.matches = 0, r.gap = 0, r.pad = 0, r.qst = 0, r.qed = 0, r.sst = 0, r.sed = 0;
+    r.maxscore = ((int)(short)(key & 0xFFFFu) - 44) >> 2, r.cells = ncA;
+    out[A.slot] = r;
+    if (tB != tA) {
+        r.maxscore = ((int)(short)(key >> 16) - 44) >> 2, r.cells = ncB;
+        out[B.slot] = r;
+    }
+}
+
+// largest min(rows, columns) whose scores fit the packed cells: (11 * n << 2) + 47 + 44 (one more substitution) <= 32767
+int align_pk_max_len() { return 740; }
+
+void launch_align_pk(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
+                     const u8* r_scls4, const u32* roff, const signed char* b62g, AlnRes* out, hipStream_t st) {
+    if (!ntasks) return;
+    const u32 pairs = (ntasks + 1) / 2;
+    hipLaunchKernelGGL(k_align_pk, dim3((pairs + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff, b62g,
+                       out);
+}

@@ -91,6 +91,11 @@ void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q
                   const u8* r_res, const u8* r_scls, const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride,
                   AlnRes* out, bool with_traceback, hipStream_t st);
 
+// k_align16.hip: score-only aligner in packed 16-bit arithmetic, two alignments per register
+int align_pk_max_len();   // largest min(rows, columns) it can score
+void launch_align_pk(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
+                     const u8* r_scls4, const u32* roff, const signed char* b62g, AlnRes* out, hipStream_t st);
+
 // k_phase2.hip
 void launch_gather_cands(const u32* src_q, const u32* src_rec, u32 n, const u32* cqoff, const u32* prior, const u32* qcoff,
                          u32* dst_rec, hipStream_t st);

@@ -40,3 +40,27 @@ def test_find_orth_cli(tmp_path):
     assert os.listdir(str(tmp_path)) == []          # nothing littered (the reference leaves ./tmp and <input>_tmp behind while it runs)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "find_orth.py")], capture_output=True, text=True)
     assert "Usage" in r.stdout
+
+
+@pytest.mark.parametrize("name,variant", orth_golden_cases())
+def test_relations_from_hit_records(name, variant):
+    """the stage's primary input is the search's fixed-width hit records, not text: the same goldens through
+    relations_from_records (records rebuilt from the golden's own .sc rows; ids handed over as the two FASTA id lists)"""
+    import numpy as np
+    from swiftortho_amd import find_orth as fo
+    meta, sc = _load(name)
+    rows = [l[:-1].split("\t") for l in open(sc)]
+    if any(len(r) < 16 for r in rows):
+        pytest.skip("12-column input: no query ordinal to rebuild records from")
+    a = fo.parse(["find_orth.py", "-i", sc] + meta["variants"][variant])
+    qid_of = {}
+    for r in rows:
+        qid_of[int(r[14])] = r[0]
+    qids = [qid_of.get(i, "unused|%d" % i) for i in range(max(qid_of) + 1)]
+    sids = sorted({r[1] for r in rows})
+    sidx = {s: i for i, s in enumerate(sids)}
+    dt = np.dtype([("qidx", "<i8"), ("sidx", "<i8"), ("identity", "<f8"), ("aln", "<i4"), ("qst", "<i4"), ("qed", "<i4"), ("bit", "<i4"), ("qlen", "<i4")])
+    rec = np.array([(int(r[14]), sidx[r[1]], float(r[2]), int(r[3]), int(r[6]), int(r[7]), int(r[11]), int(r[12])) for r in rows], dtype=dt)
+    got = [l.decode() for l in fo.relations_from_records(rec, qids, sids, float(a["-c"]), float(a["-y"]), a["-n"], a["-s"])]
+    want = open(os.path.join(GOLD, "orth_%s.%s.orth" % (name, variant))).read().split("\n")[:-1]
+    assert got == want

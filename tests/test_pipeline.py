@@ -84,3 +84,20 @@ def test_pipeline_on_gpu(cfg, tmp_path):
     assert hashlib.md5(open(sc, "rb").read()).hexdigest() == meta["sc_md5"], "search rows differ from the oracle's"
     orth, groups = downstream(sc, meta, tmp_path)
     check(meta, orth, groups, "pipe_" + cfg)
+
+
+@pytest.mark.gpu
+def test_orthology_from_hit_records_on_gpu(tmp_path):
+    """the in-process flow (swiftortho_amd/pipeline.py): GPU search, then find_orth on the hit RECORDS -- no .sc is parsed -- gives
+    the reference pipeline's relations byte for byte; the .sc it can still write is the oracle's"""
+    from swiftortho_amd import pipeline, synthprot
+    meta = json.load(open(os.path.join(GOLD, "pipe_c2.json")))
+    fa = synthprot.synthprot(meta["proteins"], 300)
+    p, sc = str(tmp_path / "x.fsa"), str(tmp_path / "x.sc")
+    open(p, "wb").write(fa)
+    d = dict(zip(meta["find_hit_flags"][0::2], meta["find_hit_flags"][1::2]))
+    lines, times = pipeline.orthology_from_search(p, sc_path=sc, ssd=d["-s"], nr=d["-r"], ht=int(d["-M"]), chk=int(d["-c"]), step=int(d["-j"]), v=int(d["-v"]),
+                                                  expect=float(d["-e"]), flt=d["-F"])
+    assert times["rows"] == meta["sc_rows"]
+    assert hashlib.md5(open(sc, "rb").read()).hexdigest() == meta["sc_md5"]
+    assert hashlib.md5(b"".join(l + b"\n" for l in lines)).hexdigest() == meta["orth_md5"]
