@@ -681,7 +681,7 @@ struct Batch {
     DevBuf<unsigned long long> qhits;
     DevBuf<u64> cs_kbase;
     DevBuf<u64> keys, keys2;
-    DevBuf<u32> hits32, bmat, bt0, btd, bext, bflag, bcnt, bccnt;  // bucketed binning (k_bucket.hip)
+    DevBuf<u32> hits32, bmat, bpart, bt0, btd, bext, bflag, bcnt, bccnt;  // bucketed binning (k_bucket.hip)
     DevBuf<u32> flags, gidx, ghead;
     DevBuf<u64> p_qs, p_sd, p_ft, p_qs2, tmp64, q_qs, q_sd, q_ft;
     DevBuf<u32> shard;
@@ -984,18 +984,23 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         if ((u64)L.R * NT >= 0xFFFFFFF0ull) return false;
         b.btd.ensure(4 * (size_t)NT + 8);
         launch_bkt_tiledesc(qseg, b.bt0.p, nqp, NT, b.cs_hoff.p, K, b.btd.p, c->st);
-        // count per (range, tile), range-major; its exclusive scan is the scatter plan
+        // count per (tile, range), stored tile-major; its exclusive scan in range-major order is the scatter plan
         const size_t nm = (size_t)L.R * NT;
         b.bmat.ensure(nm + 4);
-        HIP_CHECK(hipMemsetAsync(b.bmat.p, 0, (nm + 4) * sizeof(u32), c->st));
         {
             ProfTimer pt(c, &c->cnt.count_ms, &c->cnt.count_launches);
             launch_bkt_pass(false, b.btd.p, qseg, NT, b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, ch.dk32.p, c->ref.d_off.p + ch.seq_lo, L, b.bmat.p,
                             nullptr, c->st);
             pt.stop();
         }
-        c->d_scan_tmp.ensure(scan_u32_temp_elems(nm + 1) + 8);
-        const u32 Hv = d2h_u32(c, scan_u32(b.bmat.p, b.bmat.p, nm + 1, false, c->d_scan_tmp.p, c->st));  // hits kept (all but the dropped offset-0 ones)
+        const size_t npart = (size_t)L.R * bkt_scan_blocks(NT);
+        b.bpart.ensure(npart + 4);
+        c->d_scan_tmp.ensure(scan_u32_temp_elems(npart + 1) + 8);
+        launch_bkt_colsum(b.bmat.p, NT, L.R, b.bpart.p, c->st);
+        const u32* dHv = scan_u32(b.bpart.p, b.bpart.p, npart, false, c->d_scan_tmp.p, c->st);
+        stash_u32(c, dHv, 2);   // the total lives in d_scan_tmp: park it (k_bkt_extents reads it after later scans)
+        launch_bkt_colscan(b.bmat.p, NT, L.R, b.bpart.p, c->st);
+        const u32 Hv = d2h_u32(c, c->d_small.p + 2);  // hits kept (all but the dropped offset-0 ones)
         sc.lap("seed.bucket_count");
         b.hits32.ensure((size_t)H + 2);
         {
@@ -1009,7 +1014,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         sc.lap("seed.bucket_scatter");
         b.keys2.ensure((size_t)H + 2);
         b.bext.ensure((size_t)nb + 4);
-        launch_bkt_extents(b.bmat.p, b.bt0.p, NT, nqp, nb, b.bext.p, c->st);
+        launch_bkt_extents(b.bmat.p, b.bt0.p, NT, L.R, nqp, nb, c->d_small.p + 2, b.bext.p, c->st);
         launch_bkt_group(b.hits32.p, b.bext.p, nb, L, kl, b.keys2.p, b.bflag.p, c->st);
         // a group too large for a wave's LDS table (or pool) leaves key slots unwritten: never walk them -- sorted path instead
         const u32 refused = d2h_u32(c, b.bflag.p);

@@ -33,7 +33,13 @@
 #define KB 16
 #define PK_SENT_ROW 24          // sentinel row class
 #define PK_SENT_COL4 96         // sentinel column class * 4
-#define PK_TAB (25 * 256)       // bytes: 25 rows x 64 dwords, a 16-bit entry at (row << 8) | (col * 4)
+// Score table: one 16-bit entry per (row class, column class, lane mod 32) at byte (row << 11) | (col << 6) | (lane32 << 1).
+// With one copy of the table a lookup's bank is a function of the column class alone -- 24 classes of very unequal frequency
+// spread 32 lanes over a dozen banks, ~5 deep: measured on config 3, the round-2 aligner spent ~20 of its 25 ms per step in LDS
+// bank conflicts, which is why halving its VALU work alone changed nothing.  Here every lane reads its own copy: lanes 2k and
+// 2k + 1 share a bank (two 16-bit entries per dword), nothing else collides -- at most 2-way.  Address = one v_perm
+// (row << 8 | col * 8) and one v_lshl_or (<< 3 | lane32 * 2).
+#define PK_TAB (25 * 2048)
 #define PK_STOP 0x002C002Cu     // score 0, tag 0 (+ 44) in both halves
 #define PK_TAG3 0x00030003u
 #define PK_CI 0xD3FCD5D6u       // low bytes of (candidate for the right neighbour) - w by tag: -42, -43, -4, -45
@@ -110,18 +116,20 @@ __device__ __forceinline__ void pk_setup(PkSide& s, const AlnTask& tk, u32 slot,
     s.ncell = max(0, min(s.R, s.ncols + 16 - 2 * l) - lo_e + 1) + max(0, min(s.R, s.ncols + 15 - 2 * l) - lo_o + 1);
 }
 
-__global__ __launch_bounds__(256) void k_align_pk(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 ntasks,
+#define PK_THREADS 1024   // two workgroups (2 x 51 KB of table) per CU = 8 waves per SIMD
+__global__ __launch_bounds__(PK_THREADS) void k_align_pk(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 ntasks,
                                                   const u8* __restrict__ q_scls, const u8* __restrict__ q_scls4, const u32* __restrict__ qoff,
                                                   const u8* __restrict__ r_scls, const u8* __restrict__ r_scls4, const u32* __restrict__ roff,
                                                   const signed char* __restrict__ b62g, AlnRes* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) unsigned char s_tab[PK_TAB];
-    for (int i = threadIdx.x; i < 25 * 64; i += 256) {
-        const int a = i >> 6, b = i & 63;
-        const int v = (a < SCLS_N && b < SCLS_N) ? 4 * (int)b62g[a * SCLS_N + b] : (a == PK_SENT_ROW || b == PK_SENT_COL4 / 4) ? -400 : -16;
-        *reinterpret_cast<short*>(s_tab + a * 256 + b * 4) = (short)v;
+    for (int i = threadIdx.x; i < 25 * 32 * 32; i += PK_THREADS) {
+        const int a = i >> 10, b = (i >> 5) & 31;   // row class, column class; i & 31 = the lane's copy
+        const int v = (a < SCLS_N && b < SCLS_N) ? 4 * (int)b62g[a * SCLS_N + b] : -400;
+        reinterpret_cast<short*>(s_tab)[i] = (short)v;
     }
     __syncthreads();
-    const u32 g = blockIdx.x * 16u + (threadIdx.x >> 4);   // 16-lane row = task pair
+    const u32 lane2 = (threadIdx.x & 31u) << 1;
+    const u32 g = blockIdx.x * (PK_THREADS / 16) + (threadIdx.x >> 4);   // 16-lane row = task pair
     const int l = threadIdx.x & 15;
     if (2u * g >= ntasks) return;
     const u32 tA = 2u * g, tB = min(2u * g + 1u, ntasks - 1u);  // odd tail: the pair is (last, last), written once
@@ -145,20 +153,22 @@ __global__ __launch_bounds__(256) void k_align_pk(const AlnTask* __restrict__ ta
             const u32 mra = (u32)pk_bytemask(max(-ra, 0), min(max(A.nrows - ra, 0), 4)), mrb = (u32)pk_bytemask(max(-rb, 0), min(max(B.nrows - rb, 0), 4));
             const u64 mca = pk_bytemask(max(-ca, 0), min(max(A.ncols - ca, 0), 8)), mcb = pk_bytemask(max(-cb, 0), min(max(B.ncols - cb, 0), 8));
             rwA = (rwA & mra) | (0x18181818u & ~mra), rwB = (rwB & mrb) | (0x18181818u & ~mrb);
-            cwA = (cwA & mca) | (0x6060606060606060ull & ~mca), cwB = (cwB & mcb) | (0x6060606060606060ull & ~mcb);
+            cwA = (cwA & mca) | (0x6060606060606060ull & ~mca), cwB = (cwB & mcb) | (0x6060606060606060ull & ~mcb);   // (sentinel column 24, * 4)
         }
+        // column classes arrive * 4; the table wants * 8 (no carry between bytes: every class * 4 is < 128)
+        cwA <<= 1, cwB <<= 1;
         // all sixteen score lookups of the group first (two cells x four iterations x two alignments)
         u32 S0[4], S1[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            // (row class << 8) | column class * 4: bytes 1 and 0 picked by one v_perm (selector bytes 0-3: second source)
+            // (row class << 8) | column class * 8: bytes 1 and 0 picked by one v_perm (selector bytes 0-3: second source)
             const u32 selE = 0x0C0C0000u | ((u32)(4 + k) << 8) | (u32)k;
             const u32 selO = 0x0C0C0000u | ((u32)(4 + k) << 8) | (u32)(k + 1);
             const u32 a0A = __builtin_amdgcn_perm(rwA, (u32)cwA, selE), a0B = __builtin_amdgcn_perm(rwB, (u32)cwB, selE);
             const u32 a1A = k < 3 ? __builtin_amdgcn_perm(rwA, (u32)cwA, selO) : __builtin_amdgcn_perm(rwA, (u32)(cwA >> 32), 0x0C0C0700u);
             const u32 a1B = k < 3 ? __builtin_amdgcn_perm(rwB, (u32)cwB, selO) : __builtin_amdgcn_perm(rwB, (u32)(cwB >> 32), 0x0C0C0700u);
-            const u32 e0A = *reinterpret_cast<const unsigned short*>(s_tab + a0A), e0B = *reinterpret_cast<const unsigned short*>(s_tab + a0B);
-            const u32 e1A = *reinterpret_cast<const unsigned short*>(s_tab + a1A), e1B = *reinterpret_cast<const unsigned short*>(s_tab + a1B);
+            const u32 e0A = *reinterpret_cast<const unsigned short*>(s_tab + ((a0A << 3) | lane2)), e0B = *reinterpret_cast<const unsigned short*>(s_tab + ((a0B << 3) | lane2));
+            const u32 e1A = *reinterpret_cast<const unsigned short*>(s_tab + ((a1A << 3) | lane2)), e1B = *reinterpret_cast<const unsigned short*>(s_tab + ((a1B << 3) | lane2));
             S0[k] = (e0B << 16) | e0A;
             S1[k] = (e1B << 16) | e1A;
         }
@@ -209,6 +219,6 @@ void launch_align_pk(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8
                      const u8* r_scls4, const u32* roff, const signed char* b62g, AlnRes* out, hipStream_t st) {
     if (!ntasks) return;
     const u32 pairs = (ntasks + 1) / 2;
-    hipLaunchKernelGGL(k_align_pk, dim3((pairs + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff, b62g,
+    hipLaunchKernelGGL(k_align_pk, dim3((pairs + PK_THREADS / 16 - 1) / (PK_THREADS / 16)), dim3(PK_THREADS), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff, b62g,
                        out);
 }

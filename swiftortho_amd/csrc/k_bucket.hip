@@ -123,8 +123,10 @@ static BkHist bk_hist_layout(u32 R, bool staged, bool skewed) {
 }
 #define BK_STAGE_RMAX 128   // the staged scatter keeps one global offset per non-empty run of the tile in LDS
 
-// SCATTER = false: mat[range * NT + tile] = hits of the tile in the range (mat zeroed by the host);
-// SCATTER = true : mat holds the exclusive scan of those counts = where the tile's hits of each range go in `out`.
+// SCATTER = false: mat[tile * R + range] = hits of the tile in the range (every entry written);
+// SCATTER = true : mat holds the exclusive scan of those counts IN RANGE-MAJOR ORDER (k_bkt_colsum / k_bkt_colscan) = where the
+// tile's hits of each range go in `out`.  The matrix is stored tile-major so that a tile's R entries are one contiguous run for
+// the wave that writes / reads them (range-major storage cost R scattered 4-byte accesses per tile in both passes).
 // STAGED (scatter only, R <= BK_STAGE_RMAX): the tile's words are first put in LDS ordered by range -- the per-range LDS
 // counters give every hit its place -- and then written out position by position: one store instruction covers 64
 // consecutive staged words = two to four runs of consecutive addresses, instead of 64 lanes landing in ~R different lines
@@ -213,16 +215,16 @@ __global__ __launch_bounds__(64 * BK_WAVES, 6) void k_bkt_pass(const uint4* __re
     }
     bk_wave_sync();
     if (!SCATTER) {
-        for (u32 r = lane; r < L.R; r += 64) {
+        for (u32 r = lane; r < L.R; r += 64) {   // tile-major: the tile's R counts are one contiguous run (zeros included)
             u32 n = 0;
             for (u32 cpy = 0; cpy < ncopy; ++cpy) n += s_hist[cpy * cstride + r];
-            if (n) mat[(size_t)r * NT + t] = n;
+            mat[(size_t)t * L.R + r] = n;
         }
         return;
     }
     if (!STAGED) {
         for (u32 r = lane; r < L.R; r += 64) {  // counts -> global start of every (range, copy) share
-            u32 run = mat[(size_t)r * NT + t];
+            u32 run = mat[(size_t)t * L.R + r];
             for (u32 cpy = 0; cpy < ncopy; ++cpy) {
                 const u32 n = s_hist[cpy * cstride + r];
                 s_hist[cpy * cstride + r] = run;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(64 * BK_WAVES, 6) void k_bkt_pass(const uint4* __re
         u32 run = total + inc - n;
         if (n) {
             const u32 j = nrun + __builtin_amdgcn_mbcnt_hi((u32)(nz >> 32), __builtin_amdgcn_mbcnt_lo((u32)nz, 0u));
-            s_hist[HL.gbase + j] = mat[(size_t)r * NT + t] - run;
+            s_hist[HL.gbase + j] = mat[(size_t)t * L.R + r] - run;
             myhead[k] = run;
         }
         if (r < L.R)
@@ -321,12 +323,54 @@ static_assert(BG_CAP <= 4096 && BG_BINS % BG_THREADS == 0 && BG_CAP % BG_THREADS
 __device__ __forceinline__ void bg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // bucket b (range-major) occupies hits[bext[b] .. bext[b + 1])
-__global__ __launch_bounds__(256) void k_bkt_extents(const u32* __restrict__ mat, const u32* __restrict__ t0, u32 NT, u32 nqp, u32 nb,
-                                                     u32* __restrict__ bext /*nb + 1*/) {
+__global__ __launch_bounds__(256) void k_bkt_extents(const u32* __restrict__ mat, const u32* __restrict__ t0, u32 NT, u32 R, u32 nqp, u32 nb,
+                                                     const u32* __restrict__ total, u32* __restrict__ bext /*nb + 1*/) {
     const u32 b = blockIdx.x * 256u + threadIdx.x;
     if (b > nb) return;
-    const u32 r = b / nqp, qrel = b - r * nqp;
-    bext[b] = mat[(size_t)r * NT + t0[qrel]];   // b == nb: r = R, qrel = 0 -> mat[R * NT] = total
+    u32 r = b / nqp;
+    const u32 qrel = b - r * nqp;
+    // the first tile of a query without hits is the next query's first tile: its scanned entry is where the bucket would start;
+    // past the last tile that is the first entry of the next range (scan order: position r * NT + t), or the total
+    u32 t = b == nb ? NT : t0[qrel];
+    if (t >= NT) t = 0, r += 1;
+    bext[b] = r >= R ? *total : mat[(size_t)t * R + r];
+}
+
+// ---- exclusive scan of the tile-major count matrix in RANGE-MAJOR order ------------------------------------------------
+// position of entry (tile t, range r) in the scan order = r * NT + t.  Blocks of BK_TB consecutive tiles: column sums per block
+// (k_bkt_colsum, stored range-major), one short scan over those R * NTB partials (scan_u32), then every block rewrites its
+// entries as running sums from its column bases (k_bkt_colscan).  Thread = one range: a wave touches R contiguous words per tile.
+#define BK_TB 128
+__global__ __launch_bounds__(64) void k_bkt_colsum(const u32* __restrict__ mat, u32 NT, u32 R, u32 NTB, u32* __restrict__ partT /*[R][NTB]*/) {
+    const u32 blk = blockIdx.x, t0 = blk * BK_TB, t1 = min(NT, t0 + BK_TB);
+    for (u32 r = threadIdx.x; r < R; r += 64) {
+        u32 s = 0;
+#pragma unroll 8
+        for (u32 t = t0; t < t1; ++t) s += mat[(size_t)t * R + r];
+        partT[(size_t)r * NTB + blk] = s;
+    }
+}
+__global__ __launch_bounds__(64) void k_bkt_colscan(u32* __restrict__ mat, u32 NT, u32 R, u32 NTB, const u32* __restrict__ baseT /*[R][NTB], scanned*/) {
+    const u32 blk = blockIdx.x, t0 = blk * BK_TB, t1 = min(NT, t0 + BK_TB);
+    for (u32 r = threadIdx.x; r < R; r += 64) {
+        u32 run = baseT[(size_t)r * NTB + blk];
+        u32 t = t0;
+        for (; t + 8 <= t1; t += 8) {   // eight loads in flight, stores in order
+            u32 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = mat[(size_t)(t + k) * R + r];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                mat[(size_t)(t + k) * R + r] = run;
+                run += v[k];
+            }
+        }
+        for (; t < t1; ++t) {
+            const u32 v = mat[(size_t)t * R + r];
+            mat[(size_t)t * R + r] = run;
+            run += v;
+        }
+    }
 }
 
 __global__ __launch_bounds__(BG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bkt_group(const u32* __restrict__ hits, const u32* __restrict__ bext /*nb + 1*/, u32 nb,
@@ -641,8 +685,16 @@ void launch_bkt_pass(bool scatter, const void* td, const u32* qseg, u32 NT, cons
     else hipLaunchKernelGGL((k_bkt_pass<true, false>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
 }
 
-void launch_bkt_extents(const u32* mat, const u32* t0, u32 NT, u32 nqp, u32 nb, u32* bext, hipStream_t st) {
-    hipLaunchKernelGGL(k_bkt_extents, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, mat, t0, NT, nqp, nb, bext);
+void launch_bkt_extents(const u32* mat, const u32* t0, u32 NT, u32 R, u32 nqp, u32 nb, const u32* total, u32* bext, hipStream_t st) {
+    hipLaunchKernelGGL(k_bkt_extents, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, mat, t0, NT, R, nqp, nb, total, bext);
+}
+
+u32 bkt_scan_blocks(u32 NT) { return (NT + BK_TB - 1) / BK_TB; }
+void launch_bkt_colsum(const u32* mat, u32 NT, u32 R, u32* partT, hipStream_t st) {
+    if (NT) hipLaunchKernelGGL(k_bkt_colsum, dim3(bkt_scan_blocks(NT)), dim3(64), 0, st, mat, NT, R, bkt_scan_blocks(NT), partT);
+}
+void launch_bkt_colscan(u32* mat, u32 NT, u32 R, const u32* baseT, hipStream_t st) {
+    if (NT) hipLaunchKernelGGL(k_bkt_colscan, dim3(bkt_scan_blocks(NT)), dim3(64), 0, st, mat, NT, R, bkt_scan_blocks(NT), baseT);
 }
 
 int bkt_max_wb() {

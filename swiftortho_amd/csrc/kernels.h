@@ -130,7 +130,11 @@ void launch_bkt_tiledesc(const u32* qseg, const u32* t0, u32 nqp, u32 NT, const 
 void launch_bkt_pass(bool scatter, const void* td, const u32* qseg, u32 NT, const u32* cs_hoff, const u32* cs_base, const u64* cs_kbase,
                      const u32* dk32, const u32* roff, const BktLayout& L, u32* mat, u32* out, hipStream_t st);
 int bkt_max_wb();
-void launch_bkt_extents(const u32* mat, const u32* t0, u32 NT, u32 nqp, u32 nb, u32* bext /*nb + 1*/, hipStream_t st);
+void launch_bkt_extents(const u32* mat, const u32* t0, u32 NT, u32 R, u32 nqp, u32 nb, const u32* total, u32* bext /*nb + 1*/, hipStream_t st);
+// exclusive scan of the tile-major count matrix in range-major order: column sums per block of tiles, scan_u32 over them, running sums
+u32 bkt_scan_blocks(u32 NT);
+void launch_bkt_colsum(const u32* mat, u32 NT, u32 R, u32* partT /*R x bkt_scan_blocks(NT)*/, hipStream_t st);
+void launch_bkt_colscan(u32* mat, u32 NT, u32 R, const u32* baseT, hipStream_t st);
 void launch_bkt_group(const u32* hits, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, u64* keys, u32* fallback,
                       hipStream_t st);
 // best diagonal per (query, subject), bucket by bucket: pass records binned into the hit buckets (count -> scan -> scatter, first-touch
