@@ -1,0 +1,60 @@
+// Issue rate of the VALU instructions the aligner / extension kernels are made of (round 3): eight independent accumulators per
+// lane, 8 waves per SIMD, every CU busy; cycles per wave-instruction per SIMD at 2.4 GHz.  Also: the same with ONE accumulator
+// (a dependent chain) -- what a recurrence like the banded DP sees.
+// hipcc --offload-arch=gfx950 -O3 tools/ubench/valu.hip -o tools/ubench/valu && tools/ubench/valu
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+#define OPS(X) X(0, "v_add_u32 %0, %0, %1") X(1, "v_pk_add_u16 %0, %0, %1") X(2, "v_pk_max_i16 %0, %0, %1") X(3, "v_perm_b32 %0, %0, %1, %1") \
+               X(4, "v_and_or_b32 %0, %0, %1, %1") X(5, "v_max_i32 %0, %0, %1") X(6, "v_max3_i32 %0, %0, %1, %1") X(7, "v_lshl_or_b32 %0, %0, 3, %1") \
+               X(8, "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1") X(9, "v_cndmask_b32 %0, %0, %1, vcc") X(10, "v_pk_add_i16 %0, %0, %1 clamp")
+
+template <int OP, int CHAINS>
+__global__ __launch_bounds__(256) void k(int iters, unsigned seed, unsigned* out) {
+    unsigned a[8], b = seed + threadIdx.x;
+    for (int i = 0; i < 8; ++i) a[i] = threadIdx.x * 7 + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                unsigned& x = a[CHAINS == 1 ? 0 : i];
+#define X(N, S) if (OP == N) asm volatile(S : "+v"(x) : "v"(b));
+                OPS(X)
+#undef X
+            }
+        }
+    }
+    unsigned s = 0;
+    for (int i = 0; i < 8; ++i) s += a[i];
+    if (s == 0x12345) out[0] = s;
+}
+
+template <int OP, int CHAINS>
+int run(const char* name, unsigned* o) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int blocks = 256 * 8, iters = 4000;
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k<OP, CHAINS>), dim3(blocks), dim3(256), 0, 0, iters, 1u, o);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    const double per_simd = (double)blocks * 4 / 1024 * iters * 32;   // wave-instructions per SIMD
+    printf("%-70s %s: %7.3f ms = %5.2f cycles per wave-instruction per SIMD\n", name, CHAINS == 1 ? "1 chain " : "8 chains", ms, ms * 1e-3 * 2.4e9 / per_simd);
+    return 0;
+}
+
+int main() {
+    unsigned* o;
+    CK(hipMalloc(&o, 64));
+#define X(N, S) run<N, 8>(S, o); run<N, 1>(S, o);
+    OPS(X)
+#undef X
+    return 0;
+}
