@@ -162,6 +162,26 @@ int64_t so_masked_query(so_ctx *ctx, int64_t qidx, char *buf, int64_t cap);
  * so_search_loaded() call, in the order the reference's spill file holds them (chunk-major) */
 int64_t so_query_candidates(so_ctx *ctx, int64_t qidx, uint32_t *out4, int64_t cap);
 
+/* Markov clustering of one block of the orthology graph.  Replaces: the matrix loop of bin/find_cluster.py
+ * `mcl` (652-689) with `normalize` (636-646) as `mcl_xyz` (1425-1467) calls it on a float32 scipy csr_matrix -- column
+ * normalisation, expansion (sparse x sparse), inflation, pruning below `prune`, at most max_rounds rounds, convergence test
+ * every check_every-th round -- with scipy's arithmetic order (csrc/mcl.hip).  Input: an n x n CSR matrix (rows = indptr,
+ * columns = indices, float32 data; inputs are borrowed).  Output: the matrix the loop ends with, in scipy's storage order and
+ * with its explicitly stored zeros (the reference's read-out depends on both); arrays allocated by the library, released with
+ * so_mcl_free().  Returns 0 / non-zero with a message in so_mcl_last_error().  No so_ctx: the call owns a stream of `device`. */
+typedef struct so_mcl_result {
+    int64_t n, nnz;
+    int32_t rounds;    /* rounds executed                                  */
+    int32_t converged; /* 1 = left the loop through the convergence test   */
+    int64_t *indptr;   /* n + 1                                            */
+    int32_t *indices;  /* nnz                                              */
+    float *data;       /* nnz                                              */
+} so_mcl_result;
+int so_mcl(int device, int64_t n, const int64_t *indptr, const int32_t *indices, const float *data, double inflation, int32_t max_rounds,
+           int32_t check_every, double prune, double rtol, double atol, so_mcl_result *out);
+void so_mcl_free(so_mcl_result *result);
+const char *so_mcl_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,7 +38,13 @@ EXPORTS = ["so_abi_version", "so_create", "so_destroy", "so_last_error", "so_loa
            "so_load_queries", "so_load_queries_mem", "so_num_queries", "so_num_refs", "so_query_len", "so_search_loaded",
            "so_search", "so_free_hits", "so_write_sc", "so_format_hit", "so_get_counters", "so_reset_counters", "so_timing_report",
            "so_chunk_threshold", "so_chunk_entries", "so_chunk_download", "so_masked_query", "so_query_candidates", "so_set_profile",
-           "so_bucket_count", "so_ref_len", "so_search_device", "so_device_hits_copy", "so_query_work"]
+           "so_bucket_count", "so_ref_len", "so_search_device", "so_device_hits_copy", "so_query_work", "so_mcl", "so_mcl_free",
+           "so_mcl_last_error"]
+
+
+class SoMclResult(C.Structure):
+    _fields_ = [("n", C.c_int64), ("nnz", C.c_int64), ("rounds", C.c_int32), ("converged", C.c_int32), ("indptr", C.POINTER(C.c_int64)),
+                ("indices", C.POINTER(C.c_int32)), ("data", C.POINTER(C.c_float))]
 
 _lib = None
 
@@ -120,6 +126,9 @@ def load():
     L.so_masked_query.argtypes = [vp, i64, cp, i64]
     L.so_query_candidates.restype = i64
     L.so_query_candidates.argtypes = [vp, i64, vp, i64]
+    L.so_mcl.argtypes = [C.c_int, i64, vp, vp, vp, C.c_double, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.POINTER(SoMclResult)]
+    L.so_mcl_free.argtypes = [C.POINTER(SoMclResult)]
+    L.so_mcl_last_error.restype = cp
     if L.so_abi_version() != 1:
         raise ImportError("libsohit.so ABI version mismatch")
     _lib = L

@@ -104,7 +104,6 @@ __device__ __forceinline__ bool bk_hit(u32 c, u32 qpos, const BktLayout& L, u32&
 struct BkHist {
     u32 ncopy, cstride;   // copies (power of two), words between two copies
     u32 gbase;            // staged scatter: where the per-run global offsets live inside the histogram array
-    u32 nt;               // staged scatter: non-temporal stores (SOHIT_BK_NT=1; measured)
 };
 static BkHist bk_hist_layout(u32 R, bool staged, bool skewed) {
     u32 Rp = 1;
@@ -120,8 +119,6 @@ static BkHist bk_hist_layout(u32 R, bool staged, bool skewed) {
         h.cstride = h.ncopy > 1 ? Rp + 32u / h.ncopy : Rp;
     }
     h.gbase = h.ncopy * h.cstride;
-    static const bool nt = getenv("SOHIT_BK_NT") && atoi(getenv("SOHIT_BK_NT")) != 0;
-    h.nt = nt ? 1u : 0u;
     return h;
 }
 #define BK_STAGE_RMAX 128   // the staged scatter keeps one global offset per non-empty run of the tile in LDS
@@ -293,10 +290,7 @@ __global__ __launch_bounds__(64 * BK_WAVES, 6) void k_bkt_pass(const uint4* __re
         const u32 v = i < total ? s_stage[i] : 0u;
         const unsigned long long hb = __ballot((v >> 31) != 0);
         const u32 j = jc + __builtin_amdgcn_mbcnt_hi((u32)(hb >> 32), __builtin_amdgcn_mbcnt_lo((u32)hb, 0u)) + (v >> 31) - 1u;
-        if (i < total) {
-            if (HL.nt) __builtin_nontemporal_store(v & 0x7FFFFFFFu, out + s_hist[HL.gbase + j] + i);
-            else out[s_hist[HL.gbase + j] + i] = v & 0x7FFFFFFFu;
-        }
+        if (i < total) out[s_hist[HL.gbase + j] + i] = v & 0x7FFFFFFFu;   // (non-temporal stores: measured, no difference)
         jc += (u32)__popcll(hb);
     }
 }

@@ -3,11 +3,12 @@ relations file (find_orth output) to ortholog groups, one tab-separated group pe
 same stdout.
 
 Last stage of BASELINE config 5 (find_hit -> find_orth -> find_cluster -a mcl -I 1.5); a SURVEY.md 8f
-"next" row.  Host code: the graphs here have a few edges per protein, the stage is bounded by text
-parsing, and the Markov-cluster iteration runs on float32 CSR matrices through scipy's SpGEMM exactly
-as the reference's does (bit-identical expansion is what keeps the pruning decisions, and therefore
-the groups, identical).  Only `mcl` is provided; the reference's affinity-propagation modes
-(`-a apc|sap`) are refused with a message.
+"next" row.  The Markov-cluster iteration -- the one data-parallel part of this stage: column normalisation,
+sparse x sparse expansion, inflation, pruning on float32 CSR matrices -- runs on the GPU (libsohit `so_mcl`,
+csrc/mcl.hip) with scipy's arithmetic order, because the pruning decisions, and therefore the groups, depend
+on it; the graph bookkeeping around it (best-neighbour components, batching, the read-out) is host code.
+There is no CPU path for the loop: without the HIP library `-a mcl` fails.  Only `mcl` is provided; the
+reference's default `-a apc` and `-a sap` (affinity propagation) are refused with a message and exit code 2.
 
 Reference behaviour reproduced (bin/find_cluster.py, `cnc` 1470-1673, `mcl_xyz` 1425-1467, `mcl`
 652-689, `normalize` 636-646), including its accidents, because they decide which genes appear:
@@ -91,76 +92,111 @@ def _rows(lines):
         yield x, y, z
 
 
-def _normalize_columns(x):
-    """normalize (636-646): column sums in float32; the epsilon rule as written"""
-    y = np.asarray(x.sum(0))[0]
-    if y.min() == 0 and y.max() > 0:
-        y += y.nonzero()[0].min() / 1e3
-    else:
-        y += 1e-8
-    x.data /= y.take(x.indices, mode='clip')
+def block_matrix(edge_lines):
+    """The matrix mcl_xyz (find_cluster.py:1425-1467) hands to the Markov loop, built columnar: genes numbered by first appearance over
+    ALL lines of the batch, rows with x <= y only, (x, y) and (y, x) carry the weight of the pair's LAST line, the diagonal the largest
+    incident weight, weights in float32, explicit zeros not stored; (D + 1) x (D + 1) with an empty last row, canonical CSR (columns
+    ascending).  -> (gene names by number, indptr int64, indices int32, data float32)"""
+    cols = [l.split('\t', 3)[:3] for l in edge_lines]
+    xs = np.array([c[0] for c in cols], dtype=object)
+    ys = np.array([c[1] for c in cols], dtype=object)
+    inter = np.empty(2 * len(cols), dtype=object)
+    inter[0::2], inter[1::2] = xs, ys
+    names = list(dict.fromkeys(inter.tolist()))            # numbering in order of first appearance
+    number = {g: k for k, g in enumerate(names)}
+    dmx = len(names) + 1
+    use = np.array([c[0] <= c[1] for c in cols], dtype=bool)
+    X = np.fromiter((number[g] for g in xs[use].tolist()), dtype=np.int64, count=int(use.sum()))
+    Y = np.fromiter((number[g] for g in ys[use].tolist()), dtype=np.int64, count=int(use.sum()))
+    Z = np.array([float(c[2]) for c, u in zip(cols, use.tolist()) if u], dtype=np.float64).astype(np.float32)
+    if np.any(X == Y):
+        return names, *_block_matrix_sequential(X, Y, Z, dmx)   # self loops overwrite the diagonal in line order: rare, done one by one
+    # off-diagonal: the last line of a pair wins
+    key = X * dmx + Y
+    last = len(key) - 1 - np.unique(key[::-1], return_index=True)[1]
+    px, py, pz = X[last], Y[last], Z[last]
+    # diagonal: the largest weight seen at either end (a zero start: weights <= 0 never set it)
+    diag = np.zeros(dmx, dtype=np.float32)
+    np.maximum.at(diag, X, Z)
+    np.maximum.at(diag, Y, Z)
+    dn = np.flatnonzero(diag > 0)
+    r = np.concatenate([px, py, dn])
+    c = np.concatenate([py, px, dn])
+    v = np.concatenate([pz, pz, diag[dn]])
+    keep = v != 0
+    r, c, v = r[keep], c[keep], v[keep]
+    o = np.lexsort((c, r))
+    r, c, v = r[o], c[o], v[o]
+    indptr = np.zeros(dmx + 1, dtype=np.int64)
+    np.cumsum(np.bincount(r, minlength=dmx), out=indptr[1:])
+    return names, indptr, c.astype(np.int32), v.astype(np.float32)
 
 
-def markov_cluster(x, inflation=1.5, expansion=2, prune=1e-5, rtol=1e-5, atol=1e-8, rounds=100, check=5):
-    """mcl (652-689) on a scipy csr_matrix (float32) -> list of (row, col) pairs that survive"""
-    for i in range(rounds):
-        _normalize_columns(x)
-        if i % check == 0:
-            x_old = x.copy()
-        x = x ** expansion          # spmatrix power = matrix product (SpGEMM; entries that sum to zero are not stored)
-        x.data **= inflation
-        if i % check == 0 and i > 0:
-            if (abs(x - x_old) - rtol * abs(x_old)).max() <= atol:
-                break
-        x.data[x.data < prune] = 0.
-    rows, cols = x.nonzero()
-    vals = x.data                   # NOT masked: misaligned with (rows, cols) when pruned zeros are still stored
-    return [(int(r), int(c)) for r, c, k in zip(rows, cols, vals) if k > prune]
-
-
-def mcl_block(edge_lines, inflation):
-    """mcl_xyz (1425-1467): lines 'x\\ty\\tz...' of one batch -> groups (lists of ids) in the reference's order"""
-    from scipy import sparse
-    l2n = {}
-    for i in edge_lines:
-        x, y = i.split('\t', 3)[:2]
-        if x not in l2n:
-            l2n[x] = len(l2n)
-        if y not in l2n:
-            l2n[y] = len(l2n)
-    dmx = len(l2n) + 1
+def _block_matrix_sequential(X, Y, Z, dmx):
     cell = {}
-    for i in edge_lines:
-        x, y, z = i.split('\t', 4)[:3]
-        if x > y:
-            continue
-        X, Y = l2n[x], l2n[y]
-        Z = np.float32(float(z))
-        cell[(X, Y)] = Z
-        cell[(Y, X)] = Z
-        if cell.get((X, X), np.float32(0)) < Z:
-            cell[(X, X)] = Z
-        if cell.get((Y, Y), np.float32(0)) < Z:
-            cell[(Y, Y)] = Z
-    n2l = {}
-    while l2n:
-        key, val = l2n.popitem()
-        n2l[val] = key
-    keys = sorted(cell)             # row-major, columns ascending: the canonical CSR of the reference's lil -> csr conversion
-    r = np.fromiter((k[0] for k in keys), dtype=np.int32, count=len(keys))
-    c = np.fromiter((k[1] for k in keys), dtype=np.int32, count=len(keys))
-    v = np.fromiter((cell[k] for k in keys), dtype=np.float32, count=len(keys))
-    keep = v != 0                   # lil_matrix does not store assigned zeros
-    m = sparse.csr_matrix((v[keep], (r[keep], c[keep])), shape=(dmx, dmx), dtype='float32')
+    zero = np.float32(0)
+    for a, b, z in zip(X.tolist(), Y.tolist(), Z):
+        cell[(a, b)] = z
+        cell[(b, a)] = z
+        if cell.get((a, a), zero) < z:
+            cell[(a, a)] = z
+        if cell.get((b, b), zero) < z:
+            cell[(b, b)] = z
+    keys = sorted(k for k, v in cell.items() if v != 0)
+    r = np.array([k[0] for k in keys], dtype=np.int64)
+    indptr = np.zeros(dmx + 1, dtype=np.int64)
+    np.cumsum(np.bincount(r, minlength=dmx), out=indptr[1:])
+    return indptr, np.array([k[1] for k in keys], dtype=np.int32), np.array([cell[k] for k in keys], dtype=np.float32)
+
+
+def device_mcl(indptr, indices, data, inflation, device=0):
+    """the Markov loop on the GPU (libsohit so_mcl, csrc/mcl.hip) -> the final matrix as (indptr, indices, data) in the reference's
+    storage order, stored zeros included.  No CPU path: raises when the HIP library or a device is missing."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.load()
+    res = _lib.SoMclResult()
+    ip = np.ascontiguousarray(indptr, dtype=np.int64)
+    ix = np.ascontiguousarray(indices, dtype=np.int32)
+    dv = np.ascontiguousarray(data, dtype=np.float32)
+    rc = L.so_mcl(device, len(ip) - 1, ip.ctypes.data, ix.ctypes.data if len(ix) else None, dv.ctypes.data if len(dv) else None, float(inflation), 100, 5,
+                  1e-5, 1e-5, 1e-8, C.byref(res))
+    if rc != 0:
+        raise RuntimeError(L.so_mcl_last_error().decode())
+    try:
+        n, nnz = int(res.n), int(res.nnz)
+        out_ip = np.ctypeslib.as_array(res.indptr, shape=(n + 1,)).copy()
+        out_ix = np.ctypeslib.as_array(res.indices, shape=(max(nnz, 1),))[:nnz].copy()
+        out_dv = np.ctypeslib.as_array(res.data, shape=(max(nnz, 1),))[:nnz].copy()
+    finally:
+        L.so_mcl_free(C.byref(res))
+    return out_ip, out_ix, out_dv
+
+
+def surviving_pairs(indptr, indices, data, prune=1e-5):
+    """The reference's read-out of the final matrix (find_cluster.py:686-689): the coordinates of the entries that are not zero, paired
+    IN ORDER with the raw data array -- which still holds the pruned zeros when the loop ran out of rounds, so the pairing can be
+    shifted -- and kept where that value exceeds the threshold."""
+    rows = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr))
+    nz = data != 0
+    r, c = rows[nz], indices[nz]
+    keep = data[:len(r)] > np.float32(prune)
+    return list(zip(r[keep].tolist(), c[keep].tolist()))
+
+
+def mcl_block(edge_lines, inflation, mcl=device_mcl):
+    """one batch of edges -> groups (lists of gene ids) in the reference's order"""
+    names, indptr, indices, data = block_matrix(edge_lines)
     g = _Graph()
-    for a, b in markov_cluster(m, inflation):
+    for a, b in surviving_pairs(*mcl(indptr, indices, data, inflation)):
         g.add_edge(a, b)
     for comp in g.components():
-        yield [n2l[e] for e in comp]
+        yield [names[e] for e in comp]
 
 
-def cnc(lines, inflation=1.5, chk=10 ** 7):
-    """cnc (1470-1673): relation rows -> groups (lists of gene ids), in the reference's output order"""
+def cnc(lines, inflation=1.5, chk=10 ** 7, mcl=device_mcl):
+    """cnc (1470-1673): relation rows -> groups (lists of gene ids), in the reference's output order.  `mcl`: the Markov loop on a CSR block
+    (the device implementation; the tests pass the scipy oracle to check this host bookkeeping on CPU)"""
     lines = list(lines)
     nns = {}
     for x, y, z in _rows(lines):
@@ -208,12 +244,12 @@ def cnc(lines, inflation=1.5, chk=10 ** 7):
         c = line.split('\t', 2)[0]
         if c != cls:
             if flag > chk:
-                out.extend(mcl_block(batch, inflation))
+                out.extend(mcl_block(batch, inflation, mcl))
                 batch, flag = [], 0
             cls = c
         batch.append(line.split('\t', 1)[1])
         flag += 1
-    out.extend(mcl_block(batch, inflation))
+    out.extend(mcl_block(batch, inflation, mcl))
     return out
 
 

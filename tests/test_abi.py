@@ -60,7 +60,8 @@ def test_bad_parameters_are_reported_not_aborted(lib):
 
 
 def test_product_never_imports_the_oracle():
-    """oracle/ is test infrastructure: nothing under swiftortho_amd/ or bin/ may reference it."""
+    """oracle/ and tests/mcl_scipy_oracle.py are test infrastructure: nothing under swiftortho_amd/ or bin/ may reference them (nor scipy,
+    which only the MCL oracle uses)."""
     bad = []
     for base in ("swiftortho_amd", "bin"):
         for d, _, files in os.walk(os.path.join(ROOT, base)):
@@ -69,10 +70,22 @@ def test_product_never_imports_the_oracle():
             for f in files:
                 if f.endswith((".py", ".hip", ".h", ".cpp")):
                     txt = open(os.path.join(d, f), errors="ignore").read()
-                    if re.search(r"^\s*(from|import)\s+oracle\b|liboracle|sohit_cpu", txt, flags=re.M):
+                    if re.search(r"^\s*(from|import)\s+oracle\b|liboracle|sohit_cpu|mcl_scipy_oracle|^\s*(from|import)\s+scipy", txt, flags=re.M):
                         if f == "host.hip" and "oracle/" in txt:
                             # the header comment forbids it; make sure there is no include/link
                             if not re.search(r"#include\s+\"[^\"]*oracle", txt):
                                 continue
                         bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_mcl_fails_loudly_without_a_gpu(lib):
+    """the Markov loop has no CPU path either: so_mcl reports the missing device"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import numpy as np
+    from swiftortho_amd import find_cluster as fc
+    with pytest.raises(RuntimeError) as e:
+        fc.device_mcl(np.array([0, 1, 2, 2]), np.array([0, 1], dtype=np.int32), np.array([1, 1], dtype=np.float32), 1.5)
+    assert "HIP" in str(e.value)

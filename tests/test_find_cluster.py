@@ -1,14 +1,18 @@
 """MCL clustering counterpart (swiftortho_amd/find_cluster.py) against stdout of the REAL reference script
 bin/find_cluster.py -a mcl captured by tools/refharness/make_cluster_goldens.py, plus hand-checkable graphs.
-CPU only (host stage)."""
+The Markov loop itself runs on the GPU (so_mcl): the `gpu` tests go through it (and the CLI); the CPU tests check the host
+bookkeeping -- graph components, batching, matrix construction, read-out -- with the scipy ORACLE of the loop plugged in
+(tests/mcl_scipy_oracle.py), which pins that oracle on the same goldens."""
 import json
 import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 from conftest import GOLD, ROOT
+from mcl_scipy_oracle import scipy_mcl
 
 
 def cluster_cases():
@@ -25,12 +29,43 @@ def as_sets(text):
     return sorted(tuple(sorted(l.split("\t"))) for l in text.split("\n") if l)
 
 
-@pytest.mark.parametrize("name,variant", cluster_cases())
-def test_groups_match_reference(name, variant):
+def _groups(name, variant, mcl):
     from swiftortho_amd import find_cluster as fc
     meta = json.load(open(os.path.join(GOLD, "clu_%s.json" % name)))
     a = fc.parse(["find_cluster.py", "-i", "x"] + meta["variants"][variant])
-    groups = fc.cnc(open(os.path.join(GOLD, meta["input"])), float(a["-I"]))
+    kw = {"mcl": mcl} if mcl else {}
+    return fc.cnc(open(os.path.join(GOLD, meta["input"])), float(a["-I"]), **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,variant", cluster_cases())
+def test_groups_match_reference_device_mcl(name, variant):
+    """the product path: Markov loop on the GPU"""
+    groups = _groups(name, variant, None)
+    got = "".join("\t".join(g) + "\n" for g in groups)
+    want = open(os.path.join(GOLD, "clu_%s.%s.mcl" % (name, variant))).read()
+    assert as_sets(got) == as_sets(want)
+    assert got == want
+
+
+@pytest.mark.gpu
+def test_device_mcl_equals_scipy_oracle_matrix():
+    """so_mcl returns scipy's final matrix: same structure (storage order, stored zeros), values within one float32 ulp (the
+    inflation is a correctly rounded double pow on the device, libm powf on the host)"""
+    from swiftortho_amd import find_cluster as fc
+    meta = json.load(open(os.path.join(GOLD, "clu_taxa4_colon.json")))
+    lines = [l.split("\t", 1)[1] for l in open(os.path.join(GOLD, meta["input"])) if l.split("\t")[1] <= l.split("\t")[2]]
+    names, ip, ix, dv = fc.block_matrix(lines)
+    for infl in (1.5, 2.0, 4.0):
+        a, b = fc.device_mcl(ip, ix, dv, infl), scipy_mcl(ip, ix, dv, infl)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert np.allclose(a[2], b[2], rtol=3e-7, atol=0)
+        assert fc.surviving_pairs(*a) == fc.surviving_pairs(*b)
+
+
+@pytest.mark.parametrize("name,variant", cluster_cases())
+def test_groups_match_reference(name, variant):
+    groups = _groups(name, variant, scipy_mcl)
     got = "".join("\t".join(g) + "\n" for g in groups)
     want = open(os.path.join(GOLD, "clu_%s.%s.mcl" % (name, variant))).read()
     assert as_sets(got) == as_sets(want)        # the groups as sets (what config 5 diffs)
@@ -49,14 +84,15 @@ def test_hand_checkable_graphs():
 
     a, b = ["a|1", "a|2", "a|3", "a|4"], ["b|1", "b|2", "b|3", "b|4"]
     lines = clique(["z|0", "z|1", "z|2"], 1.0) + clique(a, 1.0) + clique(b, 1.0) + ["OT\ta|1\tb|1\t0.05\n"] + clique(["c|1", "c|2", "c|3"], 2.0)
-    groups = [sorted(g) for g in fc.cnc(lines, 2.0)]
+    groups = [sorted(g) for g in fc.cnc(lines, 2.0, mcl=scipy_mcl)]
     assert groups == [["c|1", "c|2", "c|3"], sorted(a), sorted(b)]   # block -1 first, then level-2 groups ascending; z|* dropped
     # without the bridge nothing changes; with a strong bridge and gentle inflation the two cliques stay together
     strong = clique(["z|0", "z|1"], 1.0) + clique(a, 1.0) + clique(b, 1.0) + ["OT\ta|%d\tb|%d\t1.0\n" % (i, j) for i in (1, 2, 3, 4) for j in (1, 2, 3, 4)]
-    groups = [sorted(g) for g in fc.cnc(strong + clique(["c|1", "c|2"], 1.0), 1.2)]
+    groups = [sorted(g) for g in fc.cnc(strong + clique(["c|1", "c|2"], 1.0), 1.2, mcl=scipy_mcl)]
     assert sorted(a + b) in groups
 
 
+@pytest.mark.gpu
 def test_find_cluster_cli(tmp_path):
     meta = json.load(open(os.path.join(GOLD, "clu_taxa4_colon.json")))
     inp = os.path.join(GOLD, meta["input"])

@@ -17,11 +17,19 @@ def canonical(groups_text):
     return "\n".join(rows) + "\n"
 
 
-def downstream(sc_path, meta, tmp_path):
-    """the two drop-in CLIs on an .sc file -> (orth text, groups text)"""
+def downstream(sc_path, meta, tmp_path, cpu_oracle_mcl=False):
+    """the two drop-in CLIs on an .sc file -> (orth text, groups text).  bin/find_cluster.py runs its Markov loop on the GPU; on the
+    CPU side of the suite the same host code is called in-process with the scipy oracle of that loop plugged in."""
     orth = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "find_orth.py"), "-i", sc_path] + meta["find_orth_flags"], capture_output=True, check=True).stdout
     op = str(tmp_path / "x.orth")
     open(op, "wb").write(orth)
+    if cpu_oracle_mcl:
+        from mcl_scipy_oracle import scipy_mcl
+        from swiftortho_amd import find_cluster as fc
+        a = fc.parse(["find_cluster.py", "-i", op] + meta["find_cluster_flags"])
+        with open(op) as f:
+            groups = "".join("\t".join(g) + "\n" for g in fc.cnc(f, float(a["-I"]), mcl=scipy_mcl))
+        return orth, groups
     groups = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "find_cluster.py"), "-i", op] + meta["find_cluster_flags"], capture_output=True,
                             check=True).stdout
     return orth, groups.decode()
@@ -54,7 +62,7 @@ def test_downstream_of_oracle_search_c2(oracle, tmp_path):
         for k in range(P):
             o.write(open(str(tmp_path / ("%03d.sc" % k)), "rb").read())
     assert hashlib.md5(open(sc, "rb").read()).hexdigest() == meta["sc_md5"]
-    orth, groups = downstream(sc, meta, tmp_path)
+    orth, groups = downstream(sc, meta, tmp_path, cpu_oracle_mcl=True)
     check(meta, orth, groups, "pipe_c2")
 
 
