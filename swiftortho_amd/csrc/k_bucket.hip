@@ -132,8 +132,8 @@ static BkHist bk_hist_layout(u32 R, bool staged, bool skewed) {
 // consecutive staged words = two to four runs of consecutive addresses, instead of 64 lanes landing in ~R different lines
 // (the texture-address path takes a cycle per distinct line per instruction: the round-2 kernel spent more time issuing
 // its sixteen scattered stores than reading the index).
-template <bool SCATTER, bool STAGED>
-__global__ __launch_bounds__(64 * BK_WAVES, 6) void k_bkt_pass(const uint4* __restrict__ td, const u32* __restrict__ qseg, u32 NT,
+template <bool SCATTER, bool STAGED, int WPE = 6>
+__global__ __launch_bounds__(64 * BK_WAVES, WPE) void k_bkt_pass(const uint4* __restrict__ td, const u32* __restrict__ qseg, u32 NT,
                                                               const u32* __restrict__ cs_hoff, const u32* __restrict__ cs_base,
                                                               const u64* __restrict__ cs_kbase, const u32* __restrict__ dk32,
                                                               BktLayout L, BkHist HL, u32* __restrict__ mat,
@@ -681,7 +681,12 @@ void launch_bkt_pass(bool scatter, const void* td, const u32* qseg, u32 NT, cons
     const bool staged = scatter && staged_on && L.R <= BK_STAGE_RMAX;
     const BkHist HL = bk_hist_layout(L.R, staged, skewed);
     if (!scatter) hipLaunchKernelGGL((k_bkt_pass<false, false>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
-    else if (staged) hipLaunchKernelGGL((k_bkt_pass<true, true>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
+    else if (staged) {
+        static const int wpe = getenv("SOHIT_BK_WPE") ? atoi(getenv("SOHIT_BK_WPE")) : 6;   // waves per SIMD the register budget is cut for (tuning switch)
+        if (wpe == 5) hipLaunchKernelGGL((k_bkt_pass<true, true, 5>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
+        else if (wpe == 4) hipLaunchKernelGGL((k_bkt_pass<true, true, 4>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
+        else hipLaunchKernelGGL((k_bkt_pass<true, true, 6>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
+    }
     else hipLaunchKernelGGL((k_bkt_pass<true, false>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
 }
 

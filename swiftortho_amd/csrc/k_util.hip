@@ -139,7 +139,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_small(const u32* __restri
     }
     if (threadIdx.x == 0) *total = carry;
 }
-#define SCAN_SMALL_TILES 8  // up to 64 k values
+#define SCAN_SMALL_TILES 17  // up to 136 k values: a full batch of 65536 queries (+ 1) stays in the one-launch path
 
 size_t scan_u32_temp_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 2; }
 

@@ -8,7 +8,12 @@
 
 #define OPS(X) X(0, "v_add_u32 %0, %0, %1") X(1, "v_pk_add_u16 %0, %0, %1") X(2, "v_pk_max_i16 %0, %0, %1") X(3, "v_perm_b32 %0, %0, %1, %1") \
                X(4, "v_and_or_b32 %0, %0, %1, %1") X(5, "v_max_i32 %0, %0, %1") X(6, "v_max3_i32 %0, %0, %1, %1") X(7, "v_lshl_or_b32 %0, %0, 3, %1") \
-               X(8, "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1") X(9, "v_cndmask_b32 %0, %0, %1, vcc") X(10, "v_pk_add_i16 %0, %0, %1 clamp")
+               X(8, "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1") X(9, "v_cndmask_b32 %0, %0, %1, vcc") X(10, "v_pk_add_i16 %0, %0, %1 clamp") \
+               X(11, "v_sub_u32 %0, %0, %1") X(12, "v_and_b32 %0, %0, %1") X(13, "v_or_b32 %0, %0, %1") X(14, "v_xor_b32 %0, %0, %1") X(15, "v_lshlrev_b32 %0, 1, %0") \
+               X(16, "v_min_u32 %0, %0, %1") X(17, "v_max_u32 %0, %0, %1") X(18, "v_add3_u32 %0, %0, %1, %1") X(19, "v_mov_b32 %0, %1") X(20, "v_bfe_u32 %0, %0, 3, 8") \
+               X(21, "v_mad_u32_u24 %0, %0, %1, %1") X(22, "v_add_u16 %0, %0, %1") X(23, "v_ashrrev_i32 %0, 1, %0") X(24, "v_cmp_lt_u32 vcc, %0, %1") \
+               X(25, "v_add_f32 %0, %0, %1") X(26, "v_fma_f32 %0, %0, %1, %1") X(27, "v_sad_u8 %0, %0, %1, %1") X(28, "v_alignbit_b32 %0, %0, %1, 8") X(29, "v_lshl_add_u32 %0, %0, 2, %1") \
+               X(30, "v_max_i16 %0, %0, %1") X(31, "v_pk_sub_i16 %0, %0, %1") X(32, "v_add_co_u32 %0, vcc, %0, %1") X(33, "v_max_f32 %0, %0, %1") X(34, "v_pk_max_f16 %0, %0, %1")
 
 template <int OP, int CHAINS>
 __global__ __launch_bounds__(256) void k(int iters, unsigned seed, unsigned* out) {
