@@ -35,12 +35,23 @@ __device__ __forceinline__ void bk_wave_sync() {
 }
 
 __device__ __forceinline__ u32 bk_scan_max(u32 x) {  // inclusive max-scan over the wave (DPP)
+    // (a 16-bit v_max_u16_dpp form, 2.4 against 4.2 cycles in isolation, was measured here: no difference in the kernel)
     x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));
     x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));
     x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));
     x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));
     x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
     x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+    return x;
+}
+
+__device__ __forceinline__ u32 bk_scan_add(u32 x) {  // inclusive add-scan over the wave (DPP; __shfl_up compiles to ds_bpermute round trips)
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
     return x;
 }
 
@@ -217,7 +228,12 @@ __global__ __launch_bounds__(64 * BK_WAVES, WPE) void k_bkt_pass(const uint4* __
     if (!SCATTER) {
         for (u32 r = lane; r < L.R; r += 64) {   // tile-major: the tile's R counts are one contiguous run (zeros included)
             u32 n = 0;
-            for (u32 cpy = 0; cpy < ncopy; ++cpy) n += s_hist[cpy * cstride + r];
+            if (ncopy == 8) {
+#pragma unroll
+                for (u32 cpy = 0; cpy < 8; ++cpy) n += s_hist[cpy * cstride + r];
+            } else {
+                for (u32 cpy = 0; cpy < ncopy; ++cpy) n += s_hist[cpy * cstride + r];
+            }
             mat[(size_t)t * L.R + r] = n;
         }
         return;
@@ -247,15 +263,19 @@ __global__ __launch_bounds__(64 * BK_WAVES, WPE) void k_bkt_pass(const uint4* __
         const u32 r = k * 64 + lane;
         myhead[k] = 0xFFFFFFFFu;
         if (k * 64 >= L.R) continue;   // wave-uniform
+        const u32 rr = min(r, L.R - 1u);   // lanes past the last range read a valid counter and contribute nothing
+        u32 cnt8[8];
         u32 n = 0;
-        if (r < L.R)
-            for (u32 cpy = 0; cpy < ncopy; ++cpy) n += s_hist[cpy * cstride + r];
-        u32 inc = n;
+        if (ncopy == 8) {   // wave-uniform; the usual case (up to 64 ranges): eight independent reads
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const u32 x = __shfl_up(inc, o);
-            if (lane >= (u32)o) inc += x;
+            for (u32 cpy = 0; cpy < 8; ++cpy) cnt8[cpy] = s_hist[cpy * cstride + rr];
+#pragma unroll
+            for (u32 cpy = 0; cpy < 8; ++cpy) n += cnt8[cpy];
+        } else {
+            for (u32 cpy = 0; cpy < ncopy; ++cpy) n += s_hist[cpy * cstride + rr];
         }
+        if (r >= L.R) n = 0;
+        const u32 inc = bk_scan_add(n);
         const unsigned long long nz = __ballot(n != 0);
         u32 run = total + inc - n;
         if (n) {
@@ -263,12 +283,21 @@ __global__ __launch_bounds__(64 * BK_WAVES, WPE) void k_bkt_pass(const uint4* __
             s_hist[HL.gbase + j] = mat[(size_t)t * L.R + r] - run;
             myhead[k] = run;
         }
-        if (r < L.R)
-            for (u32 cpy = 0; cpy < ncopy; ++cpy) {
-                const u32 c = s_hist[cpy * cstride + r];
-                s_hist[cpy * cstride + r] = run;
-                run += c;
+        if (r < L.R) {
+            if (ncopy == 8) {
+#pragma unroll
+                for (u32 cpy = 0; cpy < 8; ++cpy) {
+                    s_hist[cpy * cstride + r] = run;
+                    run += cnt8[cpy];
+                }
+            } else {
+                for (u32 cpy = 0; cpy < ncopy; ++cpy) {
+                    const u32 c = s_hist[cpy * cstride + r];
+                    s_hist[cpy * cstride + r] = run;
+                    run += c;
+                }
             }
+        }
         total += (u32)__builtin_amdgcn_readlane((int)inc, 63);
         nrun += (u32)__popcll(nz);
     }
@@ -682,7 +711,7 @@ void launch_bkt_pass(bool scatter, const void* td, const u32* qseg, u32 NT, cons
     const BkHist HL = bk_hist_layout(L.R, staged, skewed);
     if (!scatter) hipLaunchKernelGGL((k_bkt_pass<false, false>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
     else if (staged) {
-        static const int wpe = getenv("SOHIT_BK_WPE") ? atoi(getenv("SOHIT_BK_WPE")) : 6;   // waves per SIMD the register budget is cut for (tuning switch)
+        static const int wpe = getenv("SOHIT_BK_WPE") ? atoi(getenv("SOHIT_BK_WPE")) : 5;   // waves per SIMD the register budget is cut for: 5 = 93 VGPRs, no spill (6: 80 + 4 spilled dwords, 4-5 % slower on the 100k set; 4: slower)
         if (wpe == 5) hipLaunchKernelGGL((k_bkt_pass<true, true, 5>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
         else if (wpe == 4) hipLaunchKernelGGL((k_bkt_pass<true, true, 4>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
         else hipLaunchKernelGGL((k_bkt_pass<true, true, 6>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
