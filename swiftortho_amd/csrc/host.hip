@@ -1895,21 +1895,40 @@ int so_write_sc(so_ctx* c, const so_hit* hits, int64_t n, const char* path, cons
     return guarded(c, [&] {
         FILE* f = fopen(path, (mode && mode[0] == 'a') ? "ab" : "wb");
         if (!f) throw SoError(std::string("cannot open output ") + path);
-        std::string buf;
+        // rows are formatted in slabs of 32768 by a few threads (f2s is log10 / pow / snprintf per row: 1.6 M rows took longer to
+        // print than to search), written in order
+        const int64_t SLAB = 32768;
+        const unsigned nt = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())), (n + SLAB - 1) / SLAB));
         bool ok = true;
+        std::exception_ptr err;
+        std::mutex mu;
         try {
-            for (int64_t i = 0; i < n && ok; ++i) {
-                buf += format_hit(c, hits[i]);
-                if (buf.size() > (1u << 22)) {
-                    ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
-                    buf.clear();
+            for (int64_t base = 0; base < n && ok; base += SLAB * nt) {
+                std::vector<std::string> bufs(nt);
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < nt; ++t) {
+                    const int64_t lo = base + (int64_t)t * SLAB, hi = std::min<int64_t>(n, lo + SLAB);
+                    if (lo >= hi) break;
+                    th.emplace_back([&, t, lo, hi] {
+                        try {
+                            std::string& b = bufs[t];
+                            b.reserve((size_t)(hi - lo) * 96);
+                            for (int64_t i = lo; i < hi; ++i) b += format_hit(c, hits[i]);
+                        } catch (...) {
+                            std::lock_guard<std::mutex> g(mu);
+                            if (!err) err = std::current_exception();
+                        }
+                    });
                 }
+                for (auto& x : th) x.join();
+                if (err) std::rethrow_exception(err);
+                for (unsigned t = 0; t < nt && ok; ++t)
+                    if (!bufs[t].empty()) ok = fwrite(bufs[t].data(), 1, bufs[t].size(), f) == bufs[t].size();
             }
         } catch (...) {
             fclose(f);
             throw;
         }
-        if (ok && !buf.empty()) ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
         if (fclose(f) != 0) ok = false;
         if (!ok) throw SoError(std::string("short write to ") + path + " (disk full or I/O error)");
     });

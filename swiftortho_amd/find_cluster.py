@@ -194,60 +194,105 @@ def mcl_block(edge_lines, inflation, mcl=device_mcl):
         yield [names[e] for e in comp]
 
 
+def _component_labels(n, u, v):
+    """connected components of an undirected graph on nodes 0 .. n-1: label = smallest node of the component (min-label propagation
+    with pointer jumping)"""
+    lab = np.arange(n, dtype=np.int64)
+    if len(u) == 0:
+        return lab
+    while True:
+        new = lab.copy()
+        m = np.minimum(lab[u], lab[v])
+        np.minimum.at(new, u, m)
+        np.minimum.at(new, v, m)
+        while True:
+            nn = new[new]
+            if np.array_equal(nn, new):
+                break
+            new = nn
+        if np.array_equal(new, lab):
+            return lab
+        lab = new
+
+
+def _numbered_components(pairs_u, pairs_v):
+    """what `for flag, comp in enumerate(connected_components(G))` assigns after `G.add_edge(u, v)` for the pairs in order: nodes are
+    known in order of first appearance (u before v), components are numbered in order of their first node.
+    -> (node values in insertion order, component number of each of them)"""
+    seq = np.empty(2 * len(pairs_u), dtype=np.int64)
+    seq[0::2], seq[1::2] = pairs_u, pairs_v
+    vals, first = np.unique(seq, return_index=True)
+    order = np.argsort(first, kind='stable')
+    nodes = vals[order]                                  # insertion order
+    rank = np.empty(len(vals), dtype=np.int64)
+    rank[order] = np.arange(len(vals))
+    iu, iv = rank[np.searchsorted(vals, pairs_u)], rank[np.searchsorted(vals, pairs_v)]
+    lab = _component_labels(len(nodes), iu, iv)
+    roots = np.unique(lab)                               # ascending first node = discovery order
+    return nodes, np.searchsorted(roots, lab)
+
+
 def cnc(lines, inflation=1.5, chk=10 ** 7, mcl=device_mcl):
     """cnc (1470-1673): relation rows -> groups (lists of gene ids), in the reference's output order.  `mcl`: the Markov loop on a CSR block
-    (the device implementation; the tests pass the scipy oracle to check this host bookkeeping on CPU)"""
-    lines = list(lines)
-    nns = {}
-    for x, y, z in _rows(lines):
-        Z = float(z)
-        for a, b in ((x, y), (y, x)):
-            if a in nns:
-                if Z > nns[a][0]:
-                    nns[a] = [Z, b]
-                elif Z == nns[a][0]:
-                    nns[a].append(b)
-            else:
-                nns[a] = [Z, b]
-    g = _Graph()
-    while nns:
-        x, j = nns.popitem()
-        for y in j[1:]:
-            g.add_edge(x, y)
-    l2n = {}
-    for flag, comp in enumerate(g.components()):
-        for j in comp:
-            l2n[j] = flag
-    g2 = _Graph()
-    seen_keys = set()
-    for x, y, z in _rows(lines):
-        X, Y = l2n.get(x), l2n.get(y)
-        if X and Y:
-            key = (X, Y) if X < Y else (Y, X)
-            if key not in seen_keys:
-                seen_keys.add(key)
-                g2.add_edge(key[0], key[1])
-    n2n = {}
-    for flag, comp in enumerate(g2.components()):
-        for j in comp:
-            n2n[j] = flag
-    for i in l2n:
-        l2n[i] = n2n.get(l2n[i], -1)
-    kept = []
-    for x, y, z in _rows(lines):
-        cx, cy = l2n.get(x), l2n.get(y)
-        if cx and cy and cx == cy:
-            kept.append((cx, ('\t'.join(map(str, [cx, x, y, z])) + '\n')))
-    kept.sort(key=lambda t: (t[0], t[1].encode('latin-1')))   # LC_ALL=C sort -n: leading number, then the whole line bytewise
+    (the device implementation; the tests pass the scipy oracle to check this host bookkeeping on CPU).
+    The reference keeps Python dictionaries and networkx graphs; here genes are integers (numbered by first appearance, which is also the
+    insertion order of its best-neighbour dictionary) and each of its orders -- `popitem()` = last gene first, a graph's node order = first
+    appearance in the `add_edge` sequence, components numbered by their first node -- is reproduced as index arithmetic."""
+    rows = [r for r in _rows(lines)]
+    if not rows:
+        return []
+    xs, ys, zs = [r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows]
+    inter = [None] * (2 * len(rows))
+    inter[0::2], inter[1::2] = xs, ys
+    number = {g: k for k, g in enumerate(dict.fromkeys(inter))}
+    X = np.fromiter((number[g] for g in xs), dtype=np.int64, count=len(rows))
+    Y = np.fromiter((number[g] for g in ys), dtype=np.int64, count=len(rows))
+    Z = np.array([float(z) for z in zs], dtype=np.float64)
+    n = len(number)
+    # level 1: every gene linked to its best-scoring neighbour(s); the dictionary is emptied last gene first, a gene's ties in file order
+    best = np.full(n, -np.inf)
+    np.maximum.at(best, X, Z)
+    np.maximum.at(best, Y, Z)
+    a = np.concatenate([X, Y])
+    b = np.concatenate([Y, X])
+    ridx = np.concatenate([np.arange(len(rows)) * 2, np.arange(len(rows)) * 2 + 1])   # (x, y) of a row before its (y, x)
+    tie = np.concatenate([Z, Z]) == best[a]
+    a, b, ridx = a[tie], b[tie], ridx[tie]
+    o = np.lexsort((ridx, -a))
+    genes1, comp1_of_node = _numbered_components(a[o], b[o])
+    comp1 = np.zeros(n, dtype=np.int64)
+    comp1[genes1] = comp1_of_node
+    # level 2: components joined by an edge -- seen only when BOTH component numbers are non-zero
+    cX, cY = comp1[X], comp1[Y]
+    m = (cX != 0) & (cY != 0)
+    k0, k1 = np.minimum(cX[m], cY[m]), np.maximum(cX[m], cY[m])
+    nc = int(comp1.max()) + 2
+    key = k0 * nc + k1
+    _, first = np.unique(key, return_index=True)
+    first.sort()
+    nodes2, comp2_of_node = _numbered_components(k0[first], k1[first])
+    group_of_comp = np.full(nc, -1, dtype=np.int64)
+    group_of_comp[nodes2] = comp2_of_node
+    grp = group_of_comp[comp1]
+    # edges inside one level-2 group whose number is non-zero (-1, the pool of unmerged components, included)
+    gx, gy = grp[X], grp[Y]
+    keep = np.flatnonzero((gx != 0) & (gy != 0) & (gx == gy))
+    klines = [('%d\t%s\t%s\t%s\n' % (int(gx[r]), xs[r], ys[r], zs[r])) for r in keep.tolist()]
+    if klines:
+        kb = np.array([l.encode('latin-1') for l in klines], dtype=np.bytes_)
+        order = np.lexsort((kb, gx[keep]))               # LC_ALL=C sort -n: leading number, then the whole line bytewise
+    else:
+        order = np.zeros(0, dtype=np.int64)
     out, batch, cls, flag = [], [], None, 0
-    for cx, line in kept:
-        c = line.split('\t', 2)[0]
+    kcls = gx[keep]
+    for i in order.tolist():
+        c = int(kcls[i])
         if c != cls:
             if flag > chk:
                 out.extend(mcl_block(batch, inflation, mcl))
                 batch, flag = [], 0
             cls = c
-        batch.append(line.split('\t', 1)[1])
+        batch.append(klines[i].split('\t', 1)[1])
         flag += 1
     out.extend(mcl_block(batch, inflation, mcl))
     return out
