@@ -1025,7 +1025,9 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         }
         if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] bucketed pass: wb %d ranges %u buckets %u tiles %u hits %u of %u\n", wb, L.R, nb, NT, Hv, H);
         // best diagonal per subject bucket by bucket (k_bkt_best) when first-touch keys fit its 44-bit field; else the sorted path below
-        bbest = !(getenv("SOHIT_BUCKET_BEST") && atoi(getenv("SOHIT_BUCKET_BEST")) == 0) && !ft_walk && (kl.ba + kl.bp + ft_bits_entry <= 44);
+        // ... and a chained ungapped score fits the 20 bits k_bkt_best packs above them (at most 11 per residue of the shorter sequence)
+        bbest = !(getenv("SOHIT_BUCKET_BEST") && atoi(getenv("SOHIT_BUCKET_BEST")) == 0) && !ft_walk && (kl.ba + kl.bp + ft_bits_entry <= 44) &&
+                (u64)std::min<u32>(b.maxqlen, ch.maxslen) * 11ull < (1ull << 20);
         launch_ungap(b.keys2.p, Hv, kl, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.shard.p,
                      shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
         bL = L, bnb = nb;
@@ -1153,9 +1155,20 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     launch_iota(b.order.p, NS, c->st);
     int qshift = 0;  // where the query sits in the final sort's key stream (b.c_ft2)
     if (ftbits + kl.bq <= 64) {
-        ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(NS, 64));
         launch_combine_q_ft(c_qp, c_ftp, NS, ftbits, bsp, b.tmp64.p, c->st);
-        sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, b.order.p, b.order2.p, NS, ftbits - bsp + 1 + kl.bq, c->st);
+        static const bool cand_seg = !(getenv("SOHIT_CAND_SEGSORT") && atoi(getenv("SOHIT_CAND_SEGSORT")) == 0);
+        if (bbest && cand_seg && bL.nqp >= 256) {
+            // k_bkt_best wrote the candidates query-major: a query's segment = [ccnt[q * R], ccnt[(q + 1) * R]); only the first-touch bits
+            // are sorted, inside the segments (the query bits stay on top of the sort word for k_emit_cands)
+            b.qseg.ensure((size_t)b.nq + 4);
+            launch_stride_gather(b.bccnt.p, bL.R, bL.nqp + 1, b.qseg.p, c->st);
+            ensure_sort_tmp(c, sort_pairs_u64_u32_seg_temp_bytes(NS, bL.nqp, 0, ftbits - bsp + 1));
+            sort_pairs_u64_u32_seg(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, b.order.p, b.order2.p, NS, bL.nqp, b.qseg.p, 0,
+                                   ftbits - bsp + 1, c->st);
+        } else {
+            ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(NS, 64));
+            sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, b.order.p, b.order2.p, NS, ftbits - bsp + 1 + kl.bq, c->st);
+        }
         std::swap(b.order.p, b.order2.p);
         std::swap(b.order.cap, b.order2.cap);
         qshift = ftbits - bsp + 1;
@@ -1197,11 +1210,24 @@ struct HitCache {
         p = nullptr, bytes = 0;
         return r;
     }
+    // returning a large array to the system (munmap of 130 MB: ~18 ms) is not the caller's business: a detached thread does it
+    static void release(so_hit* q) {
+        if (!q) return;
+        if (malloc_usable_size(q) < ((size_t)8 << 20)) {
+            free(q);
+            return;
+        }
+        try {
+            std::thread([q] { free(q); }).detach();
+        } catch (...) {
+            free(q);
+        }
+    }
     void give(so_hit* q) {
         if (!q) return;
         const size_t b = malloc_usable_size(q);
         if (!enabled() || b < ((size_t)1 << 20) || b > ((size_t)2 << 30)) {  // a 1 M-protein result (24 GB) is not worth holding on to
-            free(q);
+            release(q);
             return;
         }
         so_hit* drop = q;
@@ -1209,7 +1235,7 @@ struct HitCache {
             std::lock_guard<std::mutex> g(mu);
             if (b > bytes) drop = p, p = q, bytes = b;
         }
-        free(drop);
+        release(drop);
     }
     void clear() {
         size_t n;

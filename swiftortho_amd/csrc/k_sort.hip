@@ -98,6 +98,42 @@ void sort_keys_u64_seg(void* temp, size_t temp_bytes, const u64* in, u64* out, s
     HIP_CHECK(seg_sort_dispatch(temp, temp_bytes, in, out, n, nseg, seg, seg + 1, begin_bit, end_bit, st));
 }
 
+// ---- segmented (key, value) variant: the candidates of a bucketed pass leave k_bkt_best query-major, so ordering them by first-touch
+// key inside each query needs the key's low bits only -- the query bits on top of the sort word stay where they are (k_emit_cands
+// reads them) and are not sorted: four 8-bit passes inside LDS-sized segments instead of six device-wide ones.
+template <class Cfg>
+static hipError_t seg_sort_pairs(void* temp, size_t& bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, u32 nseg, const u32* sb,
+                                 const u32* se, int b0, int b1, hipStream_t st) {
+    return rocprim::segmented_radix_sort_pairs<Cfg>(temp, bytes, kin, kout, vin, vout, (unsigned)n, nseg, sb, se, (unsigned)b0, (unsigned)b1, st, false);
+}
+static hipError_t seg_sort_pairs_dispatch(void* temp, size_t& bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, u32 nseg,
+                                          const u32* sb, const u32* se, int b0, int b1, hipStream_t st) {
+    static const int v = getenv("SOHIT_CSEG_CFG") ? atoi(getenv("SOHIT_CSEG_CFG")) : -1;   // tuning switch: 0 default, 1 = 256 x 16, 2 = 512 x 16, 3 = 1024 x 16
+    const size_t avg = nseg ? n / nseg : 0;
+    const int cfg = v >= 0 ? v : avg >= 6144 ? 3 : avg >= 3072 ? 2 : avg >= 1024 ? 1 : 0;
+    if (cfg == 3) return seg_sort_pairs<SegCfg<16, 1024>>(temp, bytes, kin, kout, vin, vout, n, nseg, sb, se, b0, b1, st);
+    if (cfg == 2) return seg_sort_pairs<SegCfg<16, 512>>(temp, bytes, kin, kout, vin, vout, n, nseg, sb, se, b0, b1, st);
+    if (cfg == 1) return seg_sort_pairs<SegCfg<16>>(temp, bytes, kin, kout, vin, vout, n, nseg, sb, se, b0, b1, st);
+    return seg_sort_pairs<rocprim::default_config>(temp, bytes, kin, kout, vin, vout, n, nseg, sb, se, b0, b1, st);
+}
+size_t sort_pairs_u64_u32_seg_temp_bytes(size_t n, u32 nseg, int begin_bit, int end_bit) {
+    size_t bytes = 0;
+    (void)seg_sort_pairs_dispatch(nullptr, bytes, nullptr, nullptr, nullptr, nullptr, n, nseg, nullptr, nullptr, begin_bit, end_bit, (hipStream_t)0);
+    return bytes;
+}
+void sort_pairs_u64_u32_seg(void* temp, size_t temp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, u32 nseg, const u32* seg,
+                            int begin_bit, int end_bit, hipStream_t st) {
+    if (n == 0) return;
+    HIP_CHECK(seg_sort_pairs_dispatch(temp, temp_bytes, kin, kout, vin, vout, n, nseg, seg, seg + 1, begin_bit, end_bit, st));
+}
+__global__ __launch_bounds__(256) void k_stride_gather(const u32* __restrict__ src, u32 stride, u32 n, u32* __restrict__ dst) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) dst[i] = src[(size_t)i * stride];
+}
+void launch_stride_gather(const u32* src, u32 stride, u32 n, u32* dst, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_stride_gather, dim3((n + 255) / 256), dim3(256), 0, st, src, stride, n, dst);
+}
+
 // (bucket id, index entry) pairs of the index build
 size_t sort_pairs_u32_u64_temp_bytes(size_t n, int bits) {
     size_t bytes = 0;

@@ -16,6 +16,10 @@ void launch_query_segments(const u32* hoff, size_t T, const u32* qoff, u32 nq, i
 size_t sort_keys_u64_seg_temp_bytes(size_t n, u32 nseg, int begin_bit, int end_bit);
 void sort_keys_u64_seg(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* seg, int begin_bit,
                        int end_bit, hipStream_t st);
+size_t sort_pairs_u64_u32_seg_temp_bytes(size_t n, u32 nseg, int begin_bit, int end_bit);
+void sort_pairs_u64_u32_seg(void* temp, size_t temp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, u32 nseg,
+                            const u32* seg /*nseg + 1 offsets*/, int begin_bit, int end_bit, hipStream_t st);
+void launch_stride_gather(const u32* src, u32 stride, u32 n, u32* dst, hipStream_t st);   // dst[i] = src[i * stride]
 size_t sort_pairs_u64_u32_temp_bytes(size_t n, int bits);
 void sort_pairs_u64_u32(void* temp, size_t temp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, int bits,
                         hipStream_t st);

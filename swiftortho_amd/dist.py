@@ -114,7 +114,9 @@ def _staging(role, nbytes, pin):
     import torch
     buf = _pinned.get(role)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 16) * 5 // 4, dtype=torch.uint8, pin_memory=pin)
+        # head room for the next, slightly larger result -- but not on multi-GB gathers (a 1 M-protein result is 24 GB of records)
+        cap = max(nbytes, 1 << 16)
+        buf = torch.empty(cap * 5 // 4 if cap < (1 << 30) else cap, dtype=torch.uint8, pin_memory=pin)
         _pinned[role] = buf
     return buf
 

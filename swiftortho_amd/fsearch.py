@@ -171,6 +171,9 @@ class DeviceHits:
         """uint8 torch tensor (n * 80 bytes) on the ctx's GPU holding a copy of the records (device-to-device)."""
         import torch
         t = torch.empty(self.n * self.record_bytes, dtype=torch.uint8, device=device or torch.device("cuda", torch.cuda.current_device()))
+        # the block comes from torch's caching allocator on torch's stream and is filled from the library's own stream: nothing torch
+        # queued earlier on that block may still be running when the copy starts
+        torch.cuda.current_stream(t.device).synchronize()
         self.s._chk(self.s.L.so_device_hits_copy(self.s.h, C.c_void_p(t.data_ptr()), self.n))
         return t
 
@@ -179,10 +182,17 @@ class DeviceHits:
 
 
 def hits_from_bytes(s, data):
-    """so_hit records gathered from other ranks (bytes / uint8 array) -> ctypes array usable with so_write_sc / so_format_hit"""
+    """so_hit records gathered from other ranks (bytes / uint8 array) -> ctypes array usable with so_write_sc / so_format_hit.
+    A writable contiguous uint8 array (the pinned staging buffer of the gather) is wrapped in place: a 1 M-protein result is 24 GB
+    and must not be copied again on rank 0."""
+    rec = C.sizeof(_lib.SoHit)
+    if isinstance(data, np.ndarray) and data.dtype == np.uint8 and data.flags.c_contiguous and data.flags.writeable and data.size >= rec:
+        n = data.size // rec
+        arr = (_lib.SoHit * n).from_buffer(data)
+        return arr, n
     buf = np.ascontiguousarray(data, dtype=np.uint8).tobytes()
-    n = len(buf) // C.sizeof(_lib.SoHit)
-    arr = (_lib.SoHit * max(n, 1)).from_buffer_copy(buf + b"\0" * (C.sizeof(_lib.SoHit) if n == 0 else 0))
+    n = len(buf) // rec
+    arr = (_lib.SoHit * max(n, 1)).from_buffer_copy(buf + b"\0" * (rec if n == 0 else 0))
     return arr, n
 
 
