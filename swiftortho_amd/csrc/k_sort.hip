@@ -110,7 +110,9 @@ static hipError_t seg_sort_pairs_dispatch(void* temp, size_t& bytes, const u64* 
                                           const u32* sb, const u32* se, int b0, int b1, hipStream_t st) {
     static const int v = getenv("SOHIT_CSEG_CFG") ? atoi(getenv("SOHIT_CSEG_CFG")) : -1;   // tuning switch: 0 default, 1 = 256 x 16, 2 = 512 x 16, 3 = 1024 x 16
     const size_t avg = nseg ? n / nseg : 0;
-    const int cfg = v >= 0 ? v : avg >= 6144 ? 3 : avg >= 3072 ? 2 : avg >= 1024 ? 1 : 0;
+    // 100k weight-6 set (7.5 k candidates per query and pass), best / candidate-order stage per step: device-wide sort 166.7 ms, 256 x 16
+    // 166.7, 512 x 16 145.4, 1024 x 16 148.9
+    const int cfg = v >= 0 ? v : avg >= 3072 ? 2 : avg >= 1024 ? 1 : 0;
     if (cfg == 3) return seg_sort_pairs<SegCfg<16, 1024>>(temp, bytes, kin, kout, vin, vout, n, nseg, sb, se, b0, b1, st);
     if (cfg == 2) return seg_sort_pairs<SegCfg<16, 512>>(temp, bytes, kin, kout, vin, vout, n, nseg, sb, se, b0, b1, st);
     if (cfg == 1) return seg_sort_pairs<SegCfg<16>>(temp, bytes, kin, kout, vin, vout, n, nseg, sb, se, b0, b1, st);

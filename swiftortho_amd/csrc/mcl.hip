@@ -12,9 +12,11 @@
 //     of row j (distinct columns), a hash table (LDS for rows of up to 1024 products, global scratch beyond) keeps sums[k], and
 //     an order array indexed by the first-touch ordinal gives the output order without a sort.  Stored zeros (pruned entries)
 //     take part exactly like scipy's: they touch columns and can decide the order;
-//   * inflation: float32 power through the double-precision pow rounded once (scipy / numpy call libm's powf, within 0.52 ulp:
-//     the two can differ in the last bit in rare cases -- a value would have to sit within one ulp of the 1e-5 threshold for that
-//     to change a decision; the goldens pin the outcome on the test graphs);
+//   * inflation: float32 power through the double-precision pow rounded once = the correctly rounded value.  numpy's float32 power is
+//     CPU-dispatched (AVX512: an SVML routine that differs from libm's powf and from the correctly rounded value by one ulp in ~21 %
+//     of inputs), so the reference's own last bits depend on the host; a last-bit difference changes a pruning decision only for a
+//     value within one ulp of the threshold, and contracting runs are insensitive to it (goldens + random-graph tests: same structure,
+//     same read-out, values within one ulp);
 //   * pruning keeps the entry and stores 0 (the reference assigns into .data), so the matrix structure -- which the reference's
 //     final read-out zips against -- is scipy's.
 // Product code behind the C ABI (so_mcl); the scipy loop survives only in tests/ as the oracle.

@@ -149,7 +149,7 @@ def _block_matrix_sequential(X, Y, Z, dmx):
     return indptr, np.array([k[1] for k in keys], dtype=np.int32), np.array([cell[k] for k in keys], dtype=np.float32)
 
 
-def device_mcl(indptr, indices, data, inflation, device=0):
+def device_mcl(indptr, indices, data, inflation, device=0, rounds=100):
     """the Markov loop on the GPU (libsohit so_mcl, csrc/mcl.hip) -> the final matrix as (indptr, indices, data) in the reference's
     storage order, stored zeros included.  No CPU path: raises when the HIP library or a device is missing."""
     import ctypes as C
@@ -159,7 +159,7 @@ def device_mcl(indptr, indices, data, inflation, device=0):
     ip = np.ascontiguousarray(indptr, dtype=np.int64)
     ix = np.ascontiguousarray(indices, dtype=np.int32)
     dv = np.ascontiguousarray(data, dtype=np.float32)
-    rc = L.so_mcl(device, len(ip) - 1, ip.ctypes.data, ix.ctypes.data if len(ix) else None, dv.ctypes.data if len(dv) else None, float(inflation), 100, 5,
+    rc = L.so_mcl(device, len(ip) - 1, ip.ctypes.data, ix.ctypes.data if len(ix) else None, dv.ctypes.data if len(dv) else None, float(inflation), int(rounds), 5,
                   1e-5, 1e-5, 1e-8, C.byref(res))
     if rc != 0:
         raise RuntimeError(L.so_mcl_last_error().decode())
