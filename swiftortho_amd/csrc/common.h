@@ -17,6 +17,14 @@ typedef uint8_t u8;
 struct SoError : std::runtime_error {
     explicit SoError(const std::string& m) : std::runtime_error(m) {}
 };
+// a query batch's 32-bit candidate store is full: the caller halves the batch
+struct CandOverflow : SoError {
+    CandOverflow() : SoError("a query batch collected >= 2^32 candidates") {}
+};
+// a device allocation failed: inside a query batch the caller frees the batch's buffers and halves the batch
+struct DevOom : SoError {
+    explicit DevOom(size_t bytes) : SoError("HIP error out of memory: device allocation of " + std::to_string(bytes) + " bytes failed") {}
+};
 
 #define HIP_CHECK(expr)                                                                                   \
     do {                                                                                                  \
@@ -35,7 +43,14 @@ struct DevBuf {
         if (n <= cap) return;
         size_t nc = n + n / 8 + 64;
         T* np_ = nullptr;
-        HIP_CHECK(hipMalloc((void**)&np_, nc * sizeof(T)));
+        {
+            const hipError_t e = hipMalloc((void**)&np_, nc * sizeof(T));
+            if (e == hipErrorOutOfMemory) {
+                (void)hipGetLastError();
+                throw DevOom(nc * sizeof(T));
+            }
+            HIP_CHECK(e);
+        }
         // SOHIT_POISON=<byte>: fill every fresh allocation (tests: results must not depend on what device memory held before)
         static const char* poison = getenv("SOHIT_POISON");
         if (poison) HIP_CHECK(hipMemset(np_, (int)strtol(poison, nullptr, 0) & 0xFF, nc * sizeof(T)));

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <malloc.h>
 #include <memory>
@@ -191,6 +192,7 @@ void build_hash_classes(const bool present[256], const std::vector<std::array<in
 }
 
 struct ChunkIndex {
+    u64 s2 = 0;  // sum of squared bucket sizes (seed hits a reference-like query window expects: s2 / E)
     i64 seq_lo = 0, seq_hi = 0;
     u32 p_lo = 0, p_hi = 0;
     u32 E = 0;
@@ -255,7 +257,9 @@ struct so_ctx {
     hipEvent_t ev_rows = nullptr, ev_rows_done = nullptr;
     bool rows_in_flight = false;
     size_t max_hits_per_pass = (size_t)1 << 30;
-    u32 max_batch = 65536;  // queries per device batch (config 3: 16384 -> 124 ms, 32768 -> 111, 65536 -> 109, 131072 -> 115: fewer passes, still two batches to overlap row emission)
+    u32 max_batch = 131072;  // queries per device batch.  Round 3, config 3 (100k queries), same box: 25000 64.1 ms, 33334 63.0, 2 x 50000 63.0,
+                             // 65536 + 34464 62.1, one batch of 100000 59.1 -- larger launches beat overlapping one batch's row download with
+                             // the next batch's kernels (round 2, when the host side was slower: 65536 109 ms, 131072 115)
     // device SEG: tables, symbol folding of the loaded query set
     DevBuf<u8> d_segtab, d_symmap, d_upmap, d_segmask;
     bool seg_on_device = false;
@@ -654,6 +658,7 @@ void build_index(so_ctx* c) {
             HIP_CHECK(hipMemsetAsync(ch->hkey.p, 0xFF, 1024 * sizeof(u32), c->st));
         }
         ch->threshold = chunk_threshold(c, ch->ucnt.p, (u64)E, s2, (u64)ch->U);
+        ch->s2 = s2;
         HIP_CHECK(hipStreamSynchronize(c->st));
         c->cnt.index_entries += ch->E;
         c->chunks.push_back(std::move(ch));
@@ -1079,7 +1084,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     if (lk_ablation) return;  // ablation runs time the lookup only: keys are not valid
     u64* c_ftp = nullptr;   // candidates of the pass: first-touch key, query, [subject, score, qi, qj]
     u32 *c_qp = nullptr, *c_recp = nullptr;
-    u32 NS = 0;
+    u32 NS = 0, maxseg = 0xFFFFFFFFu;  // candidates of the pass; the longest per-query segment (sparse path only)
     for (;;) {
         // contiguous pass list; the group counters and the pass total come back in one synchronisation
         u32* shard_off = b.shard.p + UG_SHARDS;
@@ -1132,9 +1137,13 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(NP, 64));
         sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, q_qs, b.p_qs2.p, b.pidx.p, b.pidx2.p, NP, kl.bs + kl.bq, c->st);
         b.flags.ensure((size_t)NP + 4), b.gidx.ensure((size_t)NP + 4);
-        launch_seg_flags(b.p_qs2.p, NP, b.flags.p, c->st);
+        c->d_small.ensure(16);
+        launch_seg_flags(b.p_qs2.p, NP, b.flags.p, c->d_small.p, c->st);
         const u32* dS = scan_u32(b.flags.p, b.gidx.p, NP, false, c->d_scan_tmp.p, c->st);
-        NS = d2h_u32(c, dS);
+        // per-query candidate segments and the longest one (d_small[0]), fetched with the candidate total
+        b.qseg.ensure((size_t)b.nq + 4);
+        launch_qseg(b.p_qs2.p, NP, b.gidx.p, dS, kl.bs, b.nq, b.qseg.p, c->d_small.p, c->st);
+        d2h_pair(c, dS, maxseg, NS);
         b.shead.ensure((size_t)NS + 2);
         if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] seed pass: queries %u..%u hits %u seeds %u pass records %u candidates %u\n", qa, qb, H, K, NP, NS);
         launch_group_list(b.flags.p, b.gidx.p, NP, b.shead.p, c->st);
@@ -1148,9 +1157,25 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         c->cnt.group_ms += (wall() - t1) * 1e3;
         return;
     }
+    const int ftbits = kl.ba + kl.bp + ft_bits_entry;
+    static const bool cand_lds = !(getenv("SOHIT_CAND_LDS") && atoi(getenv("SOHIT_CAND_LDS")) == 0);
+    if (!bbest && cand_lds && maxseg <= (u32)cand_order_lds_max() && ftbits - bsp + 1 <= cand_order_lds_key_bits()) {
+        // sparse path: every query's candidates fit the LDS sort -- ordered and written to the candidate store by one kernel
+        const u32 base = b.chunk_base.back();
+        const char* lim = getenv("SOHIT_CAND_LIMIT");  // (tests lower the limit to exercise the split)
+        if ((u64)base + NS >= (lim ? (u64)atoll(lim) : 0xFFFFFFF0ull)) throw CandOverflow();
+        b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
+        b.cand_rec.ensure(4 * ((size_t)base + NS) + 16, true, c->st);
+        launch_cand_order_lds(c_ftp, c_recp, b.qseg.p, b.nq, maxseg, bsp, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, c->st);
+        b.chunk_base.back() = base + NS;
+        c->cnt.candidates += NS;
+        sc.lap("group.best_order");
+        c->cnt.seed_ms += (t1 - t0) * 1e3;
+        c->cnt.group_ms += (wall() - t1) * 1e3;
+        return;
+    }
     // order candidates by (query, first-touch): one sort on (q << ftbits | ft) when that fits 64 bits,
     // else sort by first-touch and then stable-sort by query; only the populated bits are sorted
-    const int ftbits = kl.ba + kl.bp + ft_bits_entry;
     b.order.ensure((size_t)NS + 2), b.order2.ensure((size_t)NS + 2), b.tmp64.ensure((size_t)NS + 2), b.c_ft2.ensure((size_t)NS + 2);
     launch_iota(b.order.p, NS, c->st);
     int qshift = 0;  // where the query sits in the final sort's key stream (b.c_ft2)
@@ -1180,7 +1205,8 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     }
     // append to the candidate store
     const u32 base = b.chunk_base.back();
-    if ((u64)base + NS >= 0xFFFFFFF0ull) throw SoError("a query batch collected >= 2^32 candidates: lower SOHIT_BATCH");
+    const char* lim = getenv("SOHIT_CAND_LIMIT");  // (tests lower the limit to exercise the split)
+    if ((u64)base + NS >= (lim ? (u64)atoll(lim) : 0xFFFFFFF0ull)) throw CandOverflow();  // search_loaded() splits the batch and runs the halves
     b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
     b.cand_rec.ensure(4 * ((size_t)base + NS) + 16, true, c->st);
     b.segfirst.ensure((size_t)b.nq + 4);
@@ -1563,38 +1589,64 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
     const int nchunks = (int)c->chunks.size();
     if (const char* e = getenv("SOHIT_BATCH")) c->max_batch = (u32)std::max(1, atoi(e));
     if (const char* e = getenv("SOHIT_MAX_HITS")) c->max_hits_per_pass = (size_t)std::max(1ll, atoll(e));
-    // A batch's candidate store is indexed with 32 bits, and a query has at most one candidate per reference sequence:
-    // unless SOHIT_BATCH says otherwise, keep queries x reference sequences below 2^32 so that the store cannot overflow.
-    u32 batch_q = c->max_batch;
-    if (!getenv("SOHIT_BATCH")) batch_q = (u32)std::min<u64>(batch_q, std::max<u64>(1024, 0xE0000000ull / (u64)std::max<i64>(D, 1)));
-    for (i64 b0 = st; b0 < ed; b0 += batch_q) {
-        const i64 b1 = std::min<i64>(ed, b0 + batch_q);
-        if (!c->batch) c->batch = std::make_shared<Batch>();
-        Batch& b = *static_cast<Batch*>(c->batch.get());
-        b.chunk_base.clear();
-        StageClock scp(c);
-        prepare_batch(c, b, b0, b1);
-        scp.lap("prepare_batch");
-        b.ccnt.ensure((size_t)std::max(1, nchunks) * b.nq + 4);
-        HIP_CHECK(hipMemsetAsync(b.ccnt.p, 0, ((size_t)std::max(1, nchunks) * b.nq + 4) * sizeof(u32), c->st));
-        for (int ci = 0; ci < nchunks; ++ci) seed_stage(c, b, ci);
-        phase2(c, b, out);
-        unsigned long long uc[2] = {0, 0};
-        HIP_CHECK(hipMemcpyAsync(uc, b.ucount.p, sizeof uc, hipMemcpyDeviceToHost, c->st));
-        HIP_CHECK(hipStreamSynchronize(c->st));
-        c->cnt.cells += (i64)uc[1];
-        c->cnt.n_queries += b.nq;
-        c->cnt.query_aa += b.h_off[b.nq];
-        if (getenv("SOHIT_KEEP_MASKED")) {
-            if (c->masked.empty()) c->masked_lo = st;
-            if (b.h_res.empty() && b.h_off[b.nq]) {
-                b.h_res.resize(b.h_off[b.nq] + 16);
-                HIP_CHECK(hipMemcpy(b.h_res.data(), b.dev.d_res.p, b.h_off[b.nq], hipMemcpyDeviceToHost));
-            }
-            for (u32 i = 0; i < b.nq; ++i)
-                c->masked.emplace_back((const char*)b.h_res.data() + b.h_off[i], (size_t)(b.h_off[i + 1] - b.h_off[i]));
-        }
+    // A batch's candidate store is indexed with 32 bits (and costs 20 bytes of HBM per candidate).  A query has at most one candidate per
+    // reference sequence and at most one per seed hit; the hits a query expects follow from the index itself (a window drawn like the
+    // reference's own hits sum(c^2) / sum(c) entries per chunk).  Batches are sized so that the estimate stays below 2^32 -- the sparse
+    // weight-10 seed of config 3 then runs its 100k queries as ONE batch (59.1 ms against 60.4 for 65536 + 34464 and 62.1 for three
+    // batches of 37580, same box), the 1 M-protein run keeps its 3758-query batches (106.1 s; 16384-query batches 110.5 s).  The
+    // estimate can be wrong (queries unlike the reference): nothing is emitted before a batch's seed stage has finished, so a batch whose
+    // store would overflow (seed_stage throws CandOverflow) or whose buffers do not fit the device (DevOom) is run again as two halves.
+    double est_hits = 0;
+    {
+        long double s2 = 0, e1 = 0;
+        for (auto& ch : c->chunks) s2 += (long double)ch->s2, e1 += (long double)ch->E;
+        const double avg_qlen = N ? (double)c->qry.off[(size_t)N] / (double)N : 0.;
+        if (e1 > 0) est_hits = (double)(s2 / e1) * (double)c->chunks.size() * avg_qlen;
     }
+    const double est_cands = std::max(1., std::min((double)std::max<i64>(D, 1), est_hits));
+    i64 batch_q = std::max<i64>(1, c->max_batch);
+    if (!getenv("SOHIT_BATCH")) batch_q = std::min<i64>(batch_q, std::max<i64>(1024, (i64)((double)0xE0000000ull / est_cands)));
+    std::function<void(i64, i64)> run_batch = [&](i64 b0, i64 b1) {
+        const so_counters keep = c->cnt;
+        try {
+            if (!c->batch) c->batch = std::make_shared<Batch>();
+            Batch& b = *static_cast<Batch*>(c->batch.get());
+            b.chunk_base.clear();
+            StageClock scp(c);
+            prepare_batch(c, b, b0, b1);
+            scp.lap("prepare_batch");
+            b.ccnt.ensure((size_t)std::max(1, nchunks) * b.nq + 4);
+            HIP_CHECK(hipMemsetAsync(b.ccnt.p, 0, ((size_t)std::max(1, nchunks) * b.nq + 4) * sizeof(u32), c->st));
+            for (int ci = 0; ci < nchunks; ++ci) seed_stage(c, b, ci);
+            phase2(c, b, out);
+            unsigned long long uc[2] = {0, 0};
+            HIP_CHECK(hipMemcpyAsync(uc, b.ucount.p, sizeof uc, hipMemcpyDeviceToHost, c->st));
+            HIP_CHECK(hipStreamSynchronize(c->st));
+            c->cnt.cells += (i64)uc[1];
+            c->cnt.n_queries += b.nq;
+            c->cnt.query_aa += b.h_off[b.nq];
+            if (getenv("SOHIT_KEEP_MASKED")) {
+                if (c->masked.empty()) c->masked_lo = st;
+                if (b.h_res.empty() && b.h_off[b.nq]) {
+                    b.h_res.resize(b.h_off[b.nq] + 16);
+                    HIP_CHECK(hipMemcpy(b.h_res.data(), b.dev.d_res.p, b.h_off[b.nq], hipMemcpyDeviceToHost));
+                }
+                for (u32 i = 0; i < b.nq; ++i)
+                    c->masked.emplace_back((const char*)b.h_res.data() + b.h_off[i], (size_t)(b.h_off[i + 1] - b.h_off[i]));
+            }
+        } catch (const SoError& e) {
+            const bool oom = dynamic_cast<const DevOom*>(&e) != nullptr;
+            if (!oom && !dynamic_cast<const CandOverflow*>(&e)) throw;
+            if (b1 - b0 < 2) throw SoError(oom ? std::string(e.what()) : std::string("one query collected >= 2^32 candidates"));
+            (void)hipStreamSynchronize(c->st);
+            if (oom) c->batch.reset();  // hand the batch's buffers back before the halves allocate theirs
+            c->cnt = keep;
+            const i64 mid = b0 + (b1 - b0) / 2;
+            run_batch(b0, mid);
+            run_batch(mid, b1);
+        }
+    };
+    for (i64 b0 = st; b0 < ed; b0 += batch_q) run_batch(b0, std::min<i64>(ed, b0 + batch_q));
     emit_join(c, out);  // the last batch's rows
     c->cnt.rows += c->dev_out ? (i64)c->d_hits_n : (i64)out.n;
     c->cnt.total_ms += (wall() - t0) * 1e3;

@@ -405,9 +405,10 @@ __global__ __launch_bounds__(256) void k_compact_shards(const u32* __restrict__ 
 // pass records sorted by p_qs (idx = permutation).  Segment heads -> one candidate per segment:
 // best = max score, ties -> smallest first-touch key (first visited wins, strict `>` at 2709);
 // the candidate's order key = smallest first-touch key among the segment's passing groups.
-__global__ __launch_bounds__(256) void k_seg_flags(const u64* __restrict__ sorted_qs, u32 n, u32* __restrict__ flags) {
+__global__ __launch_bounds__(256) void k_seg_flags(const u64* __restrict__ sorted_qs, u32 n, u32* __restrict__ flags, u32* __restrict__ zero_word) {
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
+    if (i == 0 && zero_word) *zero_word = 0;  // k_qseg's running maximum
     flags[i] = (i == 0 || sorted_qs[i] != sorted_qs[i - 1]) ? 1u : 0u;
 }
 
@@ -485,6 +486,98 @@ __global__ __launch_bounds__(256) void k_seg_counts(const u32* __restrict__ out_
     if (i + 1 == n || out_q[i + 1] != q) qcnt[q] = i + 1 - seg_first[q];
 }
 
+// ---- sparse path: a query's candidates ordered inside LDS ------------------------------------------------------
+// k_best leaves the candidates (query, subject)-major, so the (query, first-touch) order the reference's spill file has is a
+// sort of the first-touch word INSIDE each query's segment: tens to hundreds of candidates per query and pass on the sparse
+// path.  k_qseg finds the segments from the sorted pass records (lower bound of q << bs; the exclusive scan of the head flags at
+// that record = the query's first candidate) together with the longest one, so the host -- which fetches the candidate total with
+// the same copy -- knows whether every segment fits the LDS sort; k_cand_order_lds then does, in ONE launch, what the library
+// path needs an index fill, a key build, a 7-pass device-wide radix sort, a gather and a count kernel for.
+__global__ __launch_bounds__(256) void k_qseg(const u64* __restrict__ sorted_qs, u32 n, const u32* __restrict__ gidx, const u32* __restrict__ total,
+                                              int bs, u32 nq, u32* __restrict__ seg /*nq + 1*/, u32* __restrict__ maxseg) {
+    const u32 q = blockIdx.x * 256u + threadIdx.x;
+    auto first_cand = [&](u32 qq) -> u32 {
+        const u64 key = (u64)qq << bs;
+        u32 lo = 0, hi = n;
+        while (lo < hi) {
+            const u32 mid = lo + ((hi - lo) >> 1);
+            if (sorted_qs[mid] < key) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo < n ? gidx[lo] : *total;
+    };
+    u32 len = 0;
+    if (q <= nq) {
+        const u32 a = first_cand(q);
+        seg[q] = a;
+        if (q < nq) len = first_cand(q + 1) - a;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) len = max(len, (u32)__shfl_xor((int)len, o));
+    if ((threadIdx.x & 63) == 0 && len) atomicMax(maxseg, len);
+}
+
+// One wave per query: sort word = (first-touch word << LB) | position in the segment (unique: ties keep the (query, subject) order,
+// as the stable library sort does), bitonic network over the next power of two, then the records are gathered in that order.
+template <int CAP, int LB>
+__global__ __launch_bounds__(64) void k_cand_order_lds(const u64* __restrict__ c_ft, const u32* __restrict__ c_rec, const u32* __restrict__ seg,
+                                                       int bsp, u32* __restrict__ out_q, u32* __restrict__ out_rec, u32* __restrict__ qcnt) {
+    __shared__ u64 s_key[CAP];
+    const u32 q = blockIdx.x, lane = threadIdx.x;
+    const u32 a = seg[q], n = seg[q + 1] - a;
+    if (!n) return;
+    if (lane == 0) qcnt[q] = n;
+    if (n == 1) {
+        if (lane == 0) {
+            out_q[a] = q;
+            *reinterpret_cast<uint4*>(out_rec + 4 * (size_t)a) = *reinterpret_cast<const uint4*>(c_rec + 4 * (size_t)a);
+        }
+        return;
+    }
+    u32 P = 2;
+    while (P < n) P <<= 1;
+    const u64 pm = (1ull << bsp) - 1ull;
+    for (u32 i = lane; i < P; i += 64) {
+        u64 k = ~0ull;
+        if (i < n) {
+            const u64 ft = c_ft[a + i];
+            k = ((((ft >> bsp) << 1) | ((ft & pm) == pm ? 1ull : 0ull)) << LB) | (u64)i;
+        }
+        s_key[i] = k;
+    }
+    __syncthreads();
+    for (u32 k = 2; k <= P; k <<= 1)
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 t = lane; t < (P >> 1); t += 64) {
+                const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const u64 x = s_key[i], y = s_key[l];
+                if ((x > y) == ((i & k) == 0)) s_key[i] = y, s_key[l] = x;
+            }
+            __syncthreads();
+        }
+    for (u32 i = lane; i < n; i += 64) {
+        const u32 r = (u32)s_key[i] & ((1u << LB) - 1u);
+        out_q[a + i] = q;
+        *reinterpret_cast<uint4*>(out_rec + 4 * (size_t)(a + i)) = *reinterpret_cast<const uint4*>(c_rec + 4 * (size_t)(a + r));
+    }
+}
+
+int cand_order_lds_max() { return 2048; }
+int cand_order_lds_key_bits() { return 64 - 11; }  // widest first-touch word the packed sort word holds
+
+void launch_qseg(const u64* sorted_qs, u32 n, const u32* gidx, const u32* total, int bs, u32 nq, u32* seg, u32* maxseg, hipStream_t st) {
+    hipLaunchKernelGGL(k_qseg, dim3((nq + 1 + 255) / 256), dim3(256), 0, st, sorted_qs, n, gidx, total, bs, nq, seg, maxseg);
+}
+
+void launch_cand_order_lds(const u64* c_ft, const u32* c_rec, const u32* seg, u32 nq, u32 maxseg, int bsp, u32* out_q, u32* out_rec, u32* qcnt,
+                           hipStream_t st) {
+    if (!nq) return;
+    if (maxseg <= 256)
+        hipLaunchKernelGGL((k_cand_order_lds<256, 11>), dim3(nq), dim3(64), 0, st, c_ft, c_rec, seg, bsp, out_q, out_rec, qcnt);
+    else
+        hipLaunchKernelGGL((k_cand_order_lds<2048, 11>), dim3(nq), dim3(64), 0, st, c_ft, c_rec, seg, bsp, out_q, out_rec, qcnt);
+}
+
 // ---- launch wrappers -------------------------------------------------------------------------------
 void launch_group_list(const u32* flags, const u32* gidx, u32 H, u32* ghead, hipStream_t st) {
     if (!H) return;
@@ -519,9 +612,9 @@ void launch_compact_shards(const u32* shard_cnt, u32* shard_off, u32 shard_cap, 
     hipLaunchKernelGGL(k_compact_shards, dim3(64, UG_SHARDS), dim3(256), 0, st, shard_cnt, shard_off, shard_cap, a0, a1, a2, b0, b1, b2);
 }
 
-void launch_seg_flags(const u64* sorted_qs, u32 n, u32* flags, hipStream_t st) {
+void launch_seg_flags(const u64* sorted_qs, u32 n, u32* flags, u32* zero_word, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_seg_flags, dim3((n + 255) / 256), dim3(256), 0, st, sorted_qs, n, flags);
+    hipLaunchKernelGGL(k_seg_flags, dim3((n + 255) / 256), dim3(256), 0, st, sorted_qs, n, flags, zero_word);
 }
 
 void launch_best(const u64* sorted_qs, const u32* idx, const u32* shead, u32 nseg, u32 n, const u64* p_sd, const u64* p_ft,

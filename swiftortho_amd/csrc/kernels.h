@@ -80,7 +80,12 @@ void launch_first_touch(bool walk, const u64* keys, u32 H, const KeyLayout& kl, 
 void launch_shard_scan(const u32* shard_cnt, u32* shard_off, hipStream_t st);
 void launch_compact_shards(const u32* shard_cnt, u32* shard_off, u32 shard_cap, const u64* a0, const u64* a1, const u64* a2, u64* b0,
                            u64* b1, u64* b2, hipStream_t st);
-void launch_seg_flags(const u64* sorted_qs, u32 n, u32* flags, hipStream_t st);
+void launch_seg_flags(const u64* sorted_qs, u32 n, u32* flags, u32* zero_word /*set to 0 (may be null)*/, hipStream_t st);
+int cand_order_lds_max();
+int cand_order_lds_key_bits();
+void launch_qseg(const u64* sorted_qs, u32 n, const u32* gidx, const u32* total, int bs, u32 nq, u32* seg, u32* maxseg, hipStream_t st);
+void launch_cand_order_lds(const u64* c_ft, const u32* c_rec, const u32* seg, u32 nq, u32 maxseg, int bsp, u32* out_q, u32* out_rec, u32* qcnt,
+                           hipStream_t st);
 void launch_best(const u64* sorted_qs, const u32* idx, const u32* shead, u32 nseg, u32 n, const u64* p_sd, const u64* p_ft,
                  u32 seq_lo, int bs, u64* c_ft, u32* c_q, u32* c_rec, hipStream_t st);
 void launch_gather_u32_as_u64(const u32* src, const u32* idx, u32 n, u64* dst, hipStream_t st);

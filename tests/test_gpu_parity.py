@@ -205,6 +205,24 @@ def test_query_subrange_and_small_batches(fs, oracle, tmp_path, monkeypatch):
     oracle_vs_gpu(fs, oracle, synthprot.synthprot(500, 120, 82), kw, tmp_path, sub=(100, 333))
 
 
+def test_full_candidate_store_splits_the_batch(fs, oracle, tmp_path, monkeypatch):
+    """A batch whose 32-bit candidate store would overflow is run again as two halves (host.hip run_batch).  SOHIT_CAND_LIMIT lowers
+    the limit from 2^32 so that the first attempt -- and the first halves -- overflow: rows, candidates and counters are unchanged;
+    a limit below one query's own candidates is an error, not a loop."""
+    from swiftortho_amd import synthprot
+    fa = synthprot.synthprot(500, 120, 82)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=200, step=1, v=500, expect=1e-5, flt="T")
+    c0, _ = oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+    assert c0["n_chunks"] >= 2 and c0["candidates"] > 2000
+    monkeypatch.setenv("SOHIT_CAND_LIMIT", str(c0["candidates"] // 5))
+    c1, _ = oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+    for k in ("candidates", "seed_hits", "groups", "rows", "n_queries", "query_aa", "alignments"):
+        assert c1[k] == c0[k], k
+    monkeypatch.setenv("SOHIT_CAND_LIMIT", "1")
+    with pytest.raises(Exception, match="one query collected"):
+        gpu_rows(fs, fa, fa, kw, -1, -1)
+
+
 def test_aligner_launch_order_and_result_cache_do_not_change_rows(fs, oracle, tmp_path, monkeypatch):
     """The score-only aligner launches are ordered by band rows (k_task_rows + radix sort, lists of >= 4096 tasks) and a released
     result array is reused by the next search (so_free_hits keeps one): with both switched off, and over repeated searches on one
@@ -633,6 +651,27 @@ def test_two_rank_search_equals_one_rank(tmp_path):
         outs.append(out.read_bytes())
     assert outs[0].count(b"\n") > 5000
     assert outs[0] == outs[1]
+
+
+def test_two_rank_search_over_rccl_on_two_gpus(tmp_path):
+    """The real multi-GPU flow -- one rank per GPU, hit records gathered device to device over RCCL -- whenever the box has two GPUs
+    (the pool's boxes have one: skipped there; the gloo / one-GPU test above covers the same code path functionally)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from swiftortho_amd import synthprot
+    fa = tmp_path / "w.fsa"
+    fa.write_bytes(synthprot.synthprot(3000, 300, 77))
+    outs = []
+    env = {k: v for k, v in os.environ.items() if k not in ("SOHIT_BENCH_BACKEND", "SOHIT_BENCH_ONE_GPU")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    for a in (1, 2):
+        out = tmp_path / ("a%d.sc" % a)
+        p = _cli([os.path.join("bin", "find_hit.py"), "-p", "blastp", "-i", str(fa), "-d", str(fa), "-o", str(out), "-e", "1e-5", "-s", "111111",
+                  "-a", str(a)], env=env)
+        assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+        outs.append(out.read_bytes())
+    assert outs[0].count(b"\n") > 5000 and outs[0] == outs[1]
 
 
 def test_device_resident_results_and_query_work(fs):
