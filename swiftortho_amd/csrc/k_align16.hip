@@ -159,6 +159,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_align_pk(const AlnTask* __restri
         cwA <<= 1, cwB <<= 1;
         // all sixteen score lookups of the group first (two cells x four iterations x two alignments)
         u32 S0[4], S1[4];
+        u32 ad[16];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             // (row class << 8) | column class * 8: bytes 1 and 0 picked by one v_perm (selector bytes 0-3: second source)
@@ -167,11 +168,26 @@ __global__ __launch_bounds__(PK_THREADS) void k_align_pk(const AlnTask* __restri
             const u32 a0A = __builtin_amdgcn_perm(rwA, (u32)cwA, selE), a0B = __builtin_amdgcn_perm(rwB, (u32)cwB, selE);
             const u32 a1A = k < 3 ? __builtin_amdgcn_perm(rwA, (u32)cwA, selO) : __builtin_amdgcn_perm(rwA, (u32)(cwA >> 32), 0x0C0C0700u);
             const u32 a1B = k < 3 ? __builtin_amdgcn_perm(rwB, (u32)cwB, selO) : __builtin_amdgcn_perm(rwB, (u32)(cwB >> 32), 0x0C0C0700u);
-            const u32 e0A = *reinterpret_cast<const unsigned short*>(s_tab + ((a0A << 3) | lane2)), e0B = *reinterpret_cast<const unsigned short*>(s_tab + ((a0B << 3) | lane2));
-            const u32 e1A = *reinterpret_cast<const unsigned short*>(s_tab + ((a1A << 3) | lane2)), e1B = *reinterpret_cast<const unsigned short*>(s_tab + ((a1B << 3) | lane2));
-            S0[k] = (e0B << 16) | e0A;
-            S1[k] = (e1B << 16) | e1A;
+            const u32 lds0 = (u32)(uintptr_t)s_tab;
+            ad[4 * k] = lds0 + ((a0A << 3) | lane2), ad[4 * k + 1] = lds0 + ((a0B << 3) | lane2);
+            ad[4 * k + 2] = lds0 + ((a1A << 3) | lane2), ad[4 * k + 3] = lds0 + ((a1B << 3) | lane2);
         }
+        // alignment A's entry is read zero-extended, alignment B's straight into the HIGH half (ds_read_u16_d16_hi; with SRAM ECC on, as
+        // on gfx950, a d16 load clears the other half instead of keeping it): the pair is joined by a plain OR (full-rate) instead of
+        // the byte permute the compiler emits for (b << 16) | a.
+        // (one statement per load, so that a result may reuse its own address register; the wait statement below ties all sixteen
+        // results to the counter the compiler cannot see)
+        u32 lo[8], hi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            asm volatile("ds_read_u16 %0, %1" : "=v"(lo[k]) : "v"(ad[2 * k]));
+            asm volatile("ds_read_u16_d16_hi %0, %1" : "=v"(hi[k]) : "v"(ad[2 * k + 1]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]), "+v"(hi[0]), "+v"(hi[1]),
+                       "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) S0[k] = lo[2 * k] | hi[2 * k], S1[k] = lo[2 * k + 1] | hi[2 * k + 1];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             u32 we, Ie_out, De_out, wo;

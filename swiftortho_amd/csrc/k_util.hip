@@ -104,42 +104,63 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* __restri
     }
 }
 
-// short inputs (per-query counters: one value per query of a batch): one block walks the tiles with a running carry,
-// one launch instead of three
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_small(const u32* __restrict__ in, u32* __restrict__ out, size_t n, u32* __restrict__ total,
-                                                             int inclusive) {
-    __shared__ u32 lds4[4];
+// short inputs (per-query counters: one value per query of a batch): ONE block of 1024 threads walks the input 16 K values at a
+// time with a running carry -- one launch instead of three.  Sixteen values per thread (four 16-byte loads issued together): a
+// 100 k-query batch is seven steps, ~15 us (round 3, before: 256 threads x 4 values, 98 steps, 70 us per scan, 16 scans per step).
+#define SS_THREADS 1024
+#define SS_ITEMS 16
+__global__ __launch_bounds__(SS_THREADS) void k_scan_small(const u32* __restrict__ in, u32* __restrict__ out, size_t n, u32* __restrict__ total,
+                                                           int inclusive) {
+    __shared__ u32 s_w[SS_THREADS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     u32 carry = 0;
-    for (size_t i0 = 0; i0 < n; i0 += SCAN_THREADS * 4) {
-        const size_t i = i0 + (size_t)threadIdx.x * 4;
-        u32 a = 0, b = 0, c = 0, d = 0;
-        if (i + 3 < n) {
-            uint4 v = *reinterpret_cast<const uint4*>(in + i);
-            a = v.x, b = v.y, c = v.z, d = v.w;
+    for (size_t i0 = 0; i0 < n; i0 += (size_t)SS_THREADS * SS_ITEMS) {
+        const size_t i = i0 + (size_t)threadIdx.x * SS_ITEMS;
+        u32 v[SS_ITEMS];
+        if (i + SS_ITEMS <= n) {
+#pragma unroll
+            for (int k = 0; k < SS_ITEMS; k += 4) {
+                const uint4 x = *reinterpret_cast<const uint4*>(in + i + k);
+                v[k] = x.x, v[k + 1] = x.y, v[k + 2] = x.z, v[k + 3] = x.w;
+            }
         } else {
-            if (i < n) a = in[i];
-            if (i + 1 < n) b = in[i + 1];
-            if (i + 2 < n) c = in[i + 2];
-            if (i + 3 < n) d = in[i + 3];
+#pragma unroll
+            for (int k = 0; k < SS_ITEMS; ++k) v[k] = i + k < n ? in[i + k] : 0u;
         }
-        u32 s = a + b + c + d, tot;
-        const u32 ex = carry + block_excl_scan_u32(s, lds4, &tot);
-        u32 o0, o1, o2, o3;
-        if (inclusive) o0 = ex + a, o1 = o0 + b, o2 = o1 + c, o3 = o2 + d;
-        else o0 = ex, o1 = ex + a, o2 = o1 + b, o3 = o2 + c;
-        if (i + 3 < n) {
-            *reinterpret_cast<uint4*>(out + i) = make_uint4(o0, o1, o2, o3);
+        u32 s = 0;
+#pragma unroll
+        for (int k = 0; k < SS_ITEMS; ++k) s += v[k];
+        const u32 inc = wave_incl_scan_u32(s, lane);
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        u32 base = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < SS_THREADS / 64; ++k) {
+            const u32 x = s_w[k];
+            base += k < w ? x : 0u;
+            tot += x;
+        }
+        __syncthreads();
+        u32 run = carry + base + inc - s;   // exclusive prefix of this thread's first value
+#pragma unroll
+        for (int k = 0; k < SS_ITEMS; ++k) {
+            const u32 x = v[k];
+            v[k] = inclusive ? run + x : run;
+            run += x;
+        }
+        if (i + SS_ITEMS <= n) {
+#pragma unroll
+            for (int k = 0; k < SS_ITEMS; k += 4) *reinterpret_cast<uint4*>(out + i + k) = make_uint4(v[k], v[k + 1], v[k + 2], v[k + 3]);
         } else {
-            if (i < n) out[i] = o0;
-            if (i + 1 < n) out[i + 1] = o1;
-            if (i + 2 < n) out[i + 2] = o2;
-            if (i + 3 < n) out[i + 3] = o3;
+#pragma unroll
+            for (int k = 0; k < SS_ITEMS; ++k)
+                if (i + k < n) out[i + k] = v[k];
         }
         carry += tot;
     }
     if (threadIdx.x == 0) *total = carry;
 }
-#define SCAN_SMALL_TILES 17  // up to 136 k values: a full batch of 65536 queries (+ 1) stays in the one-launch path
+#define SCAN_SMALL_TILES 17  // up to 136 k values: a full batch of 131072 queries (+ 1) stays in the one-launch path
 
 size_t scan_u32_temp_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 2; }
 
@@ -152,7 +173,7 @@ const u32* scan_u32(const u32* in, u32* out, size_t n, bool inclusive, u32* temp
         return temp;
     }
     if (nb <= SCAN_SMALL_TILES) {
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(SCAN_THREADS), 0, st, in, out, n, temp + nb, inclusive ? 1 : 0);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(SS_THREADS), 0, st, in, out, n, temp + nb, inclusive ? 1 : 0);
         return temp + nb;
     }
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, temp);
