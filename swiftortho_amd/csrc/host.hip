@@ -1458,30 +1458,73 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     HIP_CHECK(hipMemsetAsync(b.nout.p + nq, 0, 4 * sizeof(u32), c->st));
     launch_final_select(b.toff.p, nq, c->v, b.sel.p, b.st_state.p, b.bits.p, b.nout.p, c->st);
     const u32* dNO = scan_u32(b.nout.p, b.ooff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
-    const u32 NO = d2h_u32(c, dNO);
+    // The reported rows leave in up to EMIT_PARTS query ranges: a range's rows are traced, written and sent to the host while the next
+    // range is being traced (one batch per search leaves nothing else to hide the download behind).  The ranges' first rows come
+    // back with the row total: ooff at every (nq / parts)-th query.
+    enum { EMIT_PARTS_MAX = 8 };
+    static const int emit_parts = std::min<int>(EMIT_PARTS_MAX, std::max(1, getenv("SOHIT_EMIT_PARTS") ? atoi(getenv("SOHIT_EMIT_PARTS")) : 4));
+    const int EMIT_PARTS = emit_parts;   // config 3, one batch: 1 part 57.0 ms per step, 4 parts 56.0
+    const u32 qstep = (nq + EMIT_PARTS - 1) / EMIT_PARTS;
+    c->d_small.ensure(16);
+    launch_stride_gather(b.ooff.p, qstep, (nq + qstep - 1) / qstep, c->d_small.p + 4, c->st);   // d_small[4 + p] = first row of range p
+    stash_u32(c, dNO, 0);
+    u32 NO, part_row[EMIT_PARTS_MAX + 1];
+    {
+        u32* v = (u32*)small_host(c);
+        HIP_CHECK(hipMemcpyAsync(v, c->d_small.p, 12 * sizeof(u32), hipMemcpyDeviceToHost, c->st));
+        HIP_CHECK(hipStreamSynchronize(c->st));
+        NO = v[0];
+        for (int p = 0; p <= EMIT_PARTS; ++p) part_row[p] = (u64)p * qstep < nq ? v[4 + p] : NO;
+    }
     sc.lap("phase2.stop");
     if (NO) {
         // second aligner pass, with traces + traceback, over the rows that are reported (a few percent of the alignments)
+        const int parts = (c->dev_out || NO < (1u << 18)) ? 1 : EMIT_PARTS;
         b.sel_idx.ensure((size_t)NO + 4);
         launch_selected_idx(b.toff.p, b.sel.p, b.nout.p, b.ooff.p, nq, b.sel_idx.p, c->st);
-        b.trace.ensure((size_t)std::min(slab, NO) * stride + 64);
-        {
-            ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
-            const u32* slist = b.sel_idx.p;  // (ordering this pass by rows too costs more than it saves: 9.1 -> 9.9 ms on config 3)
-            for (u32 t = 0; t < NO; t += slab) {
-                const u32 n = std::min(slab, NO - t);
-                launch_align(b.tasks.p, slist + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p,
-                             c->ref.d_scls.p, c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, b.ares.p, true, c->st);
-            }
-            pt.stop();
+        u32 maxpart = NO;
+        if (parts > 1) {
+            maxpart = 0;
+            for (int p = 0; p < parts; ++p) maxpart = std::max(maxpart, part_row[p + 1] - part_row[p]);
         }
-        sc.lap("phase2.trace_pass");
+        b.trace.ensure((size_t)std::min(slab, std::max<u32>(maxpart, 1)) * stride + 64);
         b.outrec.ensure(12 * (size_t)NO + 16);
         if (c->rows_in_flight) {  // the previous batch's rows may still be on their way out of b.outrec
             HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_rows_done, 0));
             c->rows_in_flight = false;
         }
-        launch_emit_hits(b.tasks.p, b.ares.p, b.toff.p, b.sel.p, b.nout.p, b.ooff.p, b.bits.p, nq, b.outrec.p, c->st);
+        if (!c->dev_out) {
+            emit_join(c, out);  // the previous batch's job reads the staging buffer and writes into `out`
+            // pinned staging buffer: pageable D2H runs at ~1 GB/s, pinned at PCIe speed
+            if (c->pinned_cap < (size_t)NO * sizeof(HostRow)) {
+                if (c->pinned) (void)hipHostFree(c->pinned);
+                c->pinned_cap = (size_t)NO * sizeof(HostRow) * 5 / 4 + 4096;
+                HIP_CHECK(hipHostMalloc(&c->pinned, c->pinned_cap, hipHostMallocDefault));
+            }
+        }
+        const u32* slist = b.sel_idx.p;  // (ordering this pass by rows too costs more than it saves: 9.1 -> 9.9 ms on config 3)
+        for (int p = 0; p < parts; ++p) {
+            const u32 r0 = parts > 1 ? part_row[p] : 0u, r1 = parts > 1 ? part_row[p + 1] : NO;
+            const u32 qa = parts > 1 ? std::min<u32>(nq, (u32)p * qstep) : 0u, qb = parts > 1 ? std::min<u32>(nq, (u32)(p + 1) * qstep) : nq;
+            if (r1 > r0) {
+                ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
+                for (u32 t = r0; t < r1; t += slab) {
+                    const u32 n = std::min(slab, r1 - t);
+                    launch_align(b.tasks.p, slist + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p,
+                                 c->ref.d_scls.p, c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, b.ares.p, true, c->st);
+                }
+                pt.stop();
+            }
+            launch_emit_hits(b.tasks.p, b.ares.p, b.toff.p, b.sel.p, b.nout.p, b.ooff.p, b.bits.p, qa, qb, b.outrec.p, c->st);
+            if (!c->dev_out && r1 > r0) {
+                // the range's rows are downloaded on a second stream, behind the kernel that wrote them
+                HIP_CHECK(hipEventRecord(c->ev_rows, c->st));
+                HIP_CHECK(hipStreamWaitEvent(c->st_rows, c->ev_rows, 0));
+                HIP_CHECK(hipMemcpyAsync((char*)c->pinned + (size_t)r0 * sizeof(HostRow), b.outrec.p + 12 * (size_t)r0, (size_t)(r1 - r0) * sizeof(HostRow),
+                                         hipMemcpyDeviceToHost, c->st_rows));
+            }
+        }
+        sc.lap("phase2.trace_pass");
         if (c->dev_out) {
             // device-resident results: the so_hit records are built in HBM and appended to the ctx's result buffer
             if (!c->d_p2tab.p) {
@@ -1498,21 +1541,9 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             c->cnt.phase2_ms += (wall() - t0) * 1e3;
             return;
         }
-        emit_join(c, out);  // the previous batch's job reads the staging buffer and writes into `out`
-        sc.lap("phase2.emit_host");
-        // pinned staging buffer: pageable D2H runs at ~1 GB/s, pinned at PCIe speed
-        if (c->pinned_cap < (size_t)NO * sizeof(HostRow)) {
-            if (c->pinned) (void)hipHostFree(c->pinned);
-            c->pinned_cap = (size_t)NO * sizeof(HostRow) * 5 / 4 + 4096;
-            HIP_CHECK(hipHostMalloc(&c->pinned, c->pinned_cap, hipHostMallocDefault));
-        }
         const HostRow* rows = (const HostRow*)c->pinned;
-        sc.lap("phase2.emit_alloc");
-        // the rows are downloaded on a second stream, behind the kernel that wrote them; the worker below waits for the copy, the main
-        // thread goes on to the next batch (whose row kernel in turn waits for this copy before it overwrites the device rows)
-        HIP_CHECK(hipEventRecord(c->ev_rows, c->st));
-        HIP_CHECK(hipStreamWaitEvent(c->st_rows, c->ev_rows, 0));
-        HIP_CHECK(hipMemcpyAsync(c->pinned, b.outrec.p, 12 * (size_t)NO * sizeof(int), hipMemcpyDeviceToHost, c->st_rows));
+        // the worker below waits for the last range's copy, the main thread goes on to the next batch (whose row kernel in turn waits
+        // for that copy before it overwrites the device rows)
         HIP_CHECK(hipEventRecord(c->ev_rows_done, c->st_rows));
         c->rows_in_flight = true;
         if (c->profile) HIP_CHECK(hipEventSynchronize(c->ev_rows_done));

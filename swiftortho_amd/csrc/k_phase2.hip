@@ -321,9 +321,9 @@ __global__ __launch_bounds__(64) void k_selected_idx(const u32* __restrict__ tof
 
 __global__ __launch_bounds__(64) void k_emit_hits(const AlnTask* __restrict__ tasks, const AlnRes* __restrict__ res,
                                                   const u32* __restrict__ toff, const u32* __restrict__ sel, const u32* __restrict__ nout,
-                                                  const u32* __restrict__ ooff, const int* __restrict__ bits, u32 nq,
+                                                  const u32* __restrict__ ooff, const int* __restrict__ bits, u32 q0, u32 nq,
                                                   int* __restrict__ out) {
-    const u32 q = blockIdx.x * 64u + threadIdx.x;
+    const u32 q = q0 + blockIdx.x * 64u + threadIdx.x;   // queries [q0, nq) of the batch
     if (q >= nq) return;
     const u32 t0 = toff[q], no = nout[q], o0 = ooff[q];
     for (u32 k = 0; k < no; ++k) {
@@ -443,9 +443,9 @@ void launch_selected_idx(const u32* toff, const u32* sel, const u32* nout, const
 }
 
 void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, const u32* sel, const u32* nout, const u32* ooff,
-                      const int* bits, u32 nq, int* out, hipStream_t st) {
-    if (!nq) return;
-    hipLaunchKernelGGL(k_emit_hits, dim3((nq + 63) / 64), dim3(64), 0, st, tasks, res, toff, sel, nout, ooff, bits, nq, out);
+                      const int* bits, u32 q0, u32 q1, int* out, hipStream_t st) {
+    if (q1 <= q0) return;
+    hipLaunchKernelGGL(k_emit_hits, dim3((q1 - q0 + 63) / 64), dim3(64), 0, st, tasks, res, toff, sel, nout, ooff, bits, q0, q1, out);
 }
 
 void launch_sum_cells(const AlnRes* res, u32 n, unsigned long long* total, hipStream_t st) {

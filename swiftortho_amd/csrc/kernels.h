@@ -126,7 +126,7 @@ void launch_stop_round(const AlnTask* tasks, const AlnRes* res, const u32* qcoff
 void launch_final_select(const u32* toff, u32 nq, i64 v, u32* sel, const u32* st_state, const int* bits, u32* nout, hipStream_t st);
 void launch_selected_idx(const u32* toff, const u32* sel, const u32* nout, const u32* ooff, u32 nq, u32* idx, hipStream_t st);
 void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, const u32* sel, const u32* nout, const u32* ooff,
-                      const int* bits, u32 nq, int* out, hipStream_t st);
+                      const int* bits, u32 q0, u32 q1 /*queries [q0, q1) of the batch*/, int* out, hipStream_t st);
 void launch_sum_cells(const AlnRes* res, u32 n, unsigned long long* total, hipStream_t st);
 // so_hit records on the device (80 bytes each) from k_emit_hits rows; qoff_abs = offsets of the whole loaded query set
 void launch_make_hits(const int* rows, u32 n, i64 q_lo, const u32* qoff_abs, const u32* roff, i64 D, const double* p2tab, int p2n, void* out,
