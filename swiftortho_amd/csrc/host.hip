@@ -1462,8 +1462,10 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     // range is being traced (one batch per search leaves nothing else to hide the download behind).  The ranges' first rows come
     // back with the row total: ooff at every (nq / parts)-th query.
     enum { EMIT_PARTS_MAX = 8 };
-    static const int emit_parts = std::min<int>(EMIT_PARTS_MAX, std::max(1, getenv("SOHIT_EMIT_PARTS") ? atoi(getenv("SOHIT_EMIT_PARTS")) : 4));
-    const int EMIT_PARTS = emit_parts;   // config 3, one batch: 1 part 57.0 ms per step, 4 parts 56.0
+    // SOHIT_EMIT_PARTS (1-8, default 4) / SOHIT_EMIT_MIN_ROWS (default 2^18: smaller results leave in one piece): tuning and test switches
+    const int EMIT_PARTS = std::min<int>(EMIT_PARTS_MAX, std::max(1, getenv("SOHIT_EMIT_PARTS") ? atoi(getenv("SOHIT_EMIT_PARTS")) : 4));
+    const u32 emit_min_rows = getenv("SOHIT_EMIT_MIN_ROWS") ? (u32)std::max(1, atoi(getenv("SOHIT_EMIT_MIN_ROWS"))) : (1u << 18);
+    // (config 3, one batch: 1 part 57.0 ms per step, 4 parts 56.0)
     const u32 qstep = (nq + EMIT_PARTS - 1) / EMIT_PARTS;
     c->d_small.ensure(16);
     launch_stride_gather(b.ooff.p, qstep, (nq + qstep - 1) / qstep, c->d_small.p + 4, c->st);   // d_small[4 + p] = first row of range p
@@ -1479,7 +1481,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     sc.lap("phase2.stop");
     if (NO) {
         // second aligner pass, with traces + traceback, over the rows that are reported (a few percent of the alignments)
-        const int parts = (c->dev_out || NO < (1u << 18)) ? 1 : EMIT_PARTS;
+        const int parts = (c->dev_out || NO < emit_min_rows) ? 1 : EMIT_PARTS;
         b.sel_idx.ensure((size_t)NO + 4);
         launch_selected_idx(b.toff.p, b.sel.p, b.nout.p, b.ooff.p, nq, b.sel_idx.p, c->st);
         u32 maxpart = NO;

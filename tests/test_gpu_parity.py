@@ -223,6 +223,20 @@ def test_full_candidate_store_splits_the_batch(fs, oracle, tmp_path, monkeypatch
         gpu_rows(fs, fa, fa, kw, -1, -1)
 
 
+@pytest.mark.parametrize("parts", [3, 8])
+def test_rows_leave_in_query_ranges(fs, oracle, tmp_path, monkeypatch, parts):
+    """Large results are traced, written and downloaded in several query ranges (host.hip phase2, SOHIT_EMIT_PARTS); forced here on a
+    small input (SOHIT_EMIT_MIN_ROWS=1), with more ranges than some batches have queries, several batches, and queries without rows."""
+    from swiftortho_amd import synthprot
+    monkeypatch.setenv("SOHIT_EMIT_PARTS", str(parts))
+    monkeypatch.setenv("SOHIT_EMIT_MIN_ROWS", "1")
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    fa = synthprot.synthprot(700, 150, 311) + b">lonely\n" + synthprot.uniform_proteins(1, 200, 5).split(b"\n", 1)[1]
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+    monkeypatch.setenv("SOHIT_BATCH", "5")
+    oracle_vs_gpu(fs, oracle, synthprot.synthprot(60, 120, 17), kw, tmp_path, sub=(3, 41))
+
+
 def test_aligner_launch_order_and_result_cache_do_not_change_rows(fs, oracle, tmp_path, monkeypatch):
     """The score-only aligner launches are ordered by band rows (k_task_rows + radix sort, lists of >= 4096 tasks) and a released
     result array is reused by the next search (so_free_hits keeps one): with both switched off, and over repeated searches on one
