@@ -700,6 +700,7 @@ struct Batch {
     DevBuf<u32> cand_q, cand_rec;             // all chunks' regions concatenated
     std::vector<u32> chunk_base;              // region start per chunk (+ total)
     DevBuf<u32> ccnt;                         // [nchunks][nq] per-query counts
+    DevBuf<u32> tpos, spcnt, spoff, sidx, spec_trace, sel_a, sel_b;   // speculative traces of the first aligner round (phase2)
     DevBuf<u64> gx;
     DevBuf<u32> gL, gR;
     DevBuf<u32> segfirst, st_state, rcnt, tcnt, roff, ridx, ridx2, ntile, roffc, rk_slot, order_tmp;
@@ -1421,18 +1422,69 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     HIP_CHECK(hipMemsetAsync(b.st_state.p, 0, (5 * (size_t)nq + 8) * sizeof(u32), c->st));
     sc.lap("phase2.mktasks");
     u32 aligned_total = 0;
+    // Speculative traces (k_round_counts_spec): in the FIRST round, the leading tasks of every query whose ungapped score alone would pass
+    // the e-value test are aligned with traces at once; reported rows that have one skip the second alignment.  SOHIT_SPEC=0: off.
+    // SOHIT_SPEC=0 / 1: off / on whatever the size (default: on from 2^21 tasks; below that the extra launches cost more than they save:
+    // config 2, 0.55 M tasks, 16.7 -> 17.1 ms).  SOHIT_SPEC_SLACK: the guess tests the ungapped score against expect x this (default 1e3:
+    // config 3 keeps 1.44 M traces, all of them of reported rows, 175 k rows are left for the second pass; 1: 1.30 M / 315 k; 1e6: 1.56 M /
+    // 57 k with 1.3 k traces unused -- a wrong guess costs about as much as a right one saves).
+    const char* spec_env = getenv("SOHIT_SPEC");
+    const bool spec_on = spec_env ? atoi(spec_env) != 0 : NT >= (1u << 21);
+    const double spec_slack = getenv("SOHIT_SPEC_SLACK") ? atof(getenv("SOHIT_SPEC_SLACK")) : 1e3;
+    u32 spec_cap = (u32)std::min<size_t>(NT, ((size_t)1 << 31) / std::max<u32>(stride, 1));   // 8 GiB of kept traces at most
+    if (getenv("SOHIT_SPEC_CAP")) spec_cap = (u32)std::max(0, atoi(getenv("SOHIT_SPEC_CAP")));   // (tests: the round that does not fit)
+    u32 nspec = 0;
+    if (spec_on) {
+        b.tpos.ensure((size_t)NT + 4);
+        HIP_CHECK(hipMemsetAsync(b.tpos.p, 0xFF, ((size_t)NT + 4) * sizeof(u32), c->st));   // 0xFFFFFFFF = no trace kept
+    }
+    bool first_round = true;
     for (u32 minr = 8;; minr = minr < 256 ? minr * 2 : minr) {
-        launch_round_counts(b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.qcoff.p, b.st_state.p, nq, c->max_miss, minr, b.rcnt.p,
-                            b.tcnt.p, c->st);
-        const u32* dNR = scan_u32(b.tcnt.p, b.roff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
-        stash_u32(c, dNR, 0);
-        // ranks left this round (a round may hold ranks with zero tiles only)
-        const u32* dRR = scan_u32(b.rcnt.p, b.order_tmp.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
-        u32 NR, RR;
-        d2h_pair(c, dRR, NR, RR);
+        u32 NR = 0, RR = 0, NS = 0;
+        bool spec_round = spec_on && first_round;
+        first_round = false;
+        if (spec_round) {
+            b.spcnt.ensure((size_t)nq + 4), b.spoff.ensure((size_t)nq + 4), b.sidx.ensure((size_t)NT + 4);
+            c->d_small.ensure(16);
+            HIP_CHECK(hipMemsetAsync(c->d_small.p + 3, 0, sizeof(u32), c->st));
+            launch_round_counts_spec(b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.qcoff.p, b.st_state.p, nq, c->max_miss, minr, b.tasks.p, b.toff.p,
+                                     b.dev.d_off.p, c->ref.d_off.p, c->d_bittab.p, so_ctx::BITTAB_N, c->ref.N, c->expect * spec_slack, b.rcnt.p, b.tcnt.p, b.spcnt.p,
+                                     c->d_small.p + 3, c->st);
+            stash_u32(c, scan_u32(b.tcnt.p, b.roff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st), 0);
+            stash_u32(c, scan_u32(b.spcnt.p, b.spoff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st), 1);
+            u32* v = (u32*)small_host(c);
+            HIP_CHECK(hipMemcpyAsync(v, c->d_small.p, 4 * sizeof(u32), hipMemcpyDeviceToHost, c->st));
+            HIP_CHECK(hipStreamSynchronize(c->st));
+            NR = v[0], NS = v[1], RR = v[3];
+            if (NS > spec_cap) spec_round = false;   // the traces would not fit: this round again, without them
+        }
+        if (!spec_round) {
+            NS = 0;
+            launch_round_counts(b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.qcoff.p, b.st_state.p, nq, c->max_miss, minr, b.rcnt.p,
+                                b.tcnt.p, c->st);
+            const u32* dNR = scan_u32(b.tcnt.p, b.roff.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
+            stash_u32(c, dNR, 0);
+            // ranks left this round (a round may hold ranks with zero tiles only)
+            const u32* dRR = scan_u32(b.rcnt.p, b.order_tmp.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
+            d2h_pair(c, dRR, NR, RR);
+        }
         if (RR == 0) break;
-        if (NR) {
+        if (spec_round) {
+            launch_round_idx_spec(b.tcnt.p, b.spcnt.p, b.roff.p, b.spoff.p, b.toff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.st_state.p, nq,
+                                  b.ridx.p, b.sidx.p, c->st);
+            if (NS) {
+                const u32* slist = sort_by_rows(b.sidx.p, NS);
+                b.spec_trace.ensure((size_t)NS * stride + 64);
+                ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
+                launch_align_traced(b.tasks.p, slist, NS, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_scls4.p,
+                                    c->ref.d_off.p, c->d_b62c.p, b.spec_trace.p, stride, b.ares.p, b.tpos.p, 0u, c->st);
+                pt.stop();
+                nspec = NS;
+            }
+        } else if (NR) {
             launch_round_idx(b.tcnt.p, b.roff.p, b.toff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.st_state.p, nq, b.ridx.p, c->st);
+        }
+        if (NR) {
             // score-only: the stop rule needs the maximum alone; the reported rows are traced in a second pass below
             const u32* rlist = sort_by_rows(b.ridx.p, NR);
             ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
@@ -1448,7 +1500,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         launch_stop_round(b.tasks.p, b.ares.p, b.qcoff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.toff.p, b.rcnt.p, nq,
                           b.dev.d_off.p, c->ref.d_off.p, c->d_bittab.p, so_ctx::BITTAB_N, c->ref.N, c->expect, c->max_miss, c->v, b.sel.p,
                           b.st_state.p, b.bits.p, c->st);
-        aligned_total += NR;
+        aligned_total += NR + NS;
     }
     launch_sum_cells(b.ares.p, NT, b.ucount.p + 1, c->st);
     sc.lap("phase2.align_rounds");
@@ -1463,7 +1515,9 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     // back with the row total: ooff at every (nq / parts)-th query.
     enum { EMIT_PARTS_MAX = 8 };
     // SOHIT_EMIT_PARTS (1-8, default 4) / SOHIT_EMIT_MIN_ROWS (default 2^18: smaller results leave in one piece): tuning and test switches
-    const int EMIT_PARTS = std::min<int>(EMIT_PARTS_MAX, std::max(1, getenv("SOHIT_EMIT_PARTS") ? atoi(getenv("SOHIT_EMIT_PARTS")) : 4));
+    // (with kept traces -- nspec -- the last stage is short: fewer ranges, SOHIT_SPEC_PARTS, default 2)
+    const int EMIT_PARTS = std::min<int>(EMIT_PARTS_MAX, std::max(1, nspec ? (getenv("SOHIT_SPEC_PARTS") ? atoi(getenv("SOHIT_SPEC_PARTS")) : 2)
+                                                                            : (getenv("SOHIT_EMIT_PARTS") ? atoi(getenv("SOHIT_EMIT_PARTS")) : 4)));
     const u32 emit_min_rows = getenv("SOHIT_EMIT_MIN_ROWS") ? (u32)std::max(1, atoi(getenv("SOHIT_EMIT_MIN_ROWS"))) : (1u << 18);
     // (config 3, one batch: 1 part 57.0 ms per step, 4 parts 56.0)
     const u32 qstep = (nq + EMIT_PARTS - 1) / EMIT_PARTS;
@@ -1505,10 +1559,41 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             }
         }
         const u32* slist = b.sel_idx.p;  // (ordering this pass by rows too costs more than it saves: 9.1 -> 9.9 ms on config 3)
+        // Kept traces: rows that have one only need the walk, the others are aligned with traces now.  The row list is split stably
+        // (flags, scan, scatter); range p's rows without a trace are list B's [pb[p], pb[p + 1]), the others list A's
+        // [first row - pb[p], ...): the scan values at the ranges' first rows come back in one small copy.
+        u32 pb[EMIT_PARTS_MAX + 1] = {0};
+        if (nspec) {
+            b.flags.ensure((size_t)NO + 4), b.gidx.ensure((size_t)NO + 4), b.sel_b.ensure((size_t)NO + 4), b.sel_a.ensure((size_t)NO + 4);
+            c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)NO + 1) + 8);
+            launch_trace_flags(slist, NO, b.tpos.p, b.flags.p, c->st);
+            const u32* dNB = scan_u32(b.flags.p, b.gidx.p, NO, false, c->d_scan_tmp.p, c->st);
+            launch_trace_split(slist, NO, b.flags.p, b.gidx.p, b.sel_b.p, b.sel_a.p, c->st);
+            u32* v = (u32*)small_host(c);
+            HIP_CHECK(hipMemcpyAsync(v + parts, dNB, sizeof(u32), hipMemcpyDeviceToHost, c->st));
+            for (int p = 1; p < parts; ++p) {
+                if (part_row[p] < NO) HIP_CHECK(hipMemcpyAsync(v + p, b.gidx.p + part_row[p], sizeof(u32), hipMemcpyDeviceToHost, c->st));
+            }
+            HIP_CHECK(hipStreamSynchronize(c->st));
+            pb[parts] = v[parts];
+            for (int p = 1; p < parts; ++p) pb[p] = part_row[p] < NO ? v[p] : pb[parts];
+            if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] kept traces %u, reported rows %u, of them without a trace %u\n", nspec, NO, pb[parts]);
+        }
         for (int p = 0; p < parts; ++p) {
             const u32 r0 = parts > 1 ? part_row[p] : 0u, r1 = parts > 1 ? part_row[p + 1] : NO;
             const u32 qa = parts > 1 ? std::min<u32>(nq, (u32)p * qstep) : 0u, qb = parts > 1 ? std::min<u32>(nq, (u32)(p + 1) * qstep) : nq;
-            if (r1 > r0) {
+            if (r1 > r0 && nspec) {
+                const u32 b0 = pb[p], b1 = pb[p + 1], a0 = r0 - b0, a1 = r1 - b1;
+                ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
+                for (u32 t = b0; t < b1; t += slab) {
+                    const u32 n = std::min(slab, b1 - t);
+                    launch_align(b.tasks.p, b.sel_b.p + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p,
+                                 c->ref.d_scls.p, c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, b.ares.p, true, c->st);
+                }
+                launch_traceback(b.tasks.p, b.sel_a.p + a0, a1 - a0, b.dev.d_res.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_off.p, b.spec_trace.p, stride,
+                                 b.tpos.p, b.ares.p, c->st);
+                pt.stop();
+            } else if (r1 > r0) {
                 ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
                 for (u32 t = r0; t < r1; t += slab) {
                     const u32 n = std::min(slab, r1 - t);

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
                                                const u8* __restrict__ q_scls, const u8* __restrict__ q_scls4, const u32* __restrict__ qoff,
                                                const u8* __restrict__ r_scls, const u8* __restrict__ r_scls4, const u32* __restrict__ roff,
                                                const signed char* __restrict__ b62g, u32* __restrict__ trace, u32 trace_stride,
-                                               AlnRes* __restrict__ out) {
+                                               AlnRes* __restrict__ out, u32* __restrict__ tpos_out, u32 tpos_base) {
     __shared__ signed char s_b62[AL_TAB];
     for (int i = threadIdx.x; i < SCLS_N * 64; i += 256) {
         const int a = i >> 6, b = i & 63;
@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     r.maxscore = best, r.aln = 0, r.matches = 0, r.gap = 0, r.cells = ncell, r.pad = 0;
     r.qst = bi, r.qed = bj, r.sst = 0, r.sed = 0;  // (i_max, j_max) parked for k_traceback
     out[slot] = r;
+    if (TRACE && tpos_out) tpos_out[slot] = tpos_base + tid;   // where this task's trace lives (speculative traces)
 }
 
 // Traceback from the best cell until a stop cell (1418-1443), walking through row 0 ('-'), column 0
@@ -251,7 +252,8 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
 __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 ntasks,
                                                   const u8* __restrict__ q_res, const u32* __restrict__ qoff,
                                                   const u8* __restrict__ r_res, const u32* __restrict__ roff,
-                                                  const u32* __restrict__ trace, u32 trace_stride, AlnRes* __restrict__ out) {
+                                                  const u32* __restrict__ trace, u32 trace_stride, const u32* __restrict__ tpos,
+                                                  AlnRes* __restrict__ out) {
     const u32 tid = blockIdx.x * 64u + threadIdx.x;
     if (tid >= ntasks) return;
     const u32 slot = ridx ? ridx[tid] : tid;
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ ta
     const bool swp = !(la < lb);
     const u8* craw = swp ? (r_res + sb + qj) : (q_res + qb + qi);
     const u8* rraw = swp ? (q_res + qb + qi) : (r_res + sb + qj);
-    const u32* tr = trace + (size_t)tid * trace_stride;
+    const u32* tr = trace + (size_t)(tpos ? tpos[slot] : tid) * trace_stride;   // tpos: traces kept per task (speculative), else per launch position
     const int bi = r.qst, bj = r.qed;
     // The reference derives its statistics from the two aligned STRINGS, gap columns spelled '-' (1454-1471): identity
     // compares characters, and the gap counter is a three-state machine over them (op = -1 / 0 / 1; a '-' in string 0 opens
@@ -335,11 +337,26 @@ void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q
     if (!ntasks) return;
     if (!with_traceback) {
         hipLaunchKernelGGL((k_align<false>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4,
-                           roff, b62g, trace, trace_stride, out);
+                           roff, b62g, trace, trace_stride, out, (u32*)nullptr, 0u);
         return;
     }
     hipLaunchKernelGGL((k_align<true>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff,
-                       b62g, trace, trace_stride, out);
+                       b62g, trace, trace_stride, out, (u32*)nullptr, 0u);
     hipLaunchKernelGGL(k_traceback, dim3((ntasks + 63) / 64), dim3(64), 0, st, tasks, ridx, ntasks, q_res, qoff, r_res, roff, trace,
-                       trace_stride, out);
+                       trace_stride, (const u32*)nullptr, out);
+}
+
+void launch_align_traced(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
+                         const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, AlnRes* out, u32* tpos_out,
+                         u32 tpos_base, hipStream_t st) {
+    if (!ntasks) return;
+    hipLaunchKernelGGL((k_align<true>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff,
+                       b62g, trace, trace_stride, out, tpos_out, tpos_base);
+}
+
+void launch_traceback(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u32* qoff, const u8* r_res, const u32* roff,
+                      const u32* trace, u32 trace_stride, const u32* tpos, AlnRes* out, hipStream_t st) {
+    if (!ntasks) return;
+    hipLaunchKernelGGL(k_traceback, dim3((ntasks + 63) / 64), dim3(64), 0, st, tasks, ridx, ntasks, q_res, qoff, r_res, roff, trace, trace_stride, tpos,
+                       out);
 }

@@ -197,6 +197,84 @@ __global__ __launch_bounds__(256) void k_round_counts(const u32* __restrict__ nt
     tcnt[q] = tc;
 }
 
+// ---- first round with SPECULATIVE TRACES (round 3) ----------------------------------------------------------------------------------
+// Every reported row is aligned twice: score-only in the rounds, traced afterwards.  Candidates arrive ordered by ungapped score, and
+// a candidate whose UNGAPPED score alone would already pass the e-value test almost always passes with gaps: the leading tasks of a
+// query's first round that satisfy that test (a prefix: scores descend) are aligned with traces right away (k_align<true>, the trace
+// kept in a slab of its own, its position in tpos[slot]); rows that end up reported and have a trace only need the traceback walk.
+// A wrong guess costs the difference between the traced and the packed kernel for one alignment; results do not depend on the guess.
+// tcnt_pk[q] = tasks of the round for the score-only kernel, scnt[q] = tasks traced right away, *any_rank += ranks of the round.
+__global__ __launch_bounds__(256) void k_round_counts_spec(const u32* __restrict__ ntask, const u32* __restrict__ ntile,
+                                                           const u32* __restrict__ roffc, const u32* __restrict__ rk_slot,
+                                                           const u32* __restrict__ qcoff, const u32* __restrict__ st_state, u32 nq,
+                                                           double max_miss, u32 minr, const AlnTask* __restrict__ tasks,
+                                                           const u32* __restrict__ toff, const u32* __restrict__ qoff, const u32* __restrict__ roff,
+                                                           const int* __restrict__ bittab, int bittab_n, i64 D, double expect,
+                                                           u32* __restrict__ rcnt, u32* __restrict__ tcnt_pk, u32* __restrict__ scnt,
+                                                           u32* __restrict__ any_rank) {
+    const u32 q = blockIdx.x * 256u + threadIdx.x;
+    u32 c = 0, tc = 0, ns = 0;
+    if (q < nq && !st_state[5 * (size_t)q + 4]) {
+        const u32 nt = ntask[q], next = st_state[5 * (size_t)q], unmch = st_state[5 * (size_t)q + 1];
+        const u32 left = nt - next;
+        const u32 n = qcoff[q + 1] - qcoff[q];
+        double mmiss = (double)n * max_miss + 1;
+        const double inv = 100. / mmiss;
+        mmiss = mmiss > inv ? mmiss : inv;
+        mmiss = mmiss > 10. ? mmiss : 10.;
+        mmiss = mmiss < 120. ? mmiss : 120.;
+        const u32 cm = (u32)ceil(mmiss);
+        u32 need = cm > unmch ? cm - unmch : 1u;
+        need = need < minr ? minr : need;
+        c = left < need ? left : need;
+        const u32 s0 = rank_slot(rk_slot, roffc[q], next, nt, ntile[q]);
+        tc = rank_slot(rk_slot, roffc[q], next + c, nt, ntile[q]) - s0;
+        const i64 li = (i64)(qoff[q + 1] - qoff[q]);
+        const size_t base = (size_t)toff[q] + s0;
+        for (; ns < tc; ++ns) {
+            const AlnTask tk = tasks[base + ns];
+            const i64 lj = (i64)(roff[tk.subj + 1] - roff[tk.subj]);
+            const int sc = (int)tk.score < bittab_n ? (int)tk.score : bittab_n - 1;
+            const int bit = bittab[sc];
+            const double p2 = bit > 1074 ? 0.0 : ldexp(1.0, -bit);
+            if (!((double)(D * li * lj) * p2 <= expect)) break;
+        }
+    }
+    if (q <= nq) rcnt[q] = c, tcnt_pk[q] = tc - ns, scnt[q] = ns;
+    u32 sum = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += (u32)__shfl_xor((int)sum, o);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(any_rank, sum);
+}
+
+__global__ __launch_bounds__(64) void k_round_idx_spec(const u32* __restrict__ tcnt_pk, const u32* __restrict__ scnt, const u32* __restrict__ poff,
+                                                       const u32* __restrict__ soff, const u32* __restrict__ toff, const u32* __restrict__ ntask,
+                                                       const u32* __restrict__ ntile, const u32* __restrict__ roffc, const u32* __restrict__ rk_slot,
+                                                       const u32* __restrict__ st_state, u32 nq, u32* __restrict__ ridx, u32* __restrict__ sidx) {
+    const u32 q = blockIdx.x;
+    const u32 ns = scnt[q], n = tcnt_pk[q] + ns;
+    if (!n) return;
+    const u32 base = toff[q] + rank_slot(rk_slot, roffc[q], st_state[5 * (size_t)q], ntask[q], ntile[q]);
+    const u32 po = poff[q], so = soff[q];
+    for (u32 k = threadIdx.x; k < n; k += 64) {
+        if (k < ns) sidx[so + k] = base + k;
+        else ridx[po + (k - ns)] = base + k;
+    }
+}
+
+// reported rows -> those that still need the traced alignment (no trace yet: flag 1) and those that only need the walk
+__global__ __launch_bounds__(256) void k_trace_flags(const u32* __restrict__ sel_idx, u32 n, const u32* __restrict__ tpos, u32* __restrict__ flags) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) flags[i] = tpos[sel_idx[i]] == 0xFFFFFFFFu ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_trace_split(const u32* __restrict__ sel_idx, u32 n, const u32* __restrict__ flags, const u32* __restrict__ fscan,
+                                                     u32* __restrict__ list_b /*flag 1*/, u32* __restrict__ list_a /*flag 0*/) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    if (flags[i]) list_b[fscan[i]] = sel_idx[i];
+    else list_a[i - fscan[i]] = sel_idx[i];
+}
+
 __global__ __launch_bounds__(64) void k_round_idx(const u32* __restrict__ tcnt, const u32* __restrict__ troff, const u32* __restrict__ toff,
                                                   const u32* __restrict__ ntask, const u32* __restrict__ ntile,
                                                   const u32* __restrict__ roffc, const u32* __restrict__ rk_slot,
@@ -413,6 +491,24 @@ void launch_round_counts(const u32* ntask, const u32* ntile, const u32* roffc, c
                          const u32* st_state, u32 nq, double max_miss, u32 minr, u32* rcnt, u32* tcnt, hipStream_t st) {
     hipLaunchKernelGGL(k_round_counts, dim3((nq + 1 + 255) / 256), dim3(256), 0, st, ntask, ntile, roffc, rk_slot, qcoff, st_state, nq,
                        max_miss, minr, rcnt, tcnt);
+}
+
+void launch_round_counts_spec(const u32* ntask, const u32* ntile, const u32* roffc, const u32* rk_slot, const u32* qcoff, const u32* st_state, u32 nq,
+                              double max_miss, u32 minr, const AlnTask* tasks, const u32* toff, const u32* qoff, const u32* roff, const int* bittab,
+                              int bittab_n, i64 D, double expect, u32* rcnt, u32* tcnt_pk, u32* scnt, u32* any_rank, hipStream_t st) {
+    hipLaunchKernelGGL(k_round_counts_spec, dim3((nq + 1 + 255) / 256), dim3(256), 0, st, ntask, ntile, roffc, rk_slot, qcoff, st_state, nq, max_miss,
+                       minr, tasks, toff, qoff, roff, bittab, bittab_n, D, expect, rcnt, tcnt_pk, scnt, any_rank);
+}
+void launch_round_idx_spec(const u32* tcnt_pk, const u32* scnt, const u32* poff, const u32* soff, const u32* toff, const u32* ntask, const u32* ntile,
+                           const u32* roffc, const u32* rk_slot, const u32* st_state, u32 nq, u32* ridx, u32* sidx, hipStream_t st) {
+    if (!nq) return;
+    hipLaunchKernelGGL(k_round_idx_spec, dim3(nq), dim3(64), 0, st, tcnt_pk, scnt, poff, soff, toff, ntask, ntile, roffc, rk_slot, st_state, nq, ridx, sidx);
+}
+void launch_trace_flags(const u32* sel_idx, u32 n, const u32* tpos, u32* flags, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_trace_flags, dim3((n + 255) / 256), dim3(256), 0, st, sel_idx, n, tpos, flags);
+}
+void launch_trace_split(const u32* sel_idx, u32 n, const u32* flags, const u32* fscan, u32* list_b, u32* list_a, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_trace_split, dim3((n + 255) / 256), dim3(256), 0, st, sel_idx, n, flags, fscan, list_b, list_a);
 }
 
 void launch_round_idx(const u32* tcnt, const u32* troff, const u32* toff, const u32* ntask, const u32* ntile, const u32* roffc,

@@ -154,4 +154,17 @@ void launch_rec_scatter(const u64* p_qs, const u64* p_sd, const u64* p_ft, const
 void launch_bkt_best(bool write, const u64* q_qs, const u64* q_sd, const u64* q_ft, const u32* boff, u32 nb, const BktLayout& L, int bs,
                      u32 seq_lo, u32* ccnt, u64* c_ft, u32* c_q, u32* c_rec, hipStream_t st);
 
+void launch_round_counts_spec(const u32* ntask, const u32* ntile, const u32* roffc, const u32* rk_slot, const u32* qcoff, const u32* st_state, u32 nq,
+                              double max_miss, u32 minr, const AlnTask* tasks, const u32* toff, const u32* qoff, const u32* roff, const int* bittab,
+                              int bittab_n, i64 D, double expect, u32* rcnt, u32* tcnt_pk, u32* scnt, u32* any_rank, hipStream_t st);
+void launch_round_idx_spec(const u32* tcnt_pk, const u32* scnt, const u32* poff, const u32* soff, const u32* toff, const u32* ntask, const u32* ntile,
+                           const u32* roffc, const u32* rk_slot, const u32* st_state, u32 nq, u32* ridx, u32* sidx, hipStream_t st);
+void launch_trace_flags(const u32* sel_idx, u32 n, const u32* tpos, u32* flags, hipStream_t st);
+void launch_trace_split(const u32* sel_idx, u32 n, const u32* flags, const u32* fscan, u32* list_b, u32* list_a, hipStream_t st);
+// k_align.hip: the two halves of launch_align(..., true) on their own (speculative traces: the walk runs long after the alignment)
+void launch_align_traced(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
+                         const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, AlnRes* out, u32* tpos_out,
+                         u32 tpos_base, hipStream_t st);
+void launch_traceback(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u32* qoff, const u8* r_res, const u32* roff,
+                      const u32* trace, u32 trace_stride, const u32* tpos, AlnRes* out, hipStream_t st);
 void launch_task_rows(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, u64* keys, hipStream_t st);

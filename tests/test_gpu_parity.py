@@ -237,6 +237,23 @@ def test_rows_leave_in_query_ranges(fs, oracle, tmp_path, monkeypatch, parts):
     oracle_vs_gpu(fs, oracle, synthprot.synthprot(60, 120, 17), kw, tmp_path, sub=(3, 41))
 
 
+@pytest.mark.parametrize("env", [{"SOHIT_SPEC": "0"}, {"SOHIT_SPEC": "1", "SOHIT_SPEC_SLACK": "1e30"}, {"SOHIT_SPEC": "1", "SOHIT_SPEC_SLACK": "1e-30"},
+                                 {"SOHIT_SPEC": "1", "SOHIT_SPEC_CAP": "50"}, {"SOHIT_SPEC": "1"},
+                                 {"SOHIT_SPEC": "1", "SOHIT_SPEC_SLACK": "1e4", "SOHIT_SPEC_PARTS": "3", "SOHIT_EMIT_MIN_ROWS": "1"}])
+def test_speculative_traces_do_not_change_rows(fs, oracle, tmp_path, monkeypatch, env):
+    """First-round tasks whose ungapped score alone would pass the e-value test are aligned WITH traces at once (host.hip phase2,
+    k_round_counts_spec); reported rows that have a trace skip the second alignment.  Rows are the oracle's with the guess switched
+    off, with every first-round task traced, with none, with a trace budget the first round does not fit (the round is redone without
+    traces), and together with the ranged row emission; long candidates (tiled alignments) included."""
+    from swiftortho_amd import synthprot
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=1000003, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, synthprot.synthprot(600, 160, 411), kw, tmp_path)
+    kw2 = dict(kw, v=3, expect=1e-3)
+    oracle_vs_gpu(fs, oracle, synthprot.synthprot(40, 4500, 7), kw2, tmp_path)
+
+
 def test_aligner_launch_order_and_result_cache_do_not_change_rows(fs, oracle, tmp_path, monkeypatch):
     """The score-only aligner launches are ordered by band rows (k_task_rows + radix sort, lists of >= 4096 tasks) and a released
     result array is reused by the next search (so_free_hits keeps one): with both switched off, and over repeated searches on one
