@@ -281,7 +281,40 @@ __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ ta
     // loads at one wave per SIMD); the residue arrays are padded, so a window may reach past its sequence
     int cwin = -1, rwin = -1;
     u64 cw8 = 0, rw8 = 0;
+    // The 64 walks of a wave run in lockstep but reach their 8-step boundaries (next trace word, next residue windows) at different
+    // steps, so a wave that fetched on demand paid a memory round trip in nearly EVERY step, not every eighth (2.4 ms per config-3
+    // step for 1.6 M walks).  Every eighth step ALL lanes therefore request, together, what they may need before the next such step:
+    // the current items if missing and the ones behind them (same lane, previous block of 8 iterations; previous 8 residues); a lane
+    // crosses at most one boundary of each kind in 8 steps, so a boundary finds its word parked in a register.  Only a gap column,
+    // which moves the walk to another lane's words, still fetches on demand.
+    int nkey = -2, pcwin = -2, prwin = -2;
+    u32 nv = 0, step = 0;
+    u64 pcw8 = 0, prw8 = 0;
     while (i > 0 || j > 0) {
+        if ((step++ & 7u) == 0u) {
+            if (i > 0 && j > 0) {
+                const int d = j - i + KB;
+                if (d >= 0) {
+                    const int m = i + (d >> 1);
+                    const int key = ((m >> 3) - 1) * 16 + (d >> 1);
+                    if (key != wkey) wkey = key, wv = tr[key];
+                    nkey = key - 16;
+                    if (nkey >= 0) nv = tr[nkey];
+                }
+            }
+            if (j > 0) {
+                const int k = j - 1;
+                if ((k >> 3) != cwin) cwin = k >> 3, __builtin_memcpy(&cw8, craw + (k & ~7), 8);
+                pcwin = cwin - 1;
+                if (pcwin >= 0) __builtin_memcpy(&pcw8, craw + 8 * pcwin, 8);
+            }
+            if (i > 0) {
+                const int k = i - 1;
+                if ((k >> 3) != rwin) rwin = k >> 3, __builtin_memcpy(&rw8, rraw + (k & ~7), 8);
+                prwin = rwin - 1;
+                if (prwin >= 0) __builtin_memcpy(&prw8, rraw + 8 * prwin, 8);
+            }
+        }
         int tc;
         if (i == 0) tc = 2;
         else if (j == 0) tc = 3;
@@ -291,7 +324,7 @@ __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ ta
             else {
                 const int m = i + (d >> 1);  // the iteration that computed the cell in lane d >> 1 (k_align's trace layout)
                 const int key = ((m >> 3) - 1) * 16 + (d >> 1);
-                if (key != wkey) wkey = key, wv = tr[key];
+                if (key != wkey) wv = key == nkey ? nv : tr[key], wkey = key;
                 tc = (int)((wv >> (((7 - (m & 7)) << 2) + ((d & 1) << 1))) & 3u);
             }
         }
@@ -300,12 +333,20 @@ __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ ta
         int a0 = '-', a1 = '-';  // the column's two characters (1419-1432)
         if (tc != 3) {
             const int k = j - 1;
-            if ((k >> 3) != cwin) cwin = k >> 3, __builtin_memcpy(&cw8, craw + (k & ~7), 8);
+            if ((k >> 3) != cwin) {
+                cwin = k >> 3;
+                if (cwin == pcwin) cw8 = pcw8;
+                else __builtin_memcpy(&cw8, craw + (k & ~7), 8);
+            }
             a0 = (int)((cw8 >> ((k & 7) << 3)) & 0xFFu);
         }
         if (tc != 2) {
             const int k = i - 1;
-            if ((k >> 3) != rwin) rwin = k >> 3, __builtin_memcpy(&rw8, rraw + (k & ~7), 8);
+            if ((k >> 3) != rwin) {
+                rwin = k >> 3;
+                if (rwin == prwin) rw8 = prw8;
+                else __builtin_memcpy(&rw8, rraw + (k & ~7), 8);
+            }
             a1 = (int)((rw8 >> ((k & 7) << 3)) & 0xFFu);
         }
         matches += (a0 == a1) ? 1 : 0;
