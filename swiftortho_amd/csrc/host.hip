@@ -700,6 +700,7 @@ struct Batch {
     DevBuf<u32> cand_q, cand_rec;             // all chunks' regions concatenated
     std::vector<u32> chunk_base;              // region start per chunk (+ total)
     DevBuf<u32> ccnt;                         // [nchunks][nq] per-query counts
+    DevBuf<unsigned long long> qcells;        // DP cells per query (phase2)
     DevBuf<u32> tpos, spcnt, spoff, sidx, spec_trace, sel_a, sel_b;   // speculative traces of the first aligner round (phase2)
     DevBuf<u64> gx;
     DevBuf<u32> gL, gR;
@@ -1395,7 +1396,8 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     sc.lap("phase2.csort");
     b.tasks.ensure((size_t)NT + 4), b.ares.ensure((size_t)NT + 4), b.bits.ensure((size_t)NT + 4), b.sel.ensure((size_t)NT + 4);
     b.rk_slot.ensure((size_t)NRK + 4);
-    HIP_CHECK(hipMemsetAsync(b.ares.p, 0, ((size_t)NT + 4) * sizeof(AlnRes), c->st));  // unaligned slots count 0 cells
+    b.qcells.ensure((size_t)nq + 2);
+    HIP_CHECK(hipMemsetAsync(b.qcells.p, 0, ((size_t)nq + 2) * sizeof(unsigned long long), c->st));   // cells per query, added up by the stop rule
     launch_mktasks(b.fin_rec.p, b.qcoff.p, b.perm.p, b.ntask.p, b.roffc.p, b.toff.p, nq, b.dev.d_off.p, c->ref.d_off.p, b.tasks.p,
                    b.rk_slot.p, c->st);
     // k_align runs four alignments per wave and a wave lasts as long as its longest one: every launch list is ordered by band rows,
@@ -1497,12 +1499,12 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                              c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, b.ares.p, false, c->st);
             pt.stop();
         }
-        launch_stop_round(b.tasks.p, b.ares.p, b.qcoff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.toff.p, b.rcnt.p, nq,
-                          b.dev.d_off.p, c->ref.d_off.p, c->d_bittab.p, so_ctx::BITTAB_N, c->ref.N, c->expect, c->max_miss, c->v, b.sel.p,
-                          b.st_state.p, b.bits.p, c->st);
+        launch_stop_round_w(b.tasks.p, b.ares.p, b.qcoff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.toff.p, b.rcnt.p, nq,
+                            b.dev.d_off.p, c->ref.d_off.p, c->d_bittab.p, so_ctx::BITTAB_N, c->ref.N, c->expect, c->max_miss, c->v, b.sel.p,
+                            b.st_state.p, b.bits.p, b.qcells.p, c->st);
         aligned_total += NR + NS;
     }
-    launch_sum_cells(b.ares.p, NT, b.ucount.p + 1, c->st);
+    launch_sum_u64(b.qcells.p, nq, b.ucount.p + 1, c->st);
     sc.lap("phase2.align_rounds");
     c->cnt.alignments += aligned_total;
     b.nout.ensure((size_t)nq + 4), b.ooff.ensure((size_t)nq + 4);

@@ -113,8 +113,16 @@ __global__ __launch_bounds__(256) void k_dir_build(const u32* __restrict__ ub, u
     const u32 k = blockIdx.x * 256u + threadIdx.x;
     if (k >= U) return;
     const u32 b = ub[k], w = b >> 5;
-    atomicOr(&dir32[2 * (size_t)w], 1u << (b & 31u));
-    if (k == 0 || (ub[k - 1] >> 5) != w) dir32[2 * (size_t)w + 1] = k;  // the word's first occupied bucket: ub is ascending
+    if (k != 0 && (ub[k - 1] >> 5) == w) return;
+    // the word's first occupied bucket (ub is ascending) collects the word's bits -- a handful of neighbours -- and stores the word
+    // once: no atomics (round 3; 15 M atomic ORs were 0.32 ms per config-3 chunk)
+    u32 bits = 1u << (b & 31u);
+    for (u32 j = k + 1; j < U; ++j) {
+        const u32 bj = ub[j];
+        if ((bj >> 5) != w) break;
+        bits |= 1u << (bj & 31u);
+    }
+    *reinterpret_cast<uint2*>(dir32 + 2 * (size_t)w) = make_uint2(bits, k);
 }
 
 // sum c, sum c^2, #non-empty, largest non-empty bucket id over counts[0..NC)

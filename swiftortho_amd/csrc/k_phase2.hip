@@ -342,6 +342,133 @@ __global__ __launch_bounds__(64) void k_stop_round(const AlnTask* __restrict__ t
     S[0] = r, S[1] = (u32)unmch, S[2] = (u32)bv, S[3] = nsel, S[4] = done ? 1u : 0u;
 }
 
+// The same rule with a WAVE per query (round 3): the one-thread form walks up to ~90 ranks with three dependent loads per rank, one
+// memory round trip each, for every query in lockstep (0.21 ms per round on config 3).  Here a lane loads one task of the round, all at
+// once; the hit flags become a ballot, and the sequential rule runs over the bits of that mask in registers.  Queries with tiled (long)
+// candidates -- several tasks per rank -- keep the serial walk, done by lane 0.  Also adds the round's cells to the query's counter
+// (qcells; k_sum_u64 adds them up at the end: no pass over every task's result, no zero-fill of the results).
+__global__ __launch_bounds__(64) void k_stop_round_w(const AlnTask* __restrict__ tasks, const AlnRes* __restrict__ res,
+                                                     const u32* __restrict__ qcoff, const u32* __restrict__ ntask,
+                                                     const u32* __restrict__ ntile, const u32* __restrict__ roffc,
+                                                     const u32* __restrict__ rk_slot, const u32* __restrict__ toff,
+                                                     const u32* __restrict__ rcnt, u32 nq, const u32* __restrict__ qoff,
+                                                     const u32* __restrict__ roff, const int* __restrict__ bittab, int bittab_n, i64 D,
+                                                     double expect, double max_miss, i64 v, u32* __restrict__ sel,
+                                                     u32* __restrict__ st_state, int* __restrict__ bits, unsigned long long* __restrict__ qcells) {
+    const u32 q = blockIdx.x, lane = threadIdx.x;
+    const u32 nr = rcnt[q];
+    if (!nr) return;
+    u32* S = st_state + 5 * (size_t)q;
+    const u32 t0 = toff[q], r0 = roffc[q], nt = ntask[q], ntl = ntile[q];
+    const u32 n = qcoff[q + 1] - qcoff[q];
+    double mmiss = (double)n * max_miss + 1;
+    const double inv = 100. / mmiss;
+    mmiss = mmiss > inv ? mmiss : inv;
+    mmiss = mmiss > 10. ? mmiss : 10.;
+    mmiss = mmiss < 120. ? mmiss : 120.;
+    const i64 li = (i64)(qoff[q + 1] - qoff[q]);
+    u32 r = S[0];
+    i64 unmch = S[1], bv = S[2];
+    u32 nsel = S[3];
+    bool done = false;
+    const u32 rend = r + nr;
+    const u32 sA = rank_slot(rk_slot, r0, r, nt, ntl), sB = rank_slot(rk_slot, r0, rend, nt, ntl);
+    unsigned long long cells = 0;
+    bool simple = true;   // every rank of the round is exactly one task
+    for (u32 k = lane; k < nr; k += 64) simple = simple && (rank_slot(rk_slot, r0, r + k + 1, nt, ntl) - rank_slot(rk_slot, r0, r + k, nt, ntl) == 1u);
+    if (!__all(simple)) {
+        // tiled candidates: the serial walk (lane 0); the other lanes only add up cells
+        for (u32 s = sA + lane; s < sB; s += 64) cells += (unsigned long long)(u32)res[t0 + s].cells;
+        if (lane == 0) {
+            for (; r < rend; ++r) {
+                const u32 s0 = rank_slot(rk_slot, r0, r, nt, ntl), s1 = rank_slot(rk_slot, r0, r + 1, nt, ntl);
+                bool hit = false;
+                for (u32 s = s0; s < s1; ++s) {  // one task, or the tiles of a long candidate (3085-3096)
+                    const AlnTask tk = tasks[t0 + s];
+                    const AlnRes a = res[t0 + s];
+                    const i64 lj = (i64)(roff[tk.subj + 1] - roff[tk.subj]);
+                    const int sc = a.maxscore < bittab_n ? a.maxscore : bittab_n - 1;
+                    const int bit = bittab[sc];
+                    bits[t0 + s] = bit;
+                    const double p2 = bit > 1074 ? 0.0 : ldexp(1.0, -bit);
+                    const double e = (double)(D * li * lj) * p2;  // bit2e (1086), full sequence lengths
+                    if (e <= expect) {
+                        sel[t0 + nsel++] = s;
+                        hit = true;
+                        bv += 1;
+                    }
+                }
+                if (hit) unmch = 0;
+                else unmch += 1;
+                if ((double)unmch >= mmiss || (double)bv >= (double)v + mmiss) {
+                    done = true;
+                    ++r;
+                    break;
+                }
+            }
+            if (r >= nt) done = true;
+            S[0] = r, S[1] = (u32)unmch, S[2] = (u32)bv, S[3] = nsel, S[4] = done ? 1u : 0u;
+        }
+    } else {
+        // one task per rank: 64 ranks per step
+        u32 covered = 0;   // ranks whose cells are counted
+        for (u32 c0 = 0; c0 < nr && !done; c0 += 64) {
+            covered = min(nr, c0 + 64u);
+            const u32 k = c0 + lane, s = sA + k;
+            bool hit = false;
+            int bit = 0;
+            if (k < nr) {
+                const AlnTask tk = tasks[t0 + s];
+                const AlnRes a = res[t0 + s];
+                cells += (unsigned long long)(u32)a.cells;
+                const i64 lj = (i64)(roff[tk.subj + 1] - roff[tk.subj]);
+                const int sc = a.maxscore < bittab_n ? a.maxscore : bittab_n - 1;
+                bit = bittab[sc];
+                const double p2 = bit > 1074 ? 0.0 : ldexp(1.0, -bit);
+                hit = (double)(D * li * lj) * p2 <= expect;
+            }
+            const unsigned long long hb = __ballot(hit);
+            const u32 cnt = min(64u, nr - c0);
+            u32 used = cnt;   // ranks of this step the rule looks at
+            for (u32 i = 0; i < cnt; ++i) {   // (wave-uniform: registers only)
+                if ((hb >> i) & 1ull) unmch = 0, bv += 1;
+                else unmch += 1;
+                if ((double)unmch >= mmiss || (double)bv >= (double)v + mmiss) {
+                    done = true;
+                    used = i + 1;
+                    break;
+                }
+            }
+            if (lane < used) {
+                bits[t0 + s] = bit;
+                if (hit) sel[t0 + nsel + (u32)__popcll(hb & ((1ull << lane) - 1ull))] = s;
+            }
+            nsel += (u32)__popcll(used >= 64 ? hb : (hb & ((1ull << used) - 1ull)));
+            r += used;
+        }
+        // the cells of ranks behind a stop inside the round were computed too
+        for (u32 k = covered + lane; k < nr; k += 64) cells += (unsigned long long)(u32)res[t0 + sA + k].cells;
+        if (r >= nt) done = true;
+        if (lane == 0) S[0] = r, S[1] = (u32)unmch, S[2] = (u32)bv, S[3] = nsel, S[4] = done ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cells += __shfl_xor(cells, o);
+    if (lane == 0 && cells) qcells[q] += cells;
+}
+
+__global__ __launch_bounds__(256) void k_sum_u64(const unsigned long long* __restrict__ x, u32 n, unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long s_w[4];
+    unsigned long long c = 0;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) c += x[i];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (c) atomicAdd(total, c);
+    }
+}
+
 // qsort_u(m8s, key=-bit) (3108) + first v (3109).  A wave per query replays the reference quicksort on (inverted bit score, list
 // position) words in LDS (lists of up to FSEL_CAP rows: -v 500 keeps them there); longer lists take the one-thread replay.  (One
 // thread per query was 9 ms per batch on the 1 M-protein run, where every query reports its full 500 rows: 2.4 s of 121.)
@@ -391,20 +518,20 @@ __global__ __launch_bounds__(64) void k_final_select(const u32* __restrict__ tof
 // task slots of the rows that will be reported (the traced second aligner pass runs on these only)
 __global__ __launch_bounds__(64) void k_selected_idx(const u32* __restrict__ toff, const u32* __restrict__ sel, const u32* __restrict__ nout,
                                                      const u32* __restrict__ ooff, u32 nq, u32* __restrict__ idx) {
-    const u32 q = blockIdx.x * 64u + threadIdx.x;
+    const u32 q = blockIdx.x;   // a wave per query, a lane per row (a thread per query walked its rows one dependent load at a time)
     if (q >= nq) return;
     const u32 t0 = toff[q], no = nout[q], o0 = ooff[q];
-    for (u32 k = 0; k < no; ++k) idx[o0 + k] = t0 + sel[t0 + k];
+    for (u32 k = threadIdx.x; k < no; k += 64) idx[o0 + k] = t0 + sel[t0 + k];
 }
 
 __global__ __launch_bounds__(64) void k_emit_hits(const AlnTask* __restrict__ tasks, const AlnRes* __restrict__ res,
                                                   const u32* __restrict__ toff, const u32* __restrict__ sel, const u32* __restrict__ nout,
                                                   const u32* __restrict__ ooff, const int* __restrict__ bits, u32 q0, u32 nq,
                                                   int* __restrict__ out) {
-    const u32 q = q0 + blockIdx.x * 64u + threadIdx.x;   // queries [q0, nq) of the batch
+    const u32 q = q0 + blockIdx.x;   // queries [q0, nq) of the batch: a wave per query, a lane per row
     if (q >= nq) return;
     const u32 t0 = toff[q], no = nout[q], o0 = ooff[q];
-    for (u32 k = 0; k < no; ++k) {
+    for (u32 k = threadIdx.x; k < no; k += 64) {
         const u32 r = sel[t0 + k];
         const AlnTask tk = tasks[t0 + r];
         const AlnRes a = res[t0 + r];
@@ -526,6 +653,20 @@ void launch_stop_round(const AlnTask* tasks, const AlnRes* res, const u32* qcoff
                        nq, qoff, roff, bittab, bittab_n, D, expect, max_miss, v, sel, st_state, bits);
 }
 
+void launch_stop_round_w(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* ntile, const u32* roffc,
+                         const u32* rk_slot, const u32* toff, const u32* rcnt, u32 nq, const u32* qoff, const u32* roff, const int* bittab,
+                         int bittab_n, i64 D, double expect, double max_miss, i64 v, u32* sel, u32* st_state, int* bits,
+                         unsigned long long* qcells, hipStream_t st) {
+    if (!nq) return;
+    hipLaunchKernelGGL(k_stop_round_w, dim3(nq), dim3(64), 0, st, tasks, res, qcoff, ntask, ntile, roffc, rk_slot, toff, rcnt, nq, qoff, roff,
+                       bittab, bittab_n, D, expect, max_miss, v, sel, st_state, bits, qcells);
+}
+
+void launch_sum_u64(const unsigned long long* x, u32 n, unsigned long long* total, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_sum_u64, dim3(std::min<u32>(64u, (n + 255) / 256)), dim3(256), 0, st, x, n, total);
+}
+
 void launch_final_select(const u32* toff, u32 nq, i64 v, u32* sel, const u32* st_state, const int* bits, u32* nout, hipStream_t st) {
     if (!nq) return;
     // nout arrives filled with 0xFFFFFFFF: the wave kernel writes the count of every query it handles, the serial one takes the rest
@@ -535,13 +676,13 @@ void launch_final_select(const u32* toff, u32 nq, i64 v, u32* sel, const u32* st
 
 void launch_selected_idx(const u32* toff, const u32* sel, const u32* nout, const u32* ooff, u32 nq, u32* idx, hipStream_t st) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_selected_idx, dim3((nq + 63) / 64), dim3(64), 0, st, toff, sel, nout, ooff, nq, idx);
+    hipLaunchKernelGGL(k_selected_idx, dim3(nq), dim3(64), 0, st, toff, sel, nout, ooff, nq, idx);
 }
 
 void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, const u32* sel, const u32* nout, const u32* ooff,
                       const int* bits, u32 q0, u32 q1, int* out, hipStream_t st) {
     if (q1 <= q0) return;
-    hipLaunchKernelGGL(k_emit_hits, dim3((q1 - q0 + 63) / 64), dim3(64), 0, st, tasks, res, toff, sel, nout, ooff, bits, q0, q1, out);
+    hipLaunchKernelGGL(k_emit_hits, dim3(q1 - q0), dim3(64), 0, st, tasks, res, toff, sel, nout, ooff, bits, q0, q1, out);
 }
 
 void launch_sum_cells(const AlnRes* res, u32 n, unsigned long long* total, hipStream_t st) {
