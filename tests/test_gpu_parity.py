@@ -705,11 +705,14 @@ def test_two_rank_search_over_rccl_on_two_gpus(tmp_path):
     assert outs[0].count(b"\n") > 5000 and outs[0] == outs[1]
 
 
-def test_device_resident_results_and_query_work(fs):
+@pytest.mark.parametrize("spec", ["0", "1"])
+def test_device_resident_results_and_query_work(fs, monkeypatch, spec):
     """so_search_device leaves the same 80-byte so_hit records in HBM that so_search_loaded returns on the host (identity and
-    e-value evaluated on the device: bit-equal doubles); so_query_work's per-query counts add up to the seed hits searched."""
+    e-value evaluated on the device: bit-equal doubles); so_query_work's per-query counts add up to the seed hits searched.
+    Both with and without the speculative traces of the first aligner round."""
     import torch
     from swiftortho_amd import synthprot
+    monkeypatch.setenv("SOHIT_SPEC", spec)
     fa = synthprot.synthprot(1500, 200, 3)
     kw = dict(ssd="111111", nr="AST,CFILMVY,DN,EQ,G,H,KR,P,W", ht=120000000, chk=700, step=1, v=500, expect=1e-5, flt="T")
     s = fs.Searcher(**kw)
