@@ -1310,7 +1310,7 @@ void emit_join(so_ctx* c, HitBuf& out) {
         std::rethrow_exception(e);
     }
     if (c->emit.dropped.load()) {
-        // entry_point re-checks e <= expect (3234).  k_stop_round applied the same test to the same
+        // entry_point re-checks e <= expect (3234).  k_stop_round_w applied the same test to the same
         // doubles, so this never fires; kept as the reference has it.
         const double expect = c->expect;
         size_t wpos = c->emit.base;
@@ -1411,7 +1411,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, list, b.ridx2.p, n, 13, c->st);
         return b.ridx2.p;
     };
-    // banded alignments in rounds (see k_round_counts / k_stop_round)
+    // banded alignments in rounds (see k_round_counts / k_stop_round_w)
     const u32 maxwin_q = std::min<u32>(b.maxqlen, LONG_SEQ), maxwin_s = std::min<u32>(c->ref.maxlen, LONG_SEQ);
     const int maxrows = (int)std::min<u32>(std::max(maxwin_q, maxwin_s), std::min(maxwin_q, maxwin_s) + 16);
     const u32 stride = align_trace_stride(maxrows + 1);

@@ -102,7 +102,7 @@ __device__ __forceinline__ void dp_cell(m64 valid, int I, int D, int Bd, int s, 
 #define AL_TAB (SCLS_N * 256)
 
 // trace codes: 0 '*' (stop), 1 '\\' (diag), 2 '-' (left), 3 '|' (up)
-// TRACE = false: score-only run (maximum and its cell): the early-stop rule (k_stop_round) needs nothing else, and only the
+// TRACE = false: score-only run (maximum and its cell): the early-stop rule (k_stop_round_w) needs nothing else, and only the
 // few alignments that end up reported are run again with TRACE = true for the traceback.
 template <bool TRACE>
 __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 ntasks,

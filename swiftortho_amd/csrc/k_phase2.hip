@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64) void k_mktasks(const u32* __restrict__ rec, con
 // The reference aligns a query's sorted candidates one by one and stops after `mmiss` consecutive
 // misses (3052-3054, 3062-3104), so only a prefix of the top-vmax list is ever aligned.  The
 // device aligns that list in growing rounds: each round aligns the next B ranks of every query
-// that has not stopped, then k_stop_round replays the sequential rule over them.  Per-query state
+// that has not stopped, then k_stop_round_w replays the sequential rule over them.  Per-query state
 // st_state[5*q + {0 next rank, 1 unmch, 2 bv, 3 nsel, 4 done}].
 __device__ __forceinline__ u32 rank_slot(const u32* rk_slot, u32 r0, u32 r, u32 nt, u32 ntile_q) {
     return r < nt ? rk_slot[r0 + r] : ntile_q;
@@ -286,65 +286,8 @@ __global__ __launch_bounds__(64) void k_round_idx(const u32* __restrict__ tcnt, 
     for (u32 k = threadIdx.x; k < n; k += 64) ridx[o + k] = base + k;
 }
 
-__global__ __launch_bounds__(64) void k_stop_round(const AlnTask* __restrict__ tasks, const AlnRes* __restrict__ res,
-                                                   const u32* __restrict__ qcoff, const u32* __restrict__ ntask,
-                                                   const u32* __restrict__ ntile, const u32* __restrict__ roffc,
-                                                   const u32* __restrict__ rk_slot, const u32* __restrict__ toff,
-                                                   const u32* __restrict__ rcnt, u32 nq, const u32* __restrict__ qoff,
-                                                   const u32* __restrict__ roff, const int* __restrict__ bittab, int bittab_n, i64 D,
-                                                   double expect, double max_miss, i64 v, u32* __restrict__ sel,
-                                                   u32* __restrict__ st_state, int* __restrict__ bits) {
-    const u32 q = blockIdx.x * 64u + threadIdx.x;
-    if (q >= nq) return;
-    const u32 nr = rcnt[q];
-    if (!nr) return;
-    u32* S = st_state + 5 * (size_t)q;
-    const u32 t0 = toff[q], r0 = roffc[q], nt = ntask[q], ntl = ntile[q];
-    const u32 n = qcoff[q + 1] - qcoff[q];
-    double mmiss = (double)n * max_miss + 1;
-    const double inv = 100. / mmiss;
-    mmiss = mmiss > inv ? mmiss : inv;
-    mmiss = mmiss > 10. ? mmiss : 10.;
-    mmiss = mmiss < 120. ? mmiss : 120.;
-    const i64 li = (i64)(qoff[q + 1] - qoff[q]);
-    u32 r = S[0];
-    i64 unmch = S[1], bv = S[2];
-    u32 nsel = S[3];
-    bool done = false;
-    const u32 rend = r + nr;
-    for (; r < rend; ++r) {
-        const u32 s0 = rank_slot(rk_slot, r0, r, nt, ntl), s1 = rank_slot(rk_slot, r0, r + 1, nt, ntl);
-        bool hit = false;
-        for (u32 s = s0; s < s1; ++s) {  // one task, or the tiles of a long candidate (3085-3096)
-            const AlnTask tk = tasks[t0 + s];
-            const AlnRes a = res[t0 + s];
-            const i64 lj = (i64)(roff[tk.subj + 1] - roff[tk.subj]);
-            const int sc = a.maxscore < bittab_n ? a.maxscore : bittab_n - 1;
-            const int bit = bittab[sc];
-            bits[t0 + s] = bit;
-            const double p2 = bit > 1074 ? 0.0 : ldexp(1.0, -bit);
-            const double e = (double)(D * li * lj) * p2;  // bit2e (1086), full sequence lengths
-            if (e <= expect) {
-                sel[t0 + nsel++] = s;
-                hit = true;
-                bv += 1;
-            }
-        }
-        if (hit) unmch = 0;
-        else unmch += 1;
-        if ((double)unmch >= mmiss || (double)bv >= (double)v + mmiss) {
-            done = true;
-            ++r;
-            break;
-        }
-    }
-    if (r >= nt) done = true;
-    S[0] = r, S[1] = (u32)unmch, S[2] = (u32)bv, S[3] = nsel, S[4] = done ? 1u : 0u;
-}
-
-// The same rule with a WAVE per query (round 3): the one-thread form walks up to ~90 ranks with three dependent loads per rank, one
-// memory round trip each, for every query in lockstep (0.21 ms per round on config 3).  Here a lane loads one task of the round, all at
-// once; the hit flags become a ballot, and the sequential rule runs over the bits of that mask in registers.  Queries with tiled (long)
+// A WAVE per query (round 3): a thread per query walked up to ~90 ranks with three dependent loads per rank, one memory round trip
+// each, for every query in lockstep (0.21 ms per round on config 3).  Here a lane loads one task of the round, all at once; the hit flags become a ballot, and the sequential rule runs over the bits of that mask in registers.  Queries with tiled (long)
 // candidates -- several tasks per rank -- keep the serial walk, done by lane 0.  Also adds the round's cells to the query's counter
 // (qcells; k_sum_u64 adds them up at the end: no pass over every task's result, no zero-fill of the results).
 __global__ __launch_bounds__(64) void k_stop_round_w(const AlnTask* __restrict__ tasks, const AlnRes* __restrict__ res,
@@ -571,18 +514,6 @@ __global__ __launch_bounds__(256) void k_make_hits(const int* __restrict__ rows,
     out[i] = h;
 }
 
-__global__ __launch_bounds__(256) void k_sum_cells(const AlnRes* __restrict__ res, u32 n, unsigned long long* __restrict__ total) {
-    __shared__ unsigned long long s_w[4];
-    unsigned long long c = 0;
-    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) c += (unsigned long long)res[i].cells;
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        c = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        if (c) atomicAdd(total, c);
-    }
-}
 
 // ---- launch wrappers -------------------------------------------------------------------------------
 void launch_gather_cands(const u32* src_q, const u32* src_rec, u32 n, const u32* cqoff, const u32* prior, const u32* qcoff,
@@ -644,15 +575,6 @@ void launch_round_idx(const u32* tcnt, const u32* troff, const u32* toff, const 
     hipLaunchKernelGGL(k_round_idx, dim3(nq), dim3(64), 0, st, tcnt, troff, toff, ntask, ntile, roffc, rk_slot, st_state, nq, ridx);
 }
 
-void launch_stop_round(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* ntile, const u32* roffc,
-                       const u32* rk_slot, const u32* toff, const u32* rcnt, u32 nq, const u32* qoff, const u32* roff,
-                       const int* bittab, int bittab_n, i64 D, double expect, double max_miss, i64 v, u32* sel, u32* st_state, int* bits,
-                       hipStream_t st) {
-    if (!nq) return;
-    hipLaunchKernelGGL(k_stop_round, dim3((nq + 63) / 64), dim3(64), 0, st, tasks, res, qcoff, ntask, ntile, roffc, rk_slot, toff, rcnt,
-                       nq, qoff, roff, bittab, bittab_n, D, expect, max_miss, v, sel, st_state, bits);
-}
-
 void launch_stop_round_w(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* ntile, const u32* roffc,
                          const u32* rk_slot, const u32* toff, const u32* rcnt, u32 nq, const u32* qoff, const u32* roff, const int* bittab,
                          int bittab_n, i64 D, double expect, double max_miss, i64 v, u32* sel, u32* st_state, int* bits,
@@ -685,10 +607,6 @@ void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, 
     hipLaunchKernelGGL(k_emit_hits, dim3(q1 - q0), dim3(64), 0, st, tasks, res, toff, sel, nout, ooff, bits, q0, q1, out);
 }
 
-void launch_sum_cells(const AlnRes* res, u32 n, unsigned long long* total, hipStream_t st) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_sum_cells, dim3(std::min<u32>(128u, (n + 255) / 256)), dim3(256), 0, st, res, n, total);
-}
 
 void launch_make_hits(const int* rows, u32 n, i64 q_lo, const u32* qoff_abs, const u32* roff, i64 D, const double* p2tab, int p2n, void* out,
                       hipStream_t st) {

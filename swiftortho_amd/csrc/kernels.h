@@ -119,15 +119,10 @@ void launch_round_counts(const u32* ntask, const u32* ntile, const u32* roffc, c
                          const u32* st_state, u32 nq, double max_miss, u32 minr, u32* rcnt, u32* tcnt, hipStream_t st);
 void launch_round_idx(const u32* tcnt, const u32* troff, const u32* toff, const u32* ntask, const u32* ntile, const u32* roffc,
                       const u32* rk_slot, const u32* st_state, u32 nq, u32* ridx, hipStream_t st);
-void launch_stop_round(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* ntile, const u32* roffc,
-                       const u32* rk_slot, const u32* toff, const u32* rcnt, u32 nq, const u32* qoff, const u32* roff,
-                       const int* bittab, int bittab_n, i64 D, double expect, double max_miss, i64 v, u32* sel, u32* st_state, int* bits,
-                       hipStream_t st);
 void launch_final_select(const u32* toff, u32 nq, i64 v, u32* sel, const u32* st_state, const int* bits, u32* nout, hipStream_t st);
 void launch_selected_idx(const u32* toff, const u32* sel, const u32* nout, const u32* ooff, u32 nq, u32* idx, hipStream_t st);
 void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, const u32* sel, const u32* nout, const u32* ooff,
                       const int* bits, u32 q0, u32 q1 /*queries [q0, q1) of the batch*/, int* out, hipStream_t st);
-void launch_sum_cells(const AlnRes* res, u32 n, unsigned long long* total, hipStream_t st);
 // so_hit records on the device (80 bytes each) from k_emit_hits rows; qoff_abs = offsets of the whole loaded query set
 void launch_make_hits(const int* rows, u32 n, i64 q_lo, const u32* qoff_abs, const u32* roff, i64 D, const double* p2tab, int p2n, void* out,
                       hipStream_t st);

@@ -152,5 +152,8 @@ def test_bench_gpus_n_launches_its_own_ranks():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "c2",
                         "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode != 0
-    assert p.stderr.count("bench.py needs a GPU") >= 2, p.stderr[-3000:]
+    # both ranks were started (the launcher's failure report names rank 1) and at least the first one to fail said why: the
+    # launcher terminates the other rank as soon as one has failed, sometimes before it has printed its own message
+    assert p.stderr.count("bench.py needs a GPU") >= 1, p.stderr[-3000:]
+    assert "local_rank: 1" in p.stderr, p.stderr[-3000:]
     assert '"metric"' not in p.stdout
