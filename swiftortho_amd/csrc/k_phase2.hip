@@ -619,18 +619,17 @@ void launch_make_hits(const int* rows, u32 n, i64 q_lo, const u32* qoff_abs, con
 // k_align runs four alignments per wave: a wave lasts as long as its longest one.  Key = 8191 - R (longest first), R = rows of the
 // band (see k_align); the launch list is then sorted on it.
 __global__ __launch_bounds__(256) void k_task_rows(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 n,
-                                                   const u32* __restrict__ qoff, const u32* __restrict__ roff, u64* __restrict__ keys, int qshift) {
+                                                   const u32* __restrict__ qoff, const u32* __restrict__ roff, u64* __restrict__ keys) {
     const u32 t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n) return;
     const AlnTask tk = tasks[ridx ? ridx[t] : t];
     const int lq = min((int)(qoff[tk.q + 1] - qoff[tk.q]), (int)tk.qe), ls = min((int)(roff[tk.subj + 1] - roff[tk.subj]), (int)tk.se);
     const int la = lq - min((int)tk.qi, lq), lb = ls - min((int)tk.qj, ls);
     const int ncols = min(la, lb), nrows = max(la, lb);
-    // qshift < 32: blocks of 2^qshift queries are kept together (key = block << 13 | rows key): their class arrays stay in cache
-    keys[t] = ((u64)(qshift < 32 ? tk.q >> qshift : 0u) << 13) | (u64)(8191 - min(min(nrows, ncols + 16), 8191));
+    keys[t] = (u64)(8191 - min(min(nrows, ncols + 16), 8191));
 }
 
-void launch_task_rows(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, u64* keys, int qshift, hipStream_t st) {
+void launch_task_rows(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, u64* keys, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_task_rows, dim3((n + 255) / 256), dim3(256), 0, st, tasks, ridx, n, qoff, roff, keys, qshift);
+    hipLaunchKernelGGL(k_task_rows, dim3((n + 255) / 256), dim3(256), 0, st, tasks, ridx, n, qoff, roff, keys);
 }

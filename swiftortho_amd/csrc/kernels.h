@@ -167,5 +167,4 @@ void launch_stop_round_w(const AlnTask* tasks, const AlnRes* res, const u32* qco
                          int bittab_n, i64 D, double expect, double max_miss, i64 v, u32* sel, u32* st_state, int* bits,
                          unsigned long long* qcells /*[nq], += cells of the round*/, hipStream_t st);
 void launch_sum_u64(const unsigned long long* x, u32 n, unsigned long long* total, hipStream_t st);
-void launch_task_rows(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, u64* keys, int qshift /*32: no query blocks*/,
-                      hipStream_t st);
+void launch_task_rows(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, u64* keys, hipStream_t st);
