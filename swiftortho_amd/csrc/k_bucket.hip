@@ -143,6 +143,9 @@ static BkHist bk_hist_layout(u32 R, bool staged, bool skewed) {
 // consecutive staged words = two to four runs of consecutive addresses, instead of 64 lanes landing in ~R different lines
 // (the texture-address path takes a cycle per distinct line per instruction: the round-2 kernel spent more time issuing
 // its sixteen scattered stores than reading the index).
+#ifndef BK_NT
+#define BK_NT 1   // index entries are read once per pass: non-temporal loads
+#endif
 template <bool SCATTER, bool STAGED, int WPE = 6>
 __global__ __launch_bounds__(64 * BK_WAVES, WPE) void k_bkt_pass(const uint4* __restrict__ td, const u32* __restrict__ qseg, u32 NT,
                                                               const u32* __restrict__ cs_hoff, const u32* __restrict__ cs_base,
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(64 * BK_WAVES, WPE) void k_bkt_pass(const uint4* __
             const u32 a = max(inc, carry);
             carry = max(carry, (u32)__builtin_amdgcn_readlane((int)inc, 63));
             slot[it] = (u32)s_qpos[a];                                    // the seed's qpos, for now
-            word[it] = dk32[s_base[a] + lo + min(hl, len - 1u)];          // the index addend, for now
+            word[it] = BK_NT ? __builtin_nontemporal_load(&dk32[s_base[a] + lo + min(hl, len - 1u)]) : dk32[s_base[a] + lo + min(hl, len - 1u)];   // the index addend, for now
         }
     } else {
 #pragma unroll
