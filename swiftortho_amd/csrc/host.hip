@@ -1087,6 +1087,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     u64* c_ftp = nullptr;   // candidates of the pass: first-touch key, query, [subject, score, qi, qj]
     u32 *c_qp = nullptr, *c_recp = nullptr;
     u32 NS = 0, maxseg = 0xFFFFFFFFu;  // candidates of the pass; the longest per-query segment (sparse path only)
+    int cand_idx_bits = 0, cand_ftw = 0;   // > 0: k_bkt_best wrote sort words (first-touch word << idx_bits | position in the query's segment)
     for (;;) {
         // contiguous pass list; the group counters and the pass total come back in one synchronisation
         u32* shard_off = b.shard.p + UG_SHARDS;
@@ -1121,13 +1122,24 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
             launch_rec_scatter(b.p_qs.p, b.p_sd.p, b.p_ft.p, b.pidx.p, NP, kl, bL, ft_bits_entry, bsp, c->ref.d_off.p + ch.seq_lo, b.bcnt.p, b.q_qs.p,
                                b.q_sd.p, b.q_ft.p, c->st);
             HIP_CHECK(hipMemsetAsync(b.bccnt.p + bnb, 0, 2 * sizeof(u32), c->st));
-            launch_bkt_best(false, b.q_qs.p, b.q_sd.p, b.q_ft.p, b.bcnt.p, bnb, bL, kl.bs, (u32)ch.seq_lo, b.bccnt.p, nullptr, nullptr, nullptr, c->st);
+            launch_bkt_best(false, b.q_qs.p, b.q_sd.p, b.q_ft.p, b.bcnt.p, bnb, bL, kl.bs, (u32)ch.seq_lo, b.bccnt.p, nullptr, nullptr, nullptr, bsp, 0,
+                            c->st);
             NS = d2h_u32(c, scan_u32(b.bccnt.p, b.bccnt.p, (size_t)bnb + 1, false, c->d_scan_tmp.p, c->st));
             if (getenv("SOHIT_DEBUG"))
                 fprintf(stderr, "[sohit] seed pass: queries %u..%u hits %u seeds %u pass records %u candidates %u (bucketed best)\n", qa, qb, H, K, NP, NS);
             b.c_ft.ensure((size_t)NS + 2), b.c_q.ensure((size_t)NS + 2), b.c_rec.ensure(4 * (size_t)NS + 8);
             c_ftp = b.c_ft.p, c_qp = b.c_q.p, c_recp = b.c_rec.p;
-            launch_bkt_best(true, b.q_qs.p, b.q_sd.p, b.q_ft.p, b.bcnt.p, bnb, bL, kl.bs, (u32)ch.seq_lo, b.bccnt.p, c_ftp, c_qp, c_recp, c->st);
+            {
+                // candidate order as a keys-only segmented sort: the sort word = first-touch word << idx_bits | position inside the query's
+                // segment (written by k_bkt_best itself) when both fit 63 bits (bit 63 stays free: see sort_cand_keys_seg) -- no index
+                // array, no key-build pass, 8 instead of 12 bytes per candidate and radix pass (SOHIT_CAND_KEYS=0: the pairs sort)
+                static const bool cand_keys = !(getenv("SOHIT_CAND_KEYS") && atoi(getenv("SOHIT_CAND_KEYS")) == 0);
+                static const bool cand_seg0 = !(getenv("SOHIT_CAND_SEGSORT") && atoi(getenv("SOHIT_CAND_SEGSORT")) == 0);
+                const int ftw = kl.ba + kl.bp + ft_bits_entry - bsp + 1;
+                if (cand_keys && cand_seg0 && bL.nqp >= 256 && ftw < 63 && 63 - ftw >= kl.bs + 1) cand_idx_bits = 63 - ftw, cand_ftw = ftw;
+            }
+            launch_bkt_best(true, b.q_qs.p, b.q_sd.p, b.q_ft.p, b.bcnt.p, bnb, bL, kl.bs, (u32)ch.seq_lo, b.bccnt.p, c_ftp, c_qp, c_recp, bsp,
+                            cand_idx_bits, c->st);
             break;
         }
         // first-touch keys of the passing groups (k_ungap left the head hit's key / position in the third array)
@@ -1169,6 +1181,24 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
         b.cand_rec.ensure(4 * ((size_t)base + NS) + 16, true, c->st);
         launch_cand_order_lds(c_ftp, c_recp, b.qseg.p, b.nq, maxseg, bsp, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, c->st);
+        b.chunk_base.back() = base + NS;
+        c->cnt.candidates += NS;
+        sc.lap("group.best_order");
+        c->cnt.seed_ms += (t1 - t0) * 1e3;
+        c->cnt.group_ms += (wall() - t1) * 1e3;
+        return;
+    }
+    if (cand_idx_bits) {
+        const u32 base = b.chunk_base.back();
+        const char* lim = getenv("SOHIT_CAND_LIMIT");  // (tests lower the limit to exercise the split)
+        if ((u64)base + NS >= (lim ? (u64)atoll(lim) : 0xFFFFFFF0ull)) throw CandOverflow();
+        b.qseg.ensure((size_t)b.nq + 4), b.tmp64.ensure((size_t)NS + 2);
+        launch_stride_gather(b.bccnt.p, bL.R, bL.nqp + 1, b.qseg.p, c->st);
+        ensure_sort_tmp(c, sort_cand_keys_seg_temp_bytes(NS, bL.nqp, cand_idx_bits, cand_idx_bits + cand_ftw));
+        sort_cand_keys_seg(c->d_sort_tmp.p, c->d_sort_tmp.cap, c_ftp, b.tmp64.p, NS, bL.nqp, b.qseg.p, cand_idx_bits, cand_idx_bits + cand_ftw, c->st);
+        b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
+        b.cand_rec.ensure(4 * ((size_t)base + NS) + 16, true, c->st);
+        launch_emit_cands_seg(b.tmp64.p, b.qseg.p, bL.nqp, bL.qa, cand_idx_bits, c_recp, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, c->st);
         b.chunk_base.back() = base + NS;
         c->cnt.candidates += NS;
         sc.lap("group.best_order");

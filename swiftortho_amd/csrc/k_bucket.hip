@@ -612,7 +612,10 @@ template <bool WRITE>
 __global__ __launch_bounds__(BB_THREADS) void k_bkt_best(const u64* __restrict__ q_qs, const u64* __restrict__ q_sd, const u64* __restrict__ q_ft,
                                                         const u32* __restrict__ boff /*nb + 1*/, u32 nb, BktLayout L, int bs, u32 seq_lo,
                                                         u32* __restrict__ ccnt /*!WRITE: out; WRITE: scanned, in*/, u64* __restrict__ c_ft,
-                                                        u32* __restrict__ c_q, u32* __restrict__ c_rec) {
+                                                        u32* __restrict__ c_q, u32* __restrict__ c_rec, int bsp, int idx_bits) {
+    // idx_bits > 0 (WRITE): instead of (first-touch key, query) the kernel writes ONE sort word per candidate into c_ft:
+    // first-touch word << idx_bits | position inside the query's segment -- the candidate order then is a keys-only segmented sort
+    // on the word's upper bits, and the row gather reads the position out of the sorted word (no index array, no key-build pass)
     __shared__ unsigned long long s_best[BG_BINS], s_min[BG_BINS];
     __shared__ u32 s_pref[BG_BINS];
     __shared__ u32 s_wsum[BB_THREADS / 64];
@@ -674,6 +677,8 @@ __global__ __launch_bounds__(BB_THREADS) void k_bkt_best(const u64* __restrict__
         }
         __syncthreads();
         const u32 base = ccnt[ci];
+        const u32 seg0 = idx_bits ? ccnt[qrel * L.R] : 0u;   // first candidate of the query
+        const u64 pmk = (1ull << bsp) - 1ull;
         const u32 gq = L.qa + qrel;
         for (u32 i = (u32)tid; i < n; i += BB_THREADS) {
             const u64 qs = q_qs[b0 + i], sd = q_sd[b0 + i], ft = q_ft[b0 + i];
@@ -684,8 +689,13 @@ __global__ __launch_bounds__(BB_THREADS) void k_bkt_best(const u64* __restrict__
             u32 qi, qj;
             if (bdist > 0) qi = 0, qj = (u32)bdist;
             else qi = (u32)(-bdist), qj = 0;
-            c_ft[o] = s_min[s];
-            c_q[o] = gq;
+            if (idx_bits) {
+                const u64 ft = s_min[s];
+                c_ft[o] = ((((ft >> bsp) << 1) | ((ft & pmk) == pmk ? 1ull : 0ull)) << idx_bits) | (u64)(o - seg0);
+            } else {
+                c_ft[o] = s_min[s];
+                c_q[o] = gq;
+            }
             *reinterpret_cast<uint4*>(c_rec + 4 * (size_t)o) = make_uint4(((u32)qs & ((1u << bs) - 1u)) + seq_lo, (u32)(sd >> 32), qi, qj);
         }
     }
@@ -761,9 +771,31 @@ void launch_rec_scatter(const u64* p_qs, const u64* p_sd, const u64* p_ft, const
 }
 
 void launch_bkt_best(bool write, const u64* q_qs, const u64* q_sd, const u64* q_ft, const u32* boff, u32 nb, const BktLayout& L, int bs,
-                     u32 seq_lo, u32* ccnt, u64* c_ft, u32* c_q, u32* c_rec, hipStream_t st) {
+                     u32 seq_lo, u32* ccnt, u64* c_ft, u32* c_q, u32* c_rec, int bsp, int idx_bits, hipStream_t st) {
     if (!nb) return;
     const u32 grid = std::min<u32>(nb, 256u * 8u);
-    if (write) hipLaunchKernelGGL(k_bkt_best<true>, dim3(grid), dim3(BB_THREADS), 0, st, q_qs, q_sd, q_ft, boff, nb, L, bs, seq_lo, ccnt, c_ft, c_q, c_rec);
-    else hipLaunchKernelGGL(k_bkt_best<false>, dim3(grid), dim3(BB_THREADS), 0, st, q_qs, q_sd, q_ft, boff, nb, L, bs, seq_lo, ccnt, c_ft, c_q, c_rec);
+    if (write) hipLaunchKernelGGL(k_bkt_best<true>, dim3(grid), dim3(BB_THREADS), 0, st, q_qs, q_sd, q_ft, boff, nb, L, bs, seq_lo, ccnt, c_ft, c_q, c_rec, bsp, idx_bits);
+    else hipLaunchKernelGGL(k_bkt_best<false>, dim3(grid), dim3(BB_THREADS), 0, st, q_qs, q_sd, q_ft, boff, nb, L, bs, seq_lo, ccnt, c_ft, c_q, c_rec, bsp, 0);
+}
+
+// rows of a bucketed pass in candidate order: sorted[i] = first-touch word << idx_bits | position inside the query's segment
+// (k_bkt_best); a workgroup per query copies its records in that order and leaves the query's count
+__global__ __launch_bounds__(256) void k_emit_cands_seg(const u64* __restrict__ sorted, const u32* __restrict__ seg /*nqp + 1*/, u32 qa, int idx_bits,
+                                                        const u32* __restrict__ c_rec, u32* __restrict__ out_q, u32* __restrict__ out_rec,
+                                                        u32* __restrict__ qcnt) {
+    const u32 a = seg[blockIdx.x], n = seg[blockIdx.x + 1] - a;
+    if (!n) return;
+    const u32 q = qa + blockIdx.x;
+    const u64 mask = (1ull << idx_bits) - 1ull;
+    for (u32 i = threadIdx.x; i < n; i += 256) {
+        const u32 r = a + (u32)(sorted[a + i] & mask);
+        out_q[a + i] = q;
+        *reinterpret_cast<uint4*>(out_rec + 4 * (size_t)(a + i)) = *reinterpret_cast<const uint4*>(c_rec + 4 * (size_t)r);
+    }
+    if (threadIdx.x == 0) qcnt[q] = n;
+}
+
+void launch_emit_cands_seg(const u64* sorted, const u32* seg, u32 nqp, u32 qa, int idx_bits, const u32* c_rec, u32* out_q, u32* out_rec, u32* qcnt,
+                           hipStream_t st) {
+    if (nqp) hipLaunchKernelGGL(k_emit_cands_seg, dim3(nqp), dim3(256), 0, st, sorted, seg, qa, idx_bits, c_rec, out_q, out_rec, qcnt);
 }

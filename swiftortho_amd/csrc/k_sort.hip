@@ -128,6 +128,31 @@ void sort_pairs_u64_u32_seg(void* temp, size_t temp_bytes, const u64* kin, u64* 
     if (n == 0) return;
     HIP_CHECK(seg_sort_pairs_dispatch(temp, temp_bytes, kin, kout, vin, vout, n, nseg, seg, seg + 1, begin_bit, end_bit, st));
 }
+// ---- keys-only variant for the candidate order of a bucketed pass (the position rides in the low bits of the sort word) ----------
+// NOTE end_bit must stay below 64: rocPRIM's comparator for short segments builds its mask as (1 << (begin + bits)) - 1, which for
+// begin + bits == 64 shifts by the word size and ends up comparing the bits BELOW begin_bit (ROCm 7.2) -- the caller keeps bit 63 free.
+static hipError_t cand_keys_dispatch(void* temp, size_t& bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* sb, const u32* se, int b0,
+                                     int b1, hipStream_t st) {
+    static const int v = getenv("SOHIT_CSEG_CFG") ? atoi(getenv("SOHIT_CSEG_CFG")) : -1;
+    const size_t avg = nseg ? n / nseg : 0;
+    const int cfg = v >= 0 ? v : avg >= 3072 ? 2 : avg >= 1024 ? 1 : 0;
+    if (cfg == 3) return seg_sort<SegCfg<16, 1024>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
+    if (cfg == 2) return seg_sort<SegCfg<16, 512>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
+    if (cfg == 1) return seg_sort<SegCfg<16>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
+    return seg_sort<rocprim::default_config>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
+}
+size_t sort_cand_keys_seg_temp_bytes(size_t n, u32 nseg, int begin_bit, int end_bit) {
+    size_t bytes = 0;
+    (void)cand_keys_dispatch(nullptr, bytes, nullptr, nullptr, n, nseg, nullptr, nullptr, begin_bit, end_bit, (hipStream_t)0);
+    return bytes;
+}
+void sort_cand_keys_seg(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* seg, int begin_bit, int end_bit,
+                        hipStream_t st) {
+    if (n == 0) return;
+    if (end_bit >= 64) throw SoError("sort_cand_keys_seg: end_bit must be below 64");
+    HIP_CHECK(cand_keys_dispatch(temp, temp_bytes, in, out, n, nseg, seg, seg + 1, begin_bit, end_bit, st));
+}
+
 __global__ __launch_bounds__(256) void k_stride_gather(const u32* __restrict__ src, u32 stride, u32 n, u32* __restrict__ dst) {
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) dst[i] = src[(size_t)i * stride];

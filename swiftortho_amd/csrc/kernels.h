@@ -147,7 +147,12 @@ void launch_rec_count(const u64* p_qs, u32 n, int bs, const BktLayout& L, u32* b
 void launch_rec_scatter(const u64* p_qs, const u64* p_sd, const u64* p_ft, const u32* rnk, u32 n, const KeyLayout& kl, const BktLayout& L,
                         int ft_bits_entry, int bsp, const u32* roff, const u32* boff, u64* q_qs, u64* q_sd, u64* q_ft, hipStream_t st);
 void launch_bkt_best(bool write, const u64* q_qs, const u64* q_sd, const u64* q_ft, const u32* boff, u32 nb, const BktLayout& L, int bs,
-                     u32 seq_lo, u32* ccnt, u64* c_ft, u32* c_q, u32* c_rec, hipStream_t st);
+                     u32 seq_lo, u32* ccnt, u64* c_ft, u32* c_q, u32* c_rec, int bsp, int idx_bits /*> 0: c_ft receives sort words*/, hipStream_t st);
+void launch_emit_cands_seg(const u64* sorted, const u32* seg, u32 nqp, u32 qa, int idx_bits, const u32* c_rec, u32* out_q, u32* out_rec, u32* qcnt,
+                           hipStream_t st);
+size_t sort_cand_keys_seg_temp_bytes(size_t n, u32 nseg, int begin_bit, int end_bit);
+void sort_cand_keys_seg(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* seg, int begin_bit, int end_bit,
+                        hipStream_t st);
 
 void launch_round_counts_spec(const u32* ntask, const u32* ntile, const u32* roffc, const u32* rk_slot, const u32* qcoff, const u32* st_state, u32 nq,
                               double max_miss, u32 minr, const AlnTask* tasks, const u32* toff, const u32* qoff, const u32* roff, const int* bittab,
