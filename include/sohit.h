@@ -182,6 +182,22 @@ int so_mcl(int device, int64_t n, const int64_t *indptr, const int32_t *indices,
 void so_mcl_free(so_mcl_result *result);
 const char *so_mcl_last_error(void);
 
+/* Host-side tokeniser of tab-separated text for the stages behind the search (csrc/tsv.hip; no device, no so_ctx).  Replaces: the
+ * per-line `split('\t')` + `float()` loops of bin/find_orth.py (blastparse, 58-125) and bin/find_cluster.py (1425-1467) as the
+ * numpy tokeniser of swiftortho_amd/find_orth.py restates them.
+ *   so_tsv_lines  start offset of every line of buf[0..n) (a line ends at its '\n'); returns the number of lines.
+ *   so_tsv_scan   for every line and each requested column cols[c]: [beg, beg + len) of the field (numeric columns: stripped of ASCII
+ *                 white space), the number of tabs of the line, and for numeric columns the value with status 0 = plain decimal
+ *                 number (strtod), 1 = empty or missing, 2 = anything else (the caller applies Python's float()).  Arrays are
+ *                 [ncols][nline].  Returns 0.
+ *   so_tsv_codes  two columns of byte strings -> codes into their sorted distinct list (byte order, a proper prefix first: numpy's
+ *                 order of fixed-width byte strings); returns the number of distinct strings, or minus it when cap is too small. */
+int64_t so_tsv_lines(const char *buf, int64_t n, int64_t *line_start, int64_t cap);
+int so_tsv_scan(const char *buf, int64_t n, const int64_t *line_start, int64_t nline, int32_t ncols, const int32_t *cols, const uint8_t *numeric,
+                int32_t *ntab, int64_t *beg, int32_t *len, double *val, uint8_t *status);
+int64_t so_tsv_codes(const char *buf, int64_t nrows, const int64_t *beg_a, const int32_t *len_a, const int64_t *beg_b, const int32_t *len_b,
+                     int64_t *code_a, int64_t *code_b, int64_t *name_beg, int32_t *name_len, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

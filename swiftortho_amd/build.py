@@ -19,7 +19,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 SOURCES = ["k_util.hip", "k_sort.hip", "k_prep.hip", "k_index.hip", "k_seed.hip", "k_group.hip", "k_bucket.hip", "k_align.hip", "k_align16.hip", "k_phase2.hip", "mcl.hip",
-           "host.hip"]
+           "tsv.hip", "host.hip"]
 # -ffp-contract=off: host-side SEG/threshold arithmetic must round exactly like the reference's
 # (no fused multiply-add), and device fp64 compares stay IEEE.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=off", "-Wall", "-Wno-unused-function",

@@ -1,0 +1,187 @@
+// tsv.hip -- host-side tokeniser of tab-separated text for the stages behind the search (find_orth reads the 16-column hit file,
+// find_cluster the 4-column relation file: SURVEY.md 8f-1 / 8f-2).  No device code: the numpy tokeniser of those stages spent its
+// time gathering fields into fixed-width arrays and converting them (3 of find_orth's 3.4 s on config 5's 1.6 M rows); here the
+// buffer is cut into line-aligned pieces that are scanned by as many threads as the host has.
+//
+// Semantics are the Python ones the numpy path implements (swiftortho_amd/find_orth.py columns_from_text): a line is the bytes up to
+// (not including) its '\n'; column k of a line runs from the (k - 1)-th tab + 1 (column 0: the line start) to the k-th tab (or the
+// line end); a line with fewer than k tabs has no column k.  A numeric column is stripped of ASCII white space and, when it is a
+// PLAIN decimal number (sign, digits, '.', exponent -- what every real file holds), converted with strtod, which is correctly rounded
+// like Python's float(); anything else (empty, "inf", "1_0", hex ...) is only FLAGGED and the caller lets Python decide.
+#include "../../include/sohit.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+template <class F>
+void tsv_parallel(int64_t n, F f) {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = std::max(1u, std::min(nt, 16u));
+    if (n < 4096 || nt == 1) {
+        f(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int64_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const int64_t a = (int64_t)t * per, b = std::min<int64_t>(n, a + per);
+        if (a >= b) break;
+        th.emplace_back([=] { f(a, b); });
+    }
+    for (auto& x : th) x.join();
+}
+
+inline bool is_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); }   // bytes.strip(): space, \t \n \v \f \r
+
+// plain decimal number?  [+-] digits [. digits] [(e|E) [+-] digits], at least one digit in the mantissa
+inline bool plain_number(const char* p, const char* e) {
+    if (p < e && (*p == '+' || *p == '-')) ++p;
+    const char* d0 = p;
+    while (p < e && *p >= '0' && *p <= '9') ++p;
+    size_t nd = (size_t)(p - d0);
+    if (p < e && *p == '.') {
+        ++p;
+        const char* f0 = p;
+        while (p < e && *p >= '0' && *p <= '9') ++p;
+        nd += (size_t)(p - f0);
+    }
+    if (nd == 0) return false;
+    if (p < e && (*p == 'e' || *p == 'E')) {
+        ++p;
+        if (p < e && (*p == '+' || *p == '-')) ++p;
+        const char* x0 = p;
+        while (p < e && *p >= '0' && *p <= '9') ++p;
+        if (p == x0) return false;
+    }
+    return p == e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t so_tsv_lines(const char* buf, int64_t n, int64_t* line_start, int64_t cap) {
+    // (single pass with memchr: this is a small fraction of the scan below)
+    int64_t k = 0, p = 0;
+    while (p < n) {
+        if (k < cap) line_start[k] = p;
+        ++k;
+        const void* q = memchr(buf + p, '\n', (size_t)(n - p));
+        if (!q) break;
+        p = (int64_t)((const char*)q - buf) + 1;
+    }
+    return k;
+}
+
+int so_tsv_scan(const char* buf, int64_t n, const int64_t* line_start, int64_t nline, int32_t ncols, const int32_t* cols, const uint8_t* numeric,
+                int32_t* ntab, int64_t* beg, int32_t* len, double* val, uint8_t* status) {
+    if (!buf || !line_start || nline < 0 || ncols < 0) return 1;
+    int maxcol = 0;
+    for (int c = 0; c < ncols; ++c) maxcol = std::max(maxcol, (int)cols[c]);
+    tsv_parallel(nline, [&](int64_t a, int64_t b) {
+        std::vector<int64_t> tab((size_t)maxcol + 2);
+        std::string tmp;
+        for (int64_t i = a; i < b; ++i) {
+            const int64_t ls = line_start[i];
+            const char* nlp = (const char*)memchr(buf + ls, '\n', (size_t)(n - ls));
+            const int64_t le = nlp ? (int64_t)(nlp - buf) : n;   // line end (exclusive)
+            // tabs of the line: all are counted, the first maxcol + 1 are kept
+            int nt = 0;
+            for (int64_t p = ls; p < le;) {
+                const char* t = (const char*)memchr(buf + p, '\t', (size_t)(le - p));
+                if (!t) break;
+                if (nt <= maxcol) tab[(size_t)nt] = (int64_t)(t - buf);
+                ++nt;
+                p = (int64_t)(t - buf) + 1;
+            }
+            ntab[i] = nt;
+            for (int c = 0; c < ncols; ++c) {
+                const int k = cols[c];
+                const size_t o = (size_t)c * (size_t)nline + (size_t)i;
+                int64_t st = 0, en = 0;
+                const bool have = nt >= k;
+                if (have) {
+                    st = k == 0 ? ls : tab[(size_t)k - 1] + 1;
+                    en = nt > k ? tab[(size_t)k] : le;
+                    if (en < st) en = st;
+                }
+                if (numeric && numeric[c]) {
+                    while (st < en && is_space((unsigned char)buf[st])) ++st;
+                    while (en > st && is_space((unsigned char)buf[en - 1])) --en;
+                    uint8_t s = 2;
+                    double v = 0;
+                    if (!have || en == st) s = 1;
+                    else if (plain_number(buf + st, buf + en)) {
+                        tmp.assign(buf + st, (size_t)(en - st));
+                        v = strtod(tmp.c_str(), nullptr);
+                        s = 0;
+                    }
+                    if (val) val[o] = v;
+                    if (status) status[o] = s;
+                }
+                beg[o] = st;
+                len[o] = (int32_t)(en - st);
+            }
+        }
+    });
+    return 0;
+}
+
+int64_t so_tsv_codes(const char* buf, int64_t nrows, const int64_t* beg_a, const int32_t* len_a, const int64_t* beg_b, const int32_t* len_b,
+                     int64_t* code_a, int64_t* code_b, int64_t* name_beg, int32_t* name_len, int64_t cap) {
+    struct View {
+        const char* p;
+        int32_t n;
+        bool operator==(const View& o) const { return n == o.n && memcmp(p, o.p, (size_t)n) == 0; }
+    };
+    struct Hash {
+        size_t operator()(const View& v) const {
+            uint64_t h = 1469598103934665603ull;
+            for (int32_t i = 0; i < v.n; ++i) h = (h ^ (unsigned char)v.p[i]) * 1099511628211ull;
+            return (size_t)h;
+        }
+    };
+    std::unordered_map<View, int64_t, Hash> seen;
+    seen.reserve((size_t)std::min<int64_t>(2 * nrows, 1 << 22));
+    std::vector<View> distinct;
+    auto add = [&](const int64_t* bg, const int32_t* ln, int64_t* code) {
+        for (int64_t i = 0; i < nrows; ++i) {
+            const View v{buf + bg[i], ln[i]};
+            auto it = seen.find(v);
+            if (it == seen.end()) {
+                it = seen.emplace(v, (int64_t)distinct.size()).first;
+                distinct.push_back(v);
+            }
+            code[i] = it->second;   // provisional: insertion order
+        }
+    };
+    add(beg_a, len_a, code_a);
+    add(beg_b, len_b, code_b);
+    const int64_t nd = (int64_t)distinct.size();
+    if (nd > cap) return -nd;
+    // numpy orders fixed-width byte strings as if padded with NULs: byte-wise, a proper prefix first
+    std::vector<int64_t> order((size_t)nd), rank((size_t)nd);
+    for (int64_t i = 0; i < nd; ++i) order[(size_t)i] = i;
+    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
+        const View &a = distinct[(size_t)x], &b = distinct[(size_t)y];
+        const int c = memcmp(a.p, b.p, (size_t)std::min(a.n, b.n));
+        return c != 0 ? c < 0 : a.n < b.n;
+    });
+    for (int64_t r = 0; r < nd; ++r) {
+        rank[(size_t)order[(size_t)r]] = r;
+        name_beg[r] = (int64_t)(distinct[(size_t)order[(size_t)r]].p - buf);
+        name_len[r] = distinct[(size_t)order[(size_t)r]].n;
+    }
+    tsv_parallel(nrows, [&](int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; ++i) code_a[i] = rank[(size_t)code_a[i]], code_b[i] = rank[(size_t)code_b[i]];
+    });
+    return nd;
+}
+
+}  // extern "C"

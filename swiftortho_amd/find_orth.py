@@ -30,6 +30,7 @@ what the reference does, with its line numbers:
     repeats inside a run are dropped, except that one repeat of the run's first pair survives (681-762).
 Scores print as Python's str(float), like the reference under Python 3.
 """
+import os
 import sys
 
 import numpy as np
@@ -118,12 +119,72 @@ def _to_float(fields):
     return vals, ok
 
 
+_FLOAT_COLS = (('idy', 2), ('aln', 3), ('mis', 4), ('gop', 5), ('qst', 6), ('qed', 7), ('sst', 8), ('sed', 9), ('evalue', 10), ('score', 11))
+
+
+def _columns_native(data):
+    """The same tokenisation by libsohit's threaded scanner (include/sohit.h so_tsv_*, csrc/tsv.hip): field bounds, plain decimal
+    numbers through strtod (correctly rounded, like float()), id codes through a hash map.  Returns None -- and the numpy path below
+    runs -- when the library is not built, the input is tiny, or ANY numeric field is not a plain decimal number (Python's float()
+    grammar is wider: 'inf', '1_0', ...; real files never hold such fields)."""
+    n = data.count(b'\n')
+    if n < int(os.environ.get('SOHIT_TSV_MIN', '4096')) or os.environ.get('SOHIT_TSV_NATIVE', '1') == '0':   # (tests force / forbid the native path)
+        return None
+    try:
+        from . import _lib
+        L = _lib.load()
+    except Exception:
+        return None
+    import ctypes as C
+    ptr = lambda a: C.c_void_p(a.ctypes.data)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    ls = np.empty(n + 1, dtype=np.int64)
+    if L.so_tsv_lines(ptr(buf), len(data), ptr(ls), n + 1) != n:
+        return None
+    ncol = 14
+    cols = np.arange(ncol, dtype=np.int32)
+    numeric = np.array([0, 0] + [1] * 12, dtype=np.uint8)
+    ntab = np.empty(n, dtype=np.int32)
+    beg = np.empty((ncol, n), dtype=np.int64)
+    ln = np.empty((ncol, n), dtype=np.int32)
+    val = np.empty((ncol, n), dtype=np.float64)
+    st = np.empty((ncol, n), dtype=np.uint8)
+    if L.so_tsv_scan(ptr(buf), len(data), ptr(ls), n, ncol, ptr(cols), ptr(numeric), ptr(ntab), ptr(beg), ptr(ln), ptr(val), ptr(st)) != 0:
+        return None
+    if np.any(ntab < 1):
+        raise ValueError('find_orth: a row has fewer than two columns')
+    full = ntab >= 11
+    wide = ntab >= 13
+    if np.any(st[2:12][:, full] == 2) or np.any(st[12:14][:, wide] == 2):
+        return None                                # a field only Python's float() can judge
+    ok = full.copy()
+    vals = {}
+    for name, k in _FLOAT_COLS:
+        vals[name] = val[k]
+        ok &= st[k] == 0
+    qlen = np.where(wide, val[12], 0.)
+    ok &= ~wide | ((st[12] == 0) & (st[13] == 0))
+    qc = np.empty(n, dtype=np.int64)
+    sc = np.empty(n, dtype=np.int64)
+    nb = np.empty(2 * n, dtype=np.int64)
+    nlen = np.empty(2 * n, dtype=np.int32)
+    nd = L.so_tsv_codes(ptr(buf), n, ptr(beg[0]), ptr(ln[0]), ptr(beg[1]), ptr(ln[1]), ptr(qc), ptr(sc), ptr(nb), ptr(nlen), 2 * n)
+    if nd <= 0:
+        return None
+    w = max(int(nlen[:nd].max()), 1)
+    names = np.array([data[b:b + l] for b, l in zip(nb[:nd].tolist(), nlen[:nd].tolist())], dtype='S%d' % w)
+    return _finish_columns(names, qc, sc, vals, ok, wide, qlen)
+
+
 def columns_from_text(data):
     """tab-separated rows (bytes of a 12-column blast -m8 or 16-column find_hit file) -> HitColumns.  Tokenised with numpy:
     one pass finds the line ends and tabs, each needed field is gathered into a fixed-width array and converted at once."""
     data = data.replace(b'\r\n', b'\n').replace(b'\r', b'\n')   # the reference reads in text mode (universal newlines)
     if data and not data.endswith(b'\n'):
         data = data[:-1] + b'\n'                                # ... and cuts the last character of every line, newline or not
+    fast = _columns_native(data)
+    if fast is not None:
+        return fast
     buf = np.frombuffer(data, dtype=np.uint8)
     nl = np.flatnonzero(buf == 10)
     n = len(nl)
@@ -172,6 +233,11 @@ def columns_from_text(data):
         qlen = np.where(wide, v, 0.)
         ok &= ~wide | (good & good2)
     names, q, s = _codes(qn, sn)
+    return _finish_columns(names, q, s, vals, ok, wide, qlen)
+
+
+def _finish_columns(names, q, s, vals, ok, wide, qlen):
+    """rows that parsed (`ok`) -> HitColumns; 12-column rows take their query length from the first such row of the query"""
     keep = np.flatnonzero(ok)
     q, s = q[keep], s[keep]
     col = {k: v[keep] for k, v in vals.items()}

@@ -31,6 +31,47 @@ def test_find_orth_matches_reference_output(name, variant):
     assert got == want
 
 
+@pytest.mark.parametrize("name,variant", orth_golden_cases())
+def test_find_orth_native_tokeniser(name, variant, monkeypatch):
+    """the same goldens through libsohit's threaded tokeniser (so_tsv_*: forced here, small inputs normally stay on the numpy path):
+    same text, and the same columns as the numpy tokeniser, array for array"""
+    import numpy as np
+    from swiftortho_amd import find_orth as fo
+    meta, sc = _load(name)
+    data = open(sc, "rb").read()
+    monkeypatch.setenv("SOHIT_TSV_NATIVE", "0")
+    ref = fo.columns_from_text(data)
+    monkeypatch.setenv("SOHIT_TSV_NATIVE", "1")
+    monkeypatch.setenv("SOHIT_TSV_MIN", "0")
+    assert fo._columns_native(data.replace(b"\r\n", b"\n").replace(b"\r", b"\n")) is not None   # the native path really ran
+    nat = fo.columns_from_text(data)
+    for k in ("names", "q", "s", "idy", "aln", "qst", "qed", "score", "qlen"):
+        assert np.array_equal(getattr(nat, k), getattr(ref, k)), k
+    a = fo.parse(["find_orth.py", "-i", sc] + meta["variants"][variant])
+    got = fo.find_orth(open(sc), float(a["-c"]), float(a["-y"]), a["-n"], a["-s"])
+    assert got == open(os.path.join(GOLD, "orth_%s.%s.orth" % (name, variant))).read().split("\n")[:-1]
+
+
+def test_native_tokeniser_leaves_odd_fields_to_python(monkeypatch):
+    """fields that are not plain decimal numbers ('inf', '1_0', hex, empty) make the native path step aside (Python's float() decides);
+    rows with too few columns, padded numbers, a last line without newline and CRLF line ends are handled like the numpy path does"""
+    import numpy as np
+    from swiftortho_amd import find_orth as fo
+    monkeypatch.setenv("SOHIT_TSV_MIN", "0")
+    row = lambda q, s, idy, bit, extra="": ("%s\t%s\t%s\t100\t0\t0\t1\t100\t1\t100\t1e-50\t%s\t100\t100%s\n" % (q, s, idy, bit, extra)).encode()
+    plain = row("a|1", "b|1", "90.5", "200") + row("b|1", "a|1", " 91.0 ", "+2.0e2") + b"a|1\tb|2\t50\n" + row("c|1", "a|1", "77", "150", "\t5\tc|1 x")
+    assert fo._columns_native(plain) is not None
+    for odd in ("inf", "1_0", "0x10", "nan"):
+        assert fo._columns_native(plain + row("a|2", "b|2", odd, "10")) is None
+    for data in (plain, plain.replace(b"\n", b"\r\n"), plain[:-1] + b"9", plain + row("a|2", "b|2", "", "10")):
+        monkeypatch.setenv("SOHIT_TSV_NATIVE", "0")
+        ref = fo.columns_from_text(data)
+        monkeypatch.setenv("SOHIT_TSV_NATIVE", "1")
+        nat = fo.columns_from_text(data)
+        for k in ("names", "q", "s", "idy", "aln", "qst", "qed", "score", "qlen"):
+            assert np.array_equal(getattr(nat, k), getattr(ref, k)), k
+
+
 def test_find_orth_cli(tmp_path):
     meta, sc = _load("taxa4_colon")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "find_orth.py"), "-i", sc] + meta["variants"]["bsr"], capture_output=True, text=True,
