@@ -109,8 +109,26 @@ def block_matrix(edge_lines):
     X = np.fromiter((number[g] for g in xs[use].tolist()), dtype=np.int64, count=int(use.sum()))
     Y = np.fromiter((number[g] for g in ys[use].tolist()), dtype=np.int64, count=int(use.sum()))
     Z = np.array([float(c[2]) for c, u in zip(cols, use.tolist()) if u], dtype=np.float64).astype(np.float32)
+    return names, *_matrix_from_numbers(X, Y, Z, dmx)
+
+
+def block_matrix_arrays(gx, gy, z, gene_names):
+    """block_matrix for rows that are already columns: gx / gy = gene numbers (any integer labelling) of the batch's rows in batch order
+    (every row has x <= y), z = their weights (float64); genes are renumbered by first appearance over the batch (x before y)."""
+    seq = np.empty(2 * len(gx), dtype=np.int64)
+    seq[0::2], seq[1::2] = gx, gy
+    vals, first = np.unique(seq, return_index=True)
+    order = np.argsort(first, kind='stable')
+    rank = np.empty(len(vals), dtype=np.int64)
+    rank[order] = np.arange(len(vals))
+    X, Y = rank[np.searchsorted(vals, gx)], rank[np.searchsorted(vals, gy)]
+    names = [gene_names[g] for g in vals[order].tolist()]
+    return names, *_matrix_from_numbers(X, Y, np.asarray(z, dtype=np.float64).astype(np.float32), len(names) + 1)
+
+
+def _matrix_from_numbers(X, Y, Z, dmx):
     if np.any(X == Y):
-        return names, *_block_matrix_sequential(X, Y, Z, dmx)   # self loops overwrite the diagonal in line order: rare, done one by one
+        return _block_matrix_sequential(X, Y, Z, dmx)   # self loops overwrite the diagonal in line order: rare, done one by one
     # off-diagonal: the last line of a pair wins
     key = X * dmx + Y
     last = len(key) - 1 - np.unique(key[::-1], return_index=True)[1]
@@ -129,7 +147,7 @@ def block_matrix(edge_lines):
     r, c, v = r[o], c[o], v[o]
     indptr = np.zeros(dmx + 1, dtype=np.int64)
     np.cumsum(np.bincount(r, minlength=dmx), out=indptr[1:])
-    return names, indptr, c.astype(np.int32), v.astype(np.float32)
+    return indptr, c.astype(np.int32), v.astype(np.float32)
 
 
 def _block_matrix_sequential(X, Y, Z, dmx):
@@ -194,6 +212,18 @@ def mcl_block(edge_lines, inflation, mcl=device_mcl):
         yield [names[e] for e in comp]
 
 
+def mcl_block_arrays(gx, gy, z, gene_names, inflation, mcl=device_mcl):
+    """mcl_block for a batch given as columns (see block_matrix_arrays)"""
+    if len(gx) == 0:
+        return
+    names, indptr, indices, data = block_matrix_arrays(gx, gy, z, gene_names)
+    g = _Graph()
+    for a, b in surviving_pairs(*mcl(indptr, indices, data, inflation)):
+        g.add_edge(a, b)
+    for comp in g.components():
+        yield [names[e] for e in comp]
+
+
 def _component_labels(n, u, v):
     """connected components of an undirected graph on nodes 0 .. n-1: label = smallest node of the component (min-label propagation
     with pointer jumping)"""
@@ -232,30 +262,116 @@ def _numbered_components(pairs_u, pairs_v):
     return nodes, np.searchsorted(roots, lab)
 
 
-def cnc(lines, inflation=1.5, chk=10 ** 7, mcl=device_mcl):
-    """cnc (1470-1673): relation rows -> groups (lists of gene ids), in the reference's output order.  `mcl`: the Markov loop on a CSR block
-    (the device implementation; the tests pass the scipy oracle to check this host bookkeeping on CPU).
-    The reference keeps Python dictionaries and networkx graphs; here genes are integers (numbered by first appearance, which is also the
-    insertion order of its best-neighbour dictionary) and each of its orders -- `popitem()` = last gene first, a graph's node order = first
-    appearance in the `add_edge` sequence, components numbered by their first node -- is reproduced as index arithmetic."""
+def _edge_columns_native(data):
+    """relation rows of a byte buffer through libsohit's tokeniser (so_tsv_*): -> (ids sorted bytewise, code of x, code of y, weight,
+    weight text) of every row, or None when the library is missing, the input is tiny or a row is not what the fast path handles (the
+    Python loop then decides, and raises what the reference would raise)"""
+    import os
+    n = data.count(b'\n')
+    if n < int(os.environ.get('SOHIT_TSV_MIN', '4096')) or os.environ.get('SOHIT_TSV_NATIVE', '1') == '0':
+        return None
+    try:
+        from . import _lib
+        L = _lib.load()
+    except Exception:
+        return None
+    import ctypes as C
+    ptr = lambda a: C.c_void_p(a.ctypes.data)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    ls = np.empty(n + 1, dtype=np.int64)
+    if L.so_tsv_lines(ptr(buf), len(data), ptr(ls), n + 1) != n:
+        return None
+    cols = np.array([0, 1, 2, 3, 2, 3], dtype=np.int32)
+    numeric = np.array([0, 0, 0, 0, 1, 1], dtype=np.uint8)
+    ntab = np.empty(n, dtype=np.int32)
+    beg = np.empty((6, n), dtype=np.int64)
+    ln = np.empty((6, n), dtype=np.int32)
+    val = np.empty((6, n), dtype=np.float64)
+    st = np.empty((6, n), dtype=np.uint8)
+    if L.so_tsv_scan(ptr(buf), len(data), ptr(ls), n, 6, ptr(cols), ptr(numeric), ptr(ntab), ptr(beg), ptr(ln), ptr(val), ptr(st)) != 0:
+        return None
+    if np.any(ntab < 2):
+        return None
+    four = ntab == 3                                # `len(j) == 4`: a relation type in front of (x, y, weight)
+    pick = lambda a, b: np.ascontiguousarray(np.where(four, a, b))
+    xb, xl = pick(beg[1], beg[0]), pick(ln[1], ln[0])
+    yb, yl = pick(beg[2], beg[1]), pick(ln[2], ln[1])
+    zb, zl = pick(beg[3], beg[2]), pick(ln[3], ln[2])
+    z, zs = pick(val[5], val[4]), pick(st[5], st[4])
+    cx = np.empty(n, dtype=np.int64)
+    cy = np.empty(n, dtype=np.int64)
+    nb = np.empty(2 * n, dtype=np.int64)
+    nlen = np.empty(2 * n, dtype=np.int32)
+    nd = L.so_tsv_codes(ptr(buf), n, ptr(xb), ptr(xl), ptr(yb), ptr(yl), ptr(cx), ptr(cy), ptr(nb), ptr(nlen), 2 * n)
+    if nd <= 0:
+        return None
+    use = cx <= cy                                  # `if x > y: continue` (ids compare like their bytes)
+    if np.any(zs[use] != 0):
+        return None                                 # a weight only Python's float() can judge
+    names = [data[b:b + l].decode('utf-8') for b, l in zip(nb[:nd].tolist(), nlen[:nd].tolist())]
+    u = np.flatnonzero(use)
+    zb, zl = zb[u], zl[u]
+    ztext = lambda i: data[int(zb[i]):int(zb[i]) + int(zl[i])]
+    return names, cx[u], cy[u], z[u], ztext
+
+
+def _edge_columns(lines):
+    """relation rows ('[type\\t]x\\ty\\tweight\\n') -> (ids sorted bytewise, code of x, code of y, weight, weight text of row i) for the
+    rows with x <= y, in file order"""
+    data = None
+    if hasattr(lines, 'read'):
+        data = lines.buffer.read() if hasattr(lines, 'buffer') else lines.read()
+    elif isinstance(lines, (bytes, bytearray)):
+        data = bytes(lines)
+    if data is not None:
+        if isinstance(data, str):
+            data = data.encode('utf-8')
+        data = data.replace(b'\r\n', b'\n').replace(b'\r', b'\n')   # the reference reads in text mode (universal newlines)
+        if data and not data.endswith(b'\n'):
+            data = data[:-1] + b'\n'                                # ... and cuts the last character of every line, newline or not
+        cols = _edge_columns_native(data)
+        if cols is not None:
+            return cols
+        lines = data.decode('utf-8').splitlines(True)
     rows = [r for r in _rows(lines)]
-    if not rows:
-        return []
     xs, ys, zs = [r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows]
-    inter = [None] * (2 * len(rows))
-    inter[0::2], inter[1::2] = xs, ys
-    number = {g: k for k, g in enumerate(dict.fromkeys(inter))}
-    X = np.fromiter((number[g] for g in xs), dtype=np.int64, count=len(rows))
-    Y = np.fromiter((number[g] for g in ys), dtype=np.int64, count=len(rows))
-    Z = np.array([float(z) for z in zs], dtype=np.float64)
-    n = len(number)
+    both = np.array([g.encode('utf-8') for g in xs + ys], dtype=np.bytes_) if rows else np.zeros(0, dtype='S1')
+    names, inv = np.unique(both, return_inverse=True)
+    inv = inv.astype(np.int64)
+    z = np.array([float(t) for t in zs], dtype=np.float64)
+    return [g.decode('utf-8') for g in names.tolist()], inv[:len(rows)], inv[len(rows):], z, (lambda i: zs[i].encode('utf-8'))
+
+
+def cnc(lines, inflation=1.5, chk=10 ** 7, mcl=device_mcl):
+    """cnc (1470-1673): relation rows -> groups (lists of gene ids), in the reference's output order.  `lines`: an open file, bytes or an
+    iterable of lines.  `mcl`: the Markov loop on a CSR block (the device implementation; the tests pass the scipy oracle to check this host
+    bookkeeping on CPU).
+    The reference keeps Python dictionaries and networkx graphs and moves the edges between its stages as sorted text files; here the
+    rows are columns from the start (ids coded by their byte order, which is also the order `sort` compares them in), genes are integers
+    numbered by first appearance (the insertion order of the reference's best-neighbour dictionary), and each of its orders --
+    `popitem()` = last gene first, a graph's node order = first appearance in the `add_edge` sequence, components numbered by their
+    first node, `LC_ALL=C sort -n` of the group-tagged edge lines -- is reproduced as index arithmetic."""
+    names, cx, cy, Z, ztext = _edge_columns(lines)
+    nrow = len(cx)
+    if nrow == 0:
+        return []
+    # genes numbered by first appearance (x of a row before its y)
+    seq = np.empty(2 * nrow, dtype=np.int64)
+    seq[0::2], seq[1::2] = cx, cy
+    vals, first = np.unique(seq, return_index=True)
+    order = np.argsort(first, kind='stable')
+    number_of_code = np.zeros(len(names), dtype=np.int64)
+    number_of_code[vals[order]] = np.arange(len(vals))
+    X, Y = number_of_code[cx], number_of_code[cy]
+    gene_names = [names[c] for c in vals[order].tolist()]
+    n = len(vals)
     # level 1: every gene linked to its best-scoring neighbour(s); the dictionary is emptied last gene first, a gene's ties in file order
     best = np.full(n, -np.inf)
     np.maximum.at(best, X, Z)
     np.maximum.at(best, Y, Z)
     a = np.concatenate([X, Y])
     b = np.concatenate([Y, X])
-    ridx = np.concatenate([np.arange(len(rows)) * 2, np.arange(len(rows)) * 2 + 1])   # (x, y) of a row before its (y, x)
+    ridx = np.concatenate([np.arange(nrow) * 2, np.arange(nrow) * 2 + 1])   # (x, y) of a row before its (y, x)
     tie = np.concatenate([Z, Z]) == best[a]
     a, b, ridx = a[tie], b[tie], ridx[tie]
     o = np.lexsort((ridx, -a))
@@ -277,24 +393,33 @@ def cnc(lines, inflation=1.5, chk=10 ** 7, mcl=device_mcl):
     # edges inside one level-2 group whose number is non-zero (-1, the pool of unmerged components, included)
     gx, gy = grp[X], grp[Y]
     keep = np.flatnonzero((gx != 0) & (gy != 0) & (gx == gy))
-    klines = [('%d\t%s\t%s\t%s\n' % (int(gx[r]), xs[r], ys[r], zs[r])) for r in keep.tolist()]
-    if klines:
-        kb = np.array([l.encode('latin-1') for l in klines], dtype=np.bytes_)
-        order = np.lexsort((kb, gx[keep]))               # LC_ALL=C sort -n: leading number, then the whole line bytewise
-    else:
-        order = np.zeros(0, dtype=np.int64)
-    out, batch, cls, flag = [], [], None, 0
-    kcls = gx[keep]
-    for i in order.tolist():
-        c = int(kcls[i])
-        if c != cls:
-            if flag > chk:
-                out.extend(mcl_block(batch, inflation, mcl))
-                batch, flag = [], 0
-            cls = c
-        batch.append(klines[i].split('\t', 1)[1])
-        flag += 1
-    out.extend(mcl_block(batch, inflation, mcl))
+    if len(keep) == 0:
+        return []
+    # LC_ALL=C sort -n of the lines 'group\tx\ty\tweight': the leading number, then the whole line bytewise = (x, y, weight text)
+    # bytewise (ids hold no byte below the tab, so a shorter id sorts before its extensions, like its code does)
+    kg, kx, ky = gx[keep], cx[keep], cy[keep]
+    order = np.lexsort((ky, kx, kg))
+    sg, sx, sy = kg[order], kx[order], ky[order]
+    dup = np.flatnonzero((sg[1:] == sg[:-1]) & (sx[1:] == sx[:-1]) & (sy[1:] == sy[:-1]))
+    if len(dup):                                          # the same pair twice in a group: its lines are ordered by the weight's text
+        run_start = dup[np.concatenate([[True], np.diff(dup) > 1])]
+        for s0 in run_start.tolist():
+            e0 = s0 + 1
+            while e0 < len(order) and sg[e0] == sg[s0] and sx[e0] == sx[s0] and sy[e0] == sy[s0]:
+                e0 += 1
+            seg = order[s0:e0].tolist()
+            seg.sort(key=lambda r: ztext(int(keep[r])) + b'\n')
+            order[s0:e0] = seg
+    rows_sorted = keep[order]
+    kcls = kg[order]
+    # batches: a new one starts where the group changes once the running batch holds more than chk rows
+    change = np.concatenate([[0], np.flatnonzero(kcls[1:] != kcls[:-1]) + 1, [len(kcls)]])
+    out, start = [], 0
+    for c in change[1:-1].tolist():
+        if c - start > chk:
+            out.extend(mcl_block_arrays(X[rows_sorted[start:c]], Y[rows_sorted[start:c]], Z[rows_sorted[start:c]], gene_names, inflation, mcl))
+            start = c
+    out.extend(mcl_block_arrays(X[rows_sorted[start:]], Y[rows_sorted[start:]], Z[rows_sorted[start:]], gene_names, inflation, mcl))
     return out
 
 

@@ -113,6 +113,39 @@ def test_groups_match_reference(name, variant):
     assert got == want                          # and the same text: group order and member order too
 
 
+@pytest.mark.parametrize("name,variant", cluster_cases())
+def test_groups_match_reference_native_tokeniser(name, variant, monkeypatch):
+    """the same goldens with the relation file read through libsohit's tokeniser (so_tsv_*; forced: small inputs normally take the
+    Python loop), and with the file handed over as bytes"""
+    from swiftortho_amd import find_cluster as fc
+    monkeypatch.setenv("SOHIT_TSV_MIN", "0")
+    meta = json.load(open(os.path.join(GOLD, "clu_%s.json" % name)))
+    data = open(os.path.join(GOLD, meta["input"]), "rb").read()
+    assert fc._edge_columns_native(data) is not None
+    a = fc.parse(["find_cluster.py", "-i", "x"] + meta["variants"][variant])
+    want = open(os.path.join(GOLD, "clu_%s.%s.mcl" % (name, variant))).read()
+    for src in (data, open(os.path.join(GOLD, meta["input"]))):
+        got = "".join("\t".join(g) + "\n" for g in fc.cnc(src, float(a["-I"]), mcl=scipy_mcl))
+        assert got == want
+
+
+def test_columnar_cnc_equals_line_by_line_semantics(monkeypatch):
+    """random family graphs with repeated pairs (same pair, different weight texts), three-column rows, x > y rows, CRLF line ends, a
+    last line without newline and small batches (chk): the native tokeniser and the Python loop give the same groups"""
+    from swiftortho_amd import find_cluster as fc
+    lines = _family_graph(11, 30, 9)
+    lines += [l.replace("\t0.01\n", "\t0.010\n") for l in lines[-8:]] + ["t3|zz\tt1|aa\t5.0\n", "t9|b\tt9|a\t1.0\n"]
+    for text in ("".join("OT\t" + l for l in lines), "".join(lines), "".join("OT\t" + l for l in lines).replace("\n", "\r\n"), "".join(lines)[:-1]):
+        for chk in (10 ** 7, 20):
+            monkeypatch.setenv("SOHIT_TSV_NATIVE", "0")
+            ref = fc.cnc(text.encode(), 1.5, chk, mcl=scipy_mcl)
+            monkeypatch.setenv("SOHIT_TSV_NATIVE", "1")
+            monkeypatch.setenv("SOHIT_TSV_MIN", "0")
+            assert fc._edge_columns_native(text.replace("\r\n", "\n").encode() if text.endswith("\n") else (text[:-1] + "\n").encode()) is not None
+            assert fc.cnc(text.encode(), 1.5, chk, mcl=scipy_mcl) == ref
+            assert len(ref) >= 1
+
+
 def test_hand_checkable_graphs():
     """Two cliques joined by one weak edge split at I = 2; a clique stays whole.  The reference's numbering accidents, by hand:
     best-neighbour components are numbered in popitem() order (last gene of the file first), so the LAST clique of the file is
