@@ -21,10 +21,10 @@ t1 = time.time() - t; print("find_hit.py (process start, FASTA parse, GPU search
 t = time.time()
 orth = subprocess.run([py, os.path.join(ROOT, "bin", "find_orth.py"), "-i", sc], capture_output=True, check=True).stdout
 open(op, "wb").write(orth)
-t2 = time.time() - t; print("find_orth.py (numpy tokeniser + columnar stage, %d relations): %.2f s" % (orth.count(b"\n"), t2))
+t2 = time.time() - t; print("find_orth.py (library tokeniser + columnar stage, %d relations): %.2f s" % (orth.count(b"\n"), t2))
 t = time.time()
 grp = subprocess.run([py, os.path.join(ROOT, "bin", "find_cluster.py"), "-i", op, "-a", "mcl", "-I", "1.5"], capture_output=True, check=True).stdout
-t3 = time.time() - t; print("find_cluster.py -a mcl (host graph bookkeeping + Markov loop on the GPU, %d groups): %.2f s" % (grp.count(b"\n"), t3))
+t3 = time.time() - t; print("find_cluster.py -a mcl (columnar graph bookkeeping + Markov loop on the GPU, %d groups): %.2f s" % (grp.count(b"\n"), t3))
 print("orth md5 ok:", hashlib.md5(orth).hexdigest() == meta["orth_md5"], " groups sha256 ok:", hashlib.sha256(grp).hexdigest() == meta["groups_text_sha256"])
 print("== in-process: hit records handed to find_orth, no .sc parsed ==")
 lines, tm = pipeline.orthology_from_search(p, ssd=d["-s"], nr=d["-r"], ht=int(d["-M"]), chk=int(d["-c"]), step=int(d["-j"]), v=int(d["-v"]), expect=float(d["-e"]), flt=d["-F"])
