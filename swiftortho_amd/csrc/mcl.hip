@@ -103,22 +103,33 @@ __global__ __launch_bounds__(256) void k_mcl_products(const u32* __restrict__ rp
 
 // One wave per row.  WRITE = false: ccnt[i] = stored entries of output row i; WRITE = true: the entries go to (cidx, cval) at crp[i].
 // Rows above MCL_LDS_P products use the global scratch at soff[i] (u32 units): [T keys][T sums][P order].
-template <bool WRITE>
+// Three instances per pass, by the row's number of products: up to MCL_SMALL_P on a 2.5 KB table (every CU then holds its 32 waves:
+// after the first rounds nearly every row of a Markov matrix is that short), up to MCL_LDS_P on the 20 KB one, and the rest on a 40 KB
+// table up to MCL_BIG_P products, else in global scratch -- a family of 34 genes squares to ~1150 products per row, just above the
+// 20 KB instance's limit, and clearing and probing its tables in HBM cost config 5's 89 k-row block 7 ms per pass (1.64 -> 1.33 s
+// for the 100 rounds of that block).  Table sizes only move slots around: the order of the output and every sum are the same.
+#define MCL_SMALL_P 128u
+#define MCL_SMALL_T 256u
+#define MCL_BIG_P 2048u
+#define MCL_BIG_T 4096u
+template <bool WRITE, int TIER /*0: <= MCL_SMALL_P products, 1: <= MCL_LDS_P, 2: the rest*/>
 __global__ __launch_bounds__(64) void k_mcl_spgemm(const u32* __restrict__ rp, const u32* __restrict__ idx, const float* __restrict__ val, u32 row_lo,
                                                    u32 row_hi, const u32* __restrict__ P, const u64* __restrict__ soff, u32* __restrict__ scratch,
                                                    u32* __restrict__ ccnt, const u32* __restrict__ crp, u32* __restrict__ cidx, float* __restrict__ cval) {
-    __shared__ u32 s_keys[MCL_LDS_T];
-    __shared__ float s_sums[MCL_LDS_T];
-    __shared__ u32 s_ord[MCL_LDS_P];
+    constexpr u32 TL = TIER == 0 ? MCL_SMALL_T : TIER == 1 ? MCL_LDS_T : MCL_BIG_T, PL = TIER == 0 ? MCL_SMALL_P : TIER == 1 ? MCL_LDS_P : MCL_BIG_P;
+    __shared__ u32 s_keys[TL];
+    __shared__ float s_sums[TL];
+    __shared__ u32 s_ord[PL];
     const u32 i = row_lo + blockIdx.x;
     if (i >= row_hi) return;
     const u32 lane = threadIdx.x;
     const u32 Pi = P[i];
+    if (TIER == 0 ? Pi > MCL_SMALL_P : TIER == 1 ? (Pi <= MCL_SMALL_P || Pi > MCL_LDS_P) : Pi <= MCL_LDS_P) return;   // another instance's row
     u32 *keys, *ord;
     float* sums;
     u32 T;
-    if (Pi <= MCL_LDS_P) {
-        keys = s_keys, sums = s_sums, ord = s_ord, T = MCL_LDS_T;
+    if (Pi <= PL) {
+        keys = s_keys, sums = s_sums, ord = s_ord, T = TL;
     } else {
         T = 1;
         while (T < 2u * Pi) T <<= 1;
@@ -325,8 +336,12 @@ struct Mcl {
         HIP_CHECK(hipMemcpyAsync(soff.p, hoff.data(), (size_t)n * sizeof(u64), hipMemcpyHostToDevice, st));
         for (auto& r : ranges)
             if (r.second > r.first)
-                hipLaunchKernelGGL((k_mcl_spgemm<false>), dim3(r.second - r.first), dim3(64), 0, st, x.rp.p, x.idx.p, x.val.p, r.first, r.second, P.p, soff.p,
-                                   scratch.p, ccnt.p, nullptr, nullptr, nullptr);
+            {
+                const dim3 g(r.second - r.first), bl(64);
+                hipLaunchKernelGGL((k_mcl_spgemm<false, 0>), g, bl, 0, st, x.rp.p, x.idx.p, x.val.p, r.first, r.second, P.p, soff.p, scratch.p, ccnt.p, nullptr, nullptr, nullptr);
+                hipLaunchKernelGGL((k_mcl_spgemm<false, 1>), g, bl, 0, st, x.rp.p, x.idx.p, x.val.p, r.first, r.second, P.p, soff.p, scratch.p, ccnt.p, nullptr, nullptr, nullptr);
+                hipLaunchKernelGGL((k_mcl_spgemm<false, 2>), g, bl, 0, st, x.rp.p, x.idx.p, x.val.p, r.first, r.second, P.p, soff.p, scratch.p, ccnt.p, nullptr, nullptr, nullptr);
+            }
         HIP_CHECK(hipMemsetAsync(ccnt.p + n, 0, sizeof(u32), st));
         scan_tmp.ensure(scan_u32_temp_elems((size_t)n + 1) + 8);
         const u32* tot = scan_u32(ccnt.p, c.rp.p, (size_t)n + 1, false, scan_tmp.p, st);
@@ -337,8 +352,12 @@ struct Mcl {
         c.idx.ensure((size_t)nnz + 2), c.val.ensure((size_t)nnz + 2);
         for (auto& r : ranges)
             if (r.second > r.first)
-                hipLaunchKernelGGL((k_mcl_spgemm<true>), dim3(r.second - r.first), dim3(64), 0, st, x.rp.p, x.idx.p, x.val.p, r.first, r.second, P.p, soff.p,
-                                   scratch.p, ccnt.p, c.rp.p, c.idx.p, c.val.p);
+            {
+                const dim3 g(r.second - r.first), bl(64);
+                hipLaunchKernelGGL((k_mcl_spgemm<true, 0>), g, bl, 0, st, x.rp.p, x.idx.p, x.val.p, r.first, r.second, P.p, soff.p, scratch.p, ccnt.p, c.rp.p, c.idx.p, c.val.p);
+                hipLaunchKernelGGL((k_mcl_spgemm<true, 1>), g, bl, 0, st, x.rp.p, x.idx.p, x.val.p, r.first, r.second, P.p, soff.p, scratch.p, ccnt.p, c.rp.p, c.idx.p, c.val.p);
+                hipLaunchKernelGGL((k_mcl_spgemm<true, 2>), g, bl, 0, st, x.rp.p, x.idx.p, x.val.p, r.first, r.second, P.p, soff.p, scratch.p, ccnt.p, c.rp.p, c.idx.p, c.val.p);
+            }
     }
 
     bool converged(const Csr& x, const Csr& old, float rtol, float atol) {
