@@ -197,6 +197,12 @@ int so_tsv_scan(const char *buf, int64_t n, const int64_t *line_start, int64_t n
                 int32_t *ntab, int64_t *beg, int32_t *len, double *val, uint8_t *status);
 int64_t so_tsv_codes(const char *buf, int64_t nrows, const int64_t *beg_a, const int32_t *len_a, const int64_t *beg_b, const int32_t *len_b,
                      int64_t *code_a, int64_t *code_b, int64_t *name_beg, int32_t *name_len, int64_t cap);
+/* The output side of the same stages: n lines  kind \t name[x] \t name[y] \t repr(v) \n  (find_orth.py prints its relations with
+ * Python's repr of the score, 1181-1226); names = concatenated ids, name_off[k] .. name_off[k + 1] the k-th.  Returns the bytes written,
+ * or minus the bytes needed when cap is too small.  so_py_repr: repr() of n doubles, one per line (tests). */
+int64_t so_format_pairs(const char *kind, int32_t kind_len, const char *names, const int64_t *name_off, const int64_t *x, const int64_t *y,
+                        const double *v, int64_t n, char *out, int64_t cap);
+int64_t so_py_repr(const double *v, int64_t n, char *out, int64_t cap);
 
 #ifdef __cplusplus
 }

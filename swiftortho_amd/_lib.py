@@ -39,7 +39,7 @@ EXPORTS = ["so_abi_version", "so_create", "so_destroy", "so_last_error", "so_loa
            "so_search", "so_free_hits", "so_write_sc", "so_format_hit", "so_get_counters", "so_reset_counters", "so_timing_report",
            "so_chunk_threshold", "so_chunk_entries", "so_chunk_download", "so_masked_query", "so_query_candidates", "so_set_profile",
            "so_bucket_count", "so_ref_len", "so_search_device", "so_device_hits_copy", "so_query_work", "so_mcl", "so_mcl_free",
-           "so_mcl_last_error", "so_tsv_lines", "so_tsv_scan", "so_tsv_codes"]
+           "so_mcl_last_error", "so_tsv_lines", "so_tsv_scan", "so_tsv_codes", "so_format_pairs", "so_py_repr"]
 
 
 class SoMclResult(C.Structure):
@@ -123,6 +123,10 @@ def load():
     L.so_tsv_scan.argtypes = [vp, i64, vp, i64, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     L.so_tsv_codes.restype = i64
     L.so_tsv_codes.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64]
+    L.so_format_pairs.restype = i64
+    L.so_format_pairs.argtypes = [cp, C.c_int32, vp, vp, vp, vp, vp, i64, vp, i64]
+    L.so_py_repr.restype = i64
+    L.so_py_repr.argtypes = [vp, i64, vp, i64]
     for f in ("so_chunk_threshold", "so_chunk_entries"):
         getattr(L, f).restype = i64
         getattr(L, f).argtypes = [vp, i64]

@@ -10,6 +10,8 @@
 // like Python's float(); anything else (empty, "inf", "1_0", hex ...) is only FLAGGED and the caller lets Python decide.
 #include "../../include/sohit.h"
 #include <algorithm>
+#include <charconv>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -182,6 +184,92 @@ int64_t so_tsv_codes(const char* buf, int64_t nrows, const int64_t* beg_a, const
         for (int64_t i = a; i < b; ++i) code_a[i] = rank[(size_t)code_a[i]], code_b[i] = rank[(size_t)code_b[i]];
     });
     return nd;
+}
+
+// repr(float) as CPython prints it (float_repr_style 'short': the shortest digit string that round-trips, fixed notation while the
+// decimal point lies within (-4, 16], else d.ddde+XX with at least two exponent digits; integers carry '.0').  Returns the length.
+static int py_repr(double v, char* out) {
+    if (std::isnan(v)) return (int)(stpcpy(out, "nan") - out);
+    if (std::isinf(v)) return (int)(stpcpy(out, v < 0 ? "-inf" : "inf") - out);
+    char tmp[40];
+    const auto r = std::to_chars(tmp, tmp + sizeof tmp - 1, v, std::chars_format::scientific);   // shortest round-trip digits
+    *r.ptr = 0;
+    char* o = out;
+    const char* p = tmp;
+    if (*p == '-') *o++ = *p++;
+    char dig[24];
+    int nd = 0;
+    for (; p < r.ptr && *p != 'e'; ++p)
+        if (*p != '.') dig[nd++] = *p;
+    const int e10 = (int)strtol(p + 1, nullptr, 10);
+    const int decpt = e10 + 1;   // value = 0.d1d2... x 10^decpt
+    if (decpt <= -4 || decpt > 16) {
+        *o++ = dig[0];
+        if (nd > 1) {
+            *o++ = '.';
+            memcpy(o, dig + 1, (size_t)nd - 1), o += nd - 1;
+        }
+        *o++ = 'e';
+        int x = decpt - 1;
+        *o++ = x < 0 ? '-' : '+';
+        if (x < 0) x = -x;
+        if (x < 10) *o++ = '0';
+        o = std::to_chars(o, o + 8, x).ptr;
+    } else if (decpt <= 0) {
+        *o++ = '0', *o++ = '.';
+        for (int k = 0; k < -decpt; ++k) *o++ = '0';
+        memcpy(o, dig, (size_t)nd), o += nd;
+    } else if (decpt >= nd) {
+        memcpy(o, dig, (size_t)nd), o += nd;
+        for (int k = 0; k < decpt - nd; ++k) *o++ = '0';
+        *o++ = '.', *o++ = '0';
+    } else {
+        memcpy(o, dig, (size_t)decpt), o += decpt;
+        *o++ = '.';
+        memcpy(o, dig + decpt, (size_t)(nd - decpt)), o += nd - decpt;
+    }
+    return (int)(o - out);
+}
+
+int64_t so_format_pairs(const char* kind, int32_t kind_len, const char* names, const int64_t* name_off, const int64_t* x, const int64_t* y,
+                        const double* v, int64_t n, char* out, int64_t cap) {
+    // line i = kind '\t' name[x[i]] '\t' name[y[i]] '\t' repr(v[i]) '\n'; two passes: line ends, then the text (threads over rows)
+    std::vector<int64_t> end((size_t)n + 1, 0);
+    tsv_parallel(n, [&](int64_t a, int64_t b) {
+        char tmp[48];
+        for (int64_t i = a; i < b; ++i)
+            end[(size_t)i + 1] = kind_len + 1 + (name_off[x[i] + 1] - name_off[x[i]]) + 1 + (name_off[y[i] + 1] - name_off[y[i]]) + 1 + py_repr(v[i], tmp) + 1;
+    });
+    for (int64_t i = 0; i < n; ++i) end[(size_t)i + 1] += end[(size_t)i];
+    const int64_t total = end[(size_t)n];
+    if (total > cap || !out) return -total;
+    tsv_parallel(n, [&](int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; ++i) {
+            char* o = out + end[(size_t)i];
+            memcpy(o, kind, (size_t)kind_len), o += kind_len;
+            *o++ = '\t';
+            int64_t l = name_off[x[i] + 1] - name_off[x[i]];
+            memcpy(o, names + name_off[x[i]], (size_t)l), o += l;
+            *o++ = '\t';
+            l = name_off[y[i] + 1] - name_off[y[i]];
+            memcpy(o, names + name_off[y[i]], (size_t)l), o += l;
+            *o++ = '\t';
+            o += py_repr(v[i], o);
+            *o++ = '\n';
+        }
+    });
+    return total;
+}
+
+/* repr() of n doubles, newline-separated (tests) */
+int64_t so_py_repr(const double* v, int64_t n, char* out, int64_t cap) {
+    int64_t w = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (w + 40 > cap) return -1;
+        w += py_repr(v[i], out + w);
+        out[w++] = '\n';
+    }
+    return w;
 }
 
 }  // extern "C"

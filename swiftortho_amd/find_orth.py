@@ -387,12 +387,12 @@ def relations(cols, coverage=.5, identity=0., norm='no', sep='|'):
     # ---- text ----------------------------------------------------------------------------------------------------
     lines = []
     nm = names.tolist()
+    fmt = _PairFormatter(nm)
     avg = ip_avg[tax[ip_a[fwd]]]
     with np.errstate(divide='ignore', invalid='ignore'):
         val = ip_s[fwd] / avg
-    for x, y, v, d in zip(ip_a[fwd].tolist(), ip_b[fwd].tolist(), val.tolist(), avg.tolist()):
-        if d != 0:   # the reference's division raises there and the line is skipped
-            lines.append(b'IP\t' + nm[x] + b'\t' + nm[y] + b'\t' + repr(v).encode())
+    ok = avg != 0    # the reference's division raises there and the line is skipped
+    lines.extend(fmt.lines(b'IP', ip_a[fwd][ok], ip_b[fwd][ok], val[ok]))
     for kind, (pa, pb, ps) in ((b'OT', (ot_a, ot_b, ot_s)), (b'CO', (co_a, co_b, co_s))):
         if len(pa) == 0:
             continue
@@ -414,9 +414,43 @@ def relations(cols, coverage=.5, identity=0., norm='no', sep='|'):
         gsum = np.bincount(ginv, weights=ps, minlength=len(gu))
         gcnt = np.bincount(ginv, minlength=len(gu)).astype(np.float64)
         val = ps / (gsum / gcnt)[ginv]
-        for x, y, v in zip(pa.tolist(), pb.tolist(), val.tolist()):
-            lines.append(kind + b'\t' + nm[x] + b'\t' + nm[y] + b'\t' + repr(v).encode())
+        lines.extend(fmt.lines(kind, pa, pb, val))
     return lines
+
+
+class _PairFormatter:
+    """lines  kind \\t id \\t id \\t repr(score)  for arrays of id codes and scores: through libsohit (so_format_pairs: Python's repr of a
+    float reproduced digit for digit, rows written by threads) when it is there and the section is large, else one by one"""
+
+    def __init__(self, names):
+        self.nm = names
+        self.blob = None
+
+    def lines(self, kind, x, y, v):
+        n = len(x)
+        if n == 0:
+            return []
+        if n >= int(os.environ.get('SOHIT_TSV_MIN', '4096')) and os.environ.get('SOHIT_TSV_NATIVE', '1') != '0':
+            try:
+                from . import _lib
+                L = _lib.load()
+                import ctypes as C
+                if self.blob is None:
+                    self.off = np.zeros(len(self.nm) + 1, dtype=np.int64)
+                    np.cumsum([len(t) for t in self.nm], out=self.off[1:])
+                    self.blob = b''.join(self.nm)
+                xa, ya = np.ascontiguousarray(x, dtype=np.int64), np.ascontiguousarray(y, dtype=np.int64)
+                va = np.ascontiguousarray(v, dtype=np.float64)
+                ptr = lambda a: C.c_void_p(a.ctypes.data)
+                cap = int(n * (len(kind) + 32) + (self.off[xa + 1] - self.off[xa]).sum() + (self.off[ya + 1] - self.off[ya]).sum())
+                out = np.empty(cap, dtype=np.uint8)
+                w = L.so_format_pairs(kind, len(kind), self.blob, ptr(self.off), ptr(xa), ptr(ya), ptr(va), n, ptr(out), cap)
+                if w > 0:
+                    return out[:w - 1].tobytes().split(b'\n')
+            except Exception:
+                pass
+        nm = self.nm
+        return [kind + b'\t' + nm[a] + b'\t' + nm[b] + b'\t' + repr(c).encode() for a, b, c in zip(x.tolist(), y.tolist(), v.tolist())]
 
 
 def relations_from_records(hits, query_ids, subject_ids, coverage=.5, identity=0., norm='no', sep='|'):

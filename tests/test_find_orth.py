@@ -72,6 +72,25 @@ def test_native_tokeniser_leaves_odd_fields_to_python(monkeypatch):
             assert np.array_equal(getattr(nat, k), getattr(ref, k)), k
 
 
+def test_native_repr_equals_python_repr():
+    """so_py_repr / so_format_pairs print a score the way Python's repr() does (shortest round-trip digits, fixed notation while the
+    decimal point lies within (-4, 16], two-digit exponents, '.0' on integers, inf / nan): random magnitudes and raw bit patterns"""
+    import ctypes as C
+    import numpy as np
+    from swiftortho_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(11)
+    parts = [np.array([0.0, -0.0, 1.0, 0.1, 1e16, 1e15, 9999999999999998.0, 1e17, 1e-4, 1e-5, 5e-324, 1.7976931348623157e308, np.inf, -np.inf, np.nan,
+                       1 / 3, 1e22, 1e23, 123456789012345678.0])]
+    parts += [rng.random(20000) * sc for sc in (1, 1e-3, 1e-4, 1e-5, 1e3, 1e15, 1e16, 1e17, 1e-10, 1e300, 1e-300)]
+    parts += [rng.integers(0, 2 ** 64, size=100000, dtype=np.uint64).view(np.float64), rng.integers(-10 ** 17, 10 ** 17, 20000).astype(np.float64)]
+    v = np.ascontiguousarray(np.concatenate(parts), dtype=np.float64)
+    out = np.empty(len(v) * 40 + 64, dtype=np.uint8)
+    w = L.so_py_repr(C.c_void_p(v.ctypes.data), len(v), C.c_void_p(out.ctypes.data), len(out))
+    assert w > 0
+    assert out[:w].tobytes().decode().split("\n")[:-1] == [repr(x) for x in v.tolist()]
+
+
 def test_find_orth_cli(tmp_path):
     meta, sc = _load("taxa4_colon")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "find_orth.py"), "-i", sc] + meta["variants"]["bsr"], capture_output=True, text=True,
