@@ -87,6 +87,10 @@ typedef struct so_counters {
     double index_ms, seed_ms, group_ms, phase2_ms, total_ms; /* host-side stage wall times */
     int64_t count_launches;            /* launches of the lookup kernel's COUNT pass (bucketed binning) */
     double count_ms;                   /* their summed duration; lookup_* then describe its SCATTER pass */
+    /* which path the work took (round 4: both are per-task / per-pass decisions, not per-batch ones) */
+    int64_t hits_bucketed;             /* seed hits binned by the bucketed passes (k_bkt_pass); the rest took the sorted path */
+    int64_t align_wide;                /* score-only alignments the packed 16-bit aligner could not take (32-bit kernel)       */
+    int64_t cells_wide;                /* their band cells (`cells` counts every task of the early-stop rounds once)            */
 } so_counters;
 
 /* Lifetime.  Replaces: spawning `fsearch-c` with its flags (find_hit.py:119-123). */

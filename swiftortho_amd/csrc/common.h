@@ -100,7 +100,8 @@ struct SeedCfg {
     u32 nc;                         // bucket count
 };
 
-// Sort-key layout of one seed hit: [q | subj | diag | qpos | as | tag] from MSB to LSB.
+// Sort-key layout of one seed hit: [q | subj | diag | qpos | as | tag] from MSB to LSB.  With the compact (banded) index addends
+// `subj` counts diagonal bands (k_encode_band32) and diag_off is the offset of a one-band subject's diagonals.
 struct KeyLayout {
     int bq, bs, bd, bp, ba;         // bit widths
     int sh_tag, sh_as, sh_qpos, sh_diag, sh_subj, sh_q;
@@ -117,15 +118,17 @@ struct KeyLayout {
     }
 };
 
-// Bucketed diagonal binning (k_bucket.hip): a bucket = (query of the pass, range of 2^wb chunk sequences); a hit inside a
-// bucket is one 32-bit word  subject_low << (bd + bp) | diagonal << bp | qpos.
-#define BKT_RMAX 512          // subject ranges per chunk (per-wave LDS histogram of the count / scatter passes)
+// Bucketed diagonal binning (k_bucket.hip): a bucket = (query of the pass, range of 2^wb diagonal bands); a hit inside a
+// bucket is one 32-bit word  band_low << (bd + bp) | diagonal << bp | qpos.  (Bands: KeyLayout's "subject" field counts diagonal
+// bands of 2^bd ids -- one per chunk sequence, several for a sequence too long for one; k_index.hip, k_encode_band32.)  The pass
+// records of the best-diagonal reduction are binned by (query, range of 2^wb chunk SEQUENCES) with a layout of their own.
+#define BKT_RMAX 512          // ranges per chunk (per-wave LDS histogram of the count / scatter passes)
 struct BktLayout {
-    int wb, bd, bp;           // bits: subject inside the range, diagonal, query position
+    int wb, bd, bp;           // bits: band (or sequence) inside the range, diagonal, query position
     int sh_q, sh_qpos;        // where q / qpos sit in the seeds' 64-bit key bases (KeyLayout)
     u32 nqp, qa;              // queries in the pass, first one (batch-local index)
-    u32 R;                    // subject ranges: bucket id = range * nqp + (q - qa)
-    u32 maxslen;              // KeyLayout::diag_off
+    u32 R;                    // ranges: bucket id = range * nqp + (q - qa)
+    u32 maxslen;              // (unused by the kernels)
 };
 
 #ifdef __HIPCC__

@@ -121,6 +121,7 @@ struct SeqSet {
     struct { u8* p = nullptr; } d_scls;   // score classes; 16 readable bytes in front (k_ungap's left-pass windows start up to 8 bytes early)
     struct { u8* p = nullptr; } d_scls4;  // score class * 4 (k_ungap's subject side: column offset in its LDS table), same padding
     DevBuf<u32> d_off, d_words, d_pseq;
+    DevBuf<u32> d_bound;         // per sequence: upper bound of any alignment score it can take part in (k_seq_bound)
     u32 P = 0, Ppad = 0;
     HashLut lut;
 
@@ -208,8 +209,23 @@ struct ChunkIndex {
     DevBuf<u64> dir;      // bitmap + rank directory (k_dir_build) used instead of the map when NC <= 2^28
     bool use_dir = false;
     DevBuf<u64> dkeys;    // E: per-entry key addends for the layout (d_sh_subj, d_sh_diag) -- k_encode_delta
-    DevBuf<u32> dk32;     // E: compact addends for field widths (d_ba, d_bd) -- k_encode_delta32
-    int d_sh_subj = -1, d_sh_diag = -1, d_ba = -1, d_bd = -1;
+    int d_sh_subj = -1, d_sh_diag = -1;
+    // compact (4-byte) addends, one set per key layout in use -- k_encode_band32.  A layout = (tag bits, query-position bits, diagonal
+    // bits k): the chunk's (subject, diagonal) pairs are numbered in bands of 2^k ids, one band for a sequence of length <= C =
+    // 2^k - 2^bp, several for a longer one.  A search with queries of several length classes alternates between a few layouts per
+    // chunk, so the sets are kept (at most four, least recently used first out).
+    struct BandEnc {
+        int ba = -1, bp = -1, k = -1;
+        bool multi_ok = false;   // built with several bands per long subject allowed (one alphabet x one pattern only)
+        bool multi = false;      // ... and some subject does own several: btab resolves bands
+        u32 nband = 0;           // bands of the chunk (== sequences unless multi)
+        u32 C = 0;               // diagonal offset of the one-band subjects
+        DevBuf<u32> dk32, gbase; // E addends; per chunk sequence: (first band << k) + (C or, for a multi-band subject, its length)
+        DevBuf<u64> btab;        // nband x (chunk sequence | gbase << 32)
+        u64 used = 0;
+    };
+    std::vector<std::unique_ptr<BandEnc>> encs;
+    u64 enc_clock = 0;
 };
 
 }  // namespace
@@ -369,6 +385,8 @@ void layout_set(so_ctx* c, SeqSet& s, const bool present[256], size_t nres, u32 
     s.d_scls4.p = s.d_scls4_store.p + SCLS_PAD_FRONT;
     HIP_CHECK(hipMemcpyAsync(c->d_hmap.p, hmap, 256, hipMemcpyHostToDevice, c->st));
     launch_scls(s.d_res.p, nres, c->d_smap.p, s.d_scls.p, s.d_scls4.p, c->st);
+    s.d_bound.ensure((size_t)nseq + 4);
+    launch_seq_bound(s.d_scls.p, s.d_off.p, nseq, c->b62c, s.d_bound.p, c->st);
     if ((u64)nres + nseq + 64 > 0xFFFFFFF0ull) throw SoError("sequence set too large for 32-bit packed positions");
     s.P = (u32)(nres + nseq);
     s.Ppad = (s.P + 31u) & ~31u;
@@ -576,7 +594,8 @@ void build_index(so_ctx* c) {
         if (!c->spare_chunks.empty()) {
             ch = std::move(c->spare_chunks.back());
             c->spare_chunks.pop_back();
-            ch->d_sh_subj = ch->d_sh_diag = ch->d_ba = ch->d_bd = -1;  // key addends belong to the old entries
+            ch->d_sh_subj = ch->d_sh_diag = -1;  // key addends belong to the old entries
+            for (auto& e : ch->encs) e->k = -1;
         } else {
             ch = std::make_unique<ChunkIndex>();
         }
@@ -678,6 +697,14 @@ struct Batch {
     std::vector<u8> h_res;   // masked residues
     std::vector<u32> h_off;  // [nq+1]
     u32 maxqlen = 0;
+    // Queries are held in LENGTH-CLASS order inside a batch (stable inside a class): batch slot i is query q_lo + qid[i] of the file.
+    // Per-query results do not depend on their neighbours (find_hit.py:107-146 relies on the same fact), seed passes never mix
+    // classes -- so key widths follow the pass's longest query, not the batch's -- and the rows are put back in file order when they
+    // reach the host.  One class only (the usual protein set below 1024 residues): qid is the identity and `permuted` is false.
+    std::vector<u32> qid;
+    std::vector<u8> qcls;    // length class per slot (query_class)
+    bool permuted = false;
+    DevBuf<u32> d_qid, d_ocnt, d_ostart;
     SeqSet dev;              // device arrays only (d_res = masked raw, d_scls, d_off, d_words, d_pseq)
     DevBuf<u32> qbucket, korder, sbeg, scnt, pcnt, eff, nz, hoff, cidx;
     DevBuf<int> ksc;
@@ -712,15 +739,38 @@ struct Batch {
     DevBuf<u32> trace;
 };
 
+// length classes of the queries: < 1024 residues, < 2048, < 4096, longer (the aligner's tiled path)
+inline u8 query_class(u32 len) { return len < 1024 ? 0 : len < 2048 ? 1 : len < 4096 ? 2 : 3; }
+
 void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
     b.q_lo = q_lo, b.q_hi = q_hi, b.nq = (u32)(q_hi - q_lo);
     const SeqSet& Q = c->qry;
     b.h_off.assign((size_t)b.nq + 1, 0);
     b.maxqlen = 0;
+    b.qid.resize(b.nq), b.qcls.resize(b.nq);
+    {
+        const bool classes_on = !(getenv("SOHIT_QCLASS") && atoi(getenv("SOHIT_QCLASS")) == 0);   // SOHIT_QCLASS=0: file order
+        u32 cnt[4] = {0, 0, 0, 0};
+        for (u32 i = 0; i < b.nq; ++i) cnt[classes_on ? query_class(Q.len(q_lo + i)) : 0]++;
+        u32 at[4] = {0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2]};
+        b.permuted = false;
+        for (u32 i = 0; i < b.nq; ++i) {
+            const u8 k = classes_on ? query_class(Q.len(q_lo + i)) : 0;
+            b.permuted |= at[k] != i;
+            b.qcls[at[k]] = k;
+            b.qid[at[k]++] = i;
+        }
+    }
     for (u32 i = 0; i < b.nq; ++i) {
-        u32 ln = Q.len(q_lo + i);
+        u32 ln = Q.len(q_lo + b.qid[i]);
         b.h_off[i + 1] = b.h_off[i] + ln;
         b.maxqlen = std::max(b.maxqlen, ln);
+    }
+    const u32* d_qid = nullptr;
+    if (b.permuted) {
+        b.d_qid.ensure((size_t)b.nq + 4);
+        HIP_CHECK(hipMemcpyAsync(b.d_qid.p, b.qid.data(), (size_t)b.nq * sizeof(u32), hipMemcpyHostToDevice, c->st));
+        d_qid = b.d_qid.p;
     }
     const size_t nres_b = b.h_off[b.nq];
     c->masked_lo = q_lo;
@@ -731,8 +781,10 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
         HIP_CHECK(hipMemcpyAsync(b.dev.d_off.p, b.h_off.data(), ((size_t)b.nq + 1) * sizeof(u32), hipMemcpyHostToDevice, c->st));
         if (c->filter) {
             c->d_segmask.ensure(nres_b + 64);
-            launch_seg(c->qry.d_res.p, c->qry.d_off.p, (u32)q_lo, b.nq, b.dev.d_off.p, c->d_symmap.p, c->d_upmap.p, c->d_segtab.p,
+            launch_seg(c->qry.d_res.p, c->qry.d_off.p, (u32)q_lo, d_qid, b.nq, b.dev.d_off.p, c->d_symmap.p, c->d_upmap.p, c->d_segtab.p,
                        c->d_segmask.p, b.dev.d_res.p, b.maxqlen, c->st);
+        } else if (b.permuted) {
+            launch_gather_seqs(c->qry.d_res.p, c->qry.d_off.p, (u32)q_lo, d_qid, b.nq, b.dev.d_off.p, b.dev.d_res.p, c->st);
         } else {
             launch_copy_range(c->qry.d_res.p + Q.off[q_lo], b.dev.d_res.p, nres_b, c->st);
         }
@@ -742,7 +794,7 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
         // more than 64 distinct residue bytes: SEG on the host (same arithmetic, same tables)
         b.h_res.resize(nres_b + 16);
         const u8* src = Q.res.data();
-        parallel_for((i64)b.nq, [&](i64 i) { seg_mask(src + Q.off[q_lo + i], (int)Q.len(q_lo + i), b.h_res.data() + b.h_off[i]); });
+        parallel_for((i64)b.nq, [&](i64 i) { seg_mask(src + Q.off[q_lo + b.qid[i]], (int)Q.len(q_lo + b.qid[i]), b.h_res.data() + b.h_off[i]); });
         upload_set(c, b.dev, b.h_res.data(), b.h_off, b.nq);
     }
     const int AS = c->cfg.A * c->cfg.S;
@@ -832,6 +884,84 @@ struct ProfTimer {
     }
 };
 
+// Compact index addends of chunk `ch` for a pass whose queries are shorter than 2^bp (see ChunkIndex::BandEnc, k_encode_band32):
+// picks the diagonal width k, numbers the bands, encodes the entries.  multi_ok = a long subject may own several bands (the
+// kernels resolve bands through a table: one alphabet x one pattern only); otherwise k is wide enough for the longest subject.
+// Returns null when band + diagonal + tag bits exceed 31 (the pass then uses the 8-byte addends).
+ChunkIndex::BandEnc* band_encoding(so_ctx* c, ChunkIndex& ch, int ba, int bp, bool multi_ok) {
+    ++ch.enc_clock;
+    for (auto& e : ch.encs)
+        if (e->k >= 0 && e->ba == ba && e->bp == bp && e->multi_ok == multi_ok) {
+            e->used = ch.enc_clock;
+            return e->k == 0 ? nullptr : e.get();   // k == 0: "does not fit" remembered
+        }
+    const u32 nseq = (u32)(ch.seq_hi - ch.seq_lo);
+    const u64 qcap = 1ull << bp;
+    int kmax = bp + 1;
+    while ((1ull << kmax) < (u64)ch.maxslen + qcap) ++kmax;   // every subject in one band
+    auto bands_at = [&](int k) -> u64 {
+        const u64 C = (1ull << k) - qcap;
+        u64 n = 0;
+        for (i64 j = ch.seq_lo; j < ch.seq_hi; ++j) {
+            const u64 sl = c->ref.len(j);
+            n += sl <= C ? 1ull : (sl + qcap + (1ull << k) - 1) >> k;
+        }
+        return n;
+    };
+    int k = kmax;
+    u64 nband = nseq;
+    if (multi_ok) {
+        int best_bits = ceil_log2(std::max<u64>(nseq, 2)) + kmax;
+        for (int kk = kmax - 1; kk > bp; --kk) {   // (ties keep the wider k: fewer subjects with several bands)
+            const u64 nb = bands_at(kk);
+            const int bits = ceil_log2(std::max<u64>(nb, 2)) + kk;
+            if (bits < best_bits) best_bits = bits, k = kk, nband = nb;
+        }
+    }
+    // slot: a stale one, else a new one, else the least recently used
+    ChunkIndex::BandEnc* e = nullptr;
+    for (auto& x : ch.encs)
+        if (x->k < 0) e = x.get();
+    if (!e && ch.encs.size() < 4) {
+        ch.encs.push_back(std::make_unique<ChunkIndex::BandEnc>());
+        e = ch.encs.back().get();
+    }
+    if (!e) {
+        e = ch.encs[0].get();
+        for (auto& x : ch.encs)
+            if (x->used < e->used) e = x.get();
+    }
+    e->ba = ba, e->bp = bp, e->multi_ok = multi_ok, e->used = ch.enc_clock;
+    if (ceil_log2(std::max<u64>(nband, 2)) + k + ba > 31) {
+        e->k = 0;
+        return nullptr;
+    }
+    e->k = k, e->nband = (u32)nband, e->C = (u32)((1ull << k) - qcap), e->multi = nband != nseq;
+    std::vector<u32> gbase((size_t)nseq + 1);
+    std::vector<u64> btab;
+    if (e->multi) btab.resize((size_t)nband);
+    u32 band = 0;
+    for (u32 j = 0; j < nseq; ++j) {
+        const u32 sl = c->ref.len(ch.seq_lo + j);
+        const bool one = sl <= e->C;
+        const u32 nb = one ? 1u : (u32)(((u64)sl + qcap + (1ull << k) - 1) >> k);
+        gbase[j] = (band << k) + (one ? e->C : sl);
+        if (e->multi)
+            for (u32 t = 0; t < nb; ++t) btab[(size_t)band + t] = (u64)j | ((u64)gbase[j] << 32);
+        band += nb;
+    }
+    e->gbase.ensure((size_t)nseq + 4);
+    e->dk32.ensure((size_t)ch.E + 4);
+    if (nseq) HIP_CHECK(hipMemcpyAsync(e->gbase.p, gbase.data(), (size_t)nseq * sizeof(u32), hipMemcpyHostToDevice, c->st));
+    if (e->multi) {
+        e->btab.ensure((size_t)nband + 4);
+        HIP_CHECK(hipMemcpyAsync(e->btab.p, btab.data(), (size_t)nband * sizeof(u64), hipMemcpyHostToDevice, c->st));
+    }
+    launch_encode_band32(ch.entries.p, ch.E, ba, e->gbase.p, c->ref.d_off.p + ch.seq_lo, e->dk32.p, c->st);
+    HIP_CHECK(hipStreamSynchronize(c->st));   // the host vectors must outlive the copies
+    return e;
+}
+
 // seed stage of one (batch, chunk): candidates appended to the batch's candidate store
 void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageClock& sc);
 
@@ -878,7 +1008,7 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     while (qa < b.nq) {
         unsigned long long acc = 0;
         u32 qb = qa;
-        while (qb < b.nq && (qb == qa || acc + qh[qb] <= budget)) acc += qh[qb++];
+        while (qb < b.nq && (qb == qa || (acc + qh[qb] <= budget && b.qcls[qb] == b.qcls[qa]))) acc += qh[qb++];
         if (acc >= 0xFFFFFFF0ull) throw SoError("a single query visits >= 2^32 index entries in one chunk: lower -c");
         if (acc) seed_pass(c, b, ci, qa, qb, wall(), sc);
         qa = qb;
@@ -906,33 +1036,51 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         c->cnt.seed_ms += (wall() - t0) * 1e3;
         return;
     }
-    // key layout
+    // key layout.  Query-position bits follow the PASS's longest query (passes hold one length class, seed_stage); subject and
+    // diagonal bits come from the compact banded addends when they fit (band_encoding), else from the chunk's longest sequence.
+    u32 pmaxq = 0;
+    for (u32 q = qa; q < qb; ++q) pmaxq = std::max(pmaxq, b.h_off[q + 1] - b.h_off[q]);
     KeyLayout kl;
     kl.bq = ceil_log2((u64)b.nq + 1);
-    kl.bs = ceil_log2(nseq_chunk);
-    kl.bp = ceil_log2(std::max<u32>(b.maxqlen, 2));
-    kl.bd = ceil_log2((u64)b.maxqlen + ch.maxslen + 1);
+    kl.bp = ceil_log2(std::max<u32>(pmaxq, 2));
     kl.ba = AS > 1 ? ceil_log2((u64)AS) : 0;
-    kl.diag_off = ch.maxslen;
+    const bool force_wide = getenv("SOHIT_LK_WIDE") && atoi(getenv("SOHIT_LK_WIDE")) != 0;
+    const bool bands_ok = !(getenv("SOHIT_BANDS") && atoi(getenv("SOHIT_BANDS")) == 0);   // SOHIT_BANDS=0: one band per subject whatever its length
+    ChunkIndex::BandEnc* enc = force_wide ? nullptr : band_encoding(c, ch, kl.ba, kl.bp, AS == 1 && bands_ok);
+    const bool compact = enc != nullptr;
+    const u32 nunit = compact ? enc->nband : nseq_chunk;   // what the key's subject field counts
+    if (compact) {
+        kl.bs = ceil_log2(std::max<u32>(enc->nband, 2));
+        kl.bd = enc->k;
+        kl.diag_off = enc->C;
+    } else {
+        kl.bs = ceil_log2(nseq_chunk);
+        kl.bd = ceil_log2((u64)pmaxq + ch.maxslen + 1);
+        kl.diag_off = ch.maxslen;
+    }
     kl.finish();
+    // layout of the pass records: chunk sequences and plain diagonals
+    KeyLayout klr = kl;
+    const void* btab = nullptr;
+    if (compact && enc->multi) {
+        klr.bs = ceil_log2(nseq_chunk);
+        klr.bd = ceil_log2((u64)pmaxq + ch.maxslen + 1);
+        klr.diag_off = ch.maxslen;
+        klr.finish();
+        btab = enc->btab.p;
+    }
     const int bsp = ceil_log2((u64)ch.maxslen + 1);
-    const int ft_bits_entry = (kl.bs + 1) + kl.ba + bsp;
+    const int ft_bits_entry = (klr.bs + 1) + klr.ba + bsp;
     const bool ft_walk = AS > 1;  // several (alphabet, pattern) combinations: a group's first-touch key needs all its hits
     if (kl.total > 64) throw SoError("sort key needs " + std::to_string(kl.total) + " bits (> 64): lower SOHIT_BATCH or -c");
+    if (klr.sh_subj + klr.bs > 64) throw SoError("pass-record key exceeds 64 bits: sequences too long for this build");
     if (kl.ba + kl.bp + ft_bits_entry > 64) throw SoError("first-touch key exceeds 64 bits: sequences too long for this build");
     b.cs_hoff.ensure((size_t)K + 2), b.cs_beg.ensure((size_t)K + 2), b.cs_kbase.ensure((size_t)K + 2);
     launch_compact_seeds(b.eff.p, b.hoff.p, b.cidx.p, b.sbeg.p, b.dev.d_pseq.p, b.dev.d_off.p, Ppad, AS, kl, b.cs_hoff.p, b.cs_beg.p,
                          b.cs_kbase.p, c->st);
-    // per-entry key addends for this layout: 4-byte compact form whenever the fields fit, else 8-byte
-    const bool force_wide = getenv("SOHIT_LK_WIDE") && atoi(getenv("SOHIT_LK_WIDE")) != 0;
-    const bool compact = !force_wide && (kl.bs + kl.bd + kl.ba <= 32);
-    if (compact) {
-        if (ch.d_ba != kl.ba || ch.d_bd != kl.bd) {
-            ch.dk32.ensure((size_t)ch.E + 4);
-            launch_encode_delta32(ch.entries.p, ch.E, kl.ba, kl.bd, ch.maxslen, c->ref.d_off.p + ch.seq_lo, ch.dk32.p, c->st);
-            ch.d_ba = kl.ba, ch.d_bd = kl.bd;
-        }
-    } else if (ch.d_sh_subj != kl.sh_subj || ch.d_sh_diag != kl.sh_diag) {
+    // per-entry key addends: the 4-byte compact form whenever the fields fit, else 8-byte ones for this layout
+    const u32* dk32 = compact ? enc->dk32.p : nullptr;
+    if (!compact && (ch.d_sh_subj != kl.sh_subj || ch.d_sh_diag != kl.sh_diag)) {
         ch.dkeys.ensure((size_t)ch.E + 2);
         launch_encode_delta(ch.entries.p, ch.E, kl.sh_subj, kl.sh_diag, ch.maxslen, ch.dkeys.p, c->st);
         ch.d_sh_subj = kl.sh_subj, ch.d_sh_diag = kl.sh_diag;
@@ -956,15 +1104,15 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     };
 
     // ---- diagonal binning, bucketed (k_bucket.hip): no sort; count -> scan -> scatter (4 B per hit) -> LDS hash grouping ----
-    // One alphabet x one pattern, compact index addends and wb + bd + bp <= 32; returns false when the pass has to take the
-    // sorted path below.
+    // One alphabet x one pattern, compact index addends and wb + bd + bp <= 31 (wb counts diagonal bands: one per chunk sequence,
+    // several for the few sequences too long for one); returns false when the pass has to take the sorted path below.
     auto group_bucketed = [&]() -> bool {
         const bool enabled = !(getenv("SOHIT_BUCKET") && atoi(getenv("SOHIT_BUCKET")) == 0);
         if (!enabled || AS != 1 || !compact || UG_SHARDS != 1) return false;
         const u32 nqp = qb - qa;
         const int wb_hi = std::min(std::min(31 - kl.bd - kl.bp, kl.bs), bkt_max_wb());   // hit word < 2^31; subjects per range <= the sort's bins
         int wb_lo = 0;
-        while (((u64)nseq_chunk + (1ull << wb_lo) - 1) >> wb_lo > BKT_RMAX) ++wb_lo;
+        while (((u64)nunit + (1ull << wb_lo) - 1) >> wb_lo > BKT_RMAX) ++wb_lo;
         if (wb_hi < wb_lo || kl.bp > 16) return false;
         // widest subject range whose average bucket is a few hits per thread of the workgroup that groups it
         const u32 target = getenv("SOHIT_BUCKET_AVG") ? (u32)std::max(1, atoi(getenv("SOHIT_BUCKET_AVG"))) : 2560u;
@@ -972,11 +1120,11 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         // sparse passes (long seeds: a few hundred hits per query) would leave the grouping kernel walking mostly empty
         // buckets: the sorted path handles those well (its segments are short)
         const u32 sparse = getenv("SOHIT_BUCKET_MIN") ? (u32)std::max(0, atoi(getenv("SOHIT_BUCKET_MIN"))) : 192u;
-        if ((u64)H / ((u64)nqp * (((u64)nseq_chunk + (1ull << wb) - 1) >> wb)) < sparse) return false;
-        while (wb > wb_lo && (u64)H / ((u64)nqp * (((u64)nseq_chunk + (1ull << wb) - 1) >> wb)) > target) --wb;
+        if ((u64)H / ((u64)nqp * (((u64)nunit + (1ull << wb) - 1) >> wb)) < sparse) return false;
+        while (wb > wb_lo && (u64)H / ((u64)nqp * (((u64)nunit + (1ull << wb) - 1) >> wb)) > target) --wb;
         BktLayout L;
         L.wb = wb, L.bd = kl.bd, L.bp = kl.bp, L.sh_q = kl.sh_q, L.sh_qpos = kl.sh_qpos, L.nqp = nqp, L.qa = qa;
-        L.R = (u32)(((u64)nseq_chunk + (1ull << wb) - 1) >> wb);
+        L.R = (u32)(((u64)nunit + (1ull << wb) - 1) >> wb);
         L.maxslen = ch.maxslen;
         if ((u64)L.R * nqp >= 0xFFFFFFF0ull) return false;
         const u32 nb = L.R * nqp;
@@ -996,7 +1144,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         b.bmat.ensure(nm + 4);
         {
             ProfTimer pt(c, &c->cnt.count_ms, &c->cnt.count_launches);
-            launch_bkt_pass(false, b.btd.p, qseg, NT, b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, ch.dk32.p, c->ref.d_off.p + ch.seq_lo, L, b.bmat.p,
+            launch_bkt_pass(false, b.btd.p, qseg, NT, b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, dk32, c->ref.d_off.p + ch.seq_lo, L, b.bmat.p,
                             nullptr, c->st);
             pt.stop();
         }
@@ -1012,7 +1160,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         b.hits32.ensure((size_t)H + 2);
         {
             ProfTimer pt(c, &c->cnt.lookup_ms, &c->cnt.lookup_launches);
-            launch_bkt_pass(true, b.btd.p, qseg, NT, b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, ch.dk32.p, c->ref.d_off.p + ch.seq_lo, L, b.bmat.p,
+            launch_bkt_pass(true, b.btd.p, qseg, NT, b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, dk32, c->ref.d_off.p + ch.seq_lo, L, b.bmat.p,
                             b.hits32.p, c->st);
             pt.stop();
             if (c->profile) c->cnt.lookup_bytes += (i64)8 * (i64)H;
@@ -1034,10 +1182,14 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         // best diagonal per subject bucket by bucket (k_bkt_best) when first-touch keys fit its 44-bit field; else the sorted path below
         // ... and a chained ungapped score fits the 20 bits k_bkt_best packs above them (at most 11 per residue of the shorter sequence)
         bbest = !(getenv("SOHIT_BUCKET_BEST") && atoi(getenv("SOHIT_BUCKET_BEST")) == 0) && !ft_walk && (kl.ba + kl.bp + ft_bits_entry <= 44) &&
-                (u64)std::min<u32>(b.maxqlen, ch.maxslen) * 11ull < (1ull << 20);
-        launch_ungap(b.keys2.p, Hv, kl, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.shard.p,
+                (u64)std::min<u32>(pmaxq, ch.maxslen) * 11ull < (1ull << 20);
+        launch_ungap(b.keys2.p, Hv, kl, klr, btab, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.shard.p,
                      shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
-        bL = L, bnb = nb;
+        // the pass records are binned by (query, range of 2^wb chunk SEQUENCES): the same layout unless bands and sequences differ
+        bL = L;
+        bL.R = (u32)(((u64)nseq_chunk + (1ull << wb) - 1) >> wb);
+        bnb = bL.R * nqp;
+        c->cnt.hits_bucketed += H;
         return true;
     };
 
@@ -1048,7 +1200,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     b.keys.ensure((size_t)H + 2), b.keys2.ensure((size_t)H + 2);
     {
         ProfTimer pt(c, &c->cnt.lookup_ms, &c->cnt.lookup_launches);
-        launch_lookup(b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, b.blk_first.p, K, H, compact ? (const void*)ch.dk32.p : (const void*)ch.dkeys.p,
+        launch_lookup(b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, b.blk_first.p, K, H, compact ? (const void*)dk32 : (const void*)ch.dkeys.p,
                       compact, c->ref.d_off.p + ch.seq_lo, kl, ch.maxslen, b.keys.p, c->st);
         pt.stop();
         if (c->profile) c->cnt.lookup_bytes += (i64)8 * (i64)H;
@@ -1073,7 +1225,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     }
     sc.lap("group.sort_keys");
     // group walk + chained ungapped extension (the kernel finds the group heads itself)
-    launch_ungap(b.keys2.p, H, kl, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo,
+    launch_ungap(b.keys2.p, H, kl, klr, btab, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo,
                  c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
     };
 
@@ -1117,12 +1269,12 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
             b.q_qs.ensure((size_t)NP + 2), b.q_sd.ensure((size_t)NP + 2), b.q_ft.ensure((size_t)NP + 2);
             c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)bnb + 2) + 8);
             HIP_CHECK(hipMemsetAsync(b.bcnt.p, 0, ((size_t)bnb + 2) * sizeof(u32), c->st));
-            launch_rec_count(b.p_qs.p, NP, kl.bs, bL, b.bcnt.p, b.pidx.p, c->st);
+            launch_rec_count(b.p_qs.p, NP, klr.bs, bL, b.bcnt.p, b.pidx.p, c->st);
             scan_u32(b.bcnt.p, b.bcnt.p, (size_t)bnb + 1, false, c->d_scan_tmp.p, c->st);
-            launch_rec_scatter(b.p_qs.p, b.p_sd.p, b.p_ft.p, b.pidx.p, NP, kl, bL, ft_bits_entry, bsp, c->ref.d_off.p + ch.seq_lo, b.bcnt.p, b.q_qs.p,
+            launch_rec_scatter(b.p_qs.p, b.p_sd.p, b.p_ft.p, b.pidx.p, NP, klr, bL, ft_bits_entry, bsp, c->ref.d_off.p + ch.seq_lo, b.bcnt.p, b.q_qs.p,
                                b.q_sd.p, b.q_ft.p, c->st);
             HIP_CHECK(hipMemsetAsync(b.bccnt.p + bnb, 0, 2 * sizeof(u32), c->st));
-            launch_bkt_best(false, b.q_qs.p, b.q_sd.p, b.q_ft.p, b.bcnt.p, bnb, bL, kl.bs, (u32)ch.seq_lo, b.bccnt.p, nullptr, nullptr, nullptr, bsp, 0,
+            launch_bkt_best(false, b.q_qs.p, b.q_sd.p, b.q_ft.p, b.bcnt.p, bnb, bL, klr.bs, (u32)ch.seq_lo, b.bccnt.p, nullptr, nullptr, nullptr, bsp, 0,
                             c->st);
             NS = d2h_u32(c, scan_u32(b.bccnt.p, b.bccnt.p, (size_t)bnb + 1, false, c->d_scan_tmp.p, c->st));
             if (getenv("SOHIT_DEBUG"))
@@ -1136,34 +1288,34 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
                 static const bool cand_keys = !(getenv("SOHIT_CAND_KEYS") && atoi(getenv("SOHIT_CAND_KEYS")) == 0);
                 static const bool cand_seg0 = !(getenv("SOHIT_CAND_SEGSORT") && atoi(getenv("SOHIT_CAND_SEGSORT")) == 0);
                 const int ftw = kl.ba + kl.bp + ft_bits_entry - bsp + 1;
-                if (cand_keys && cand_seg0 && bL.nqp >= 256 && ftw < 63 && 63 - ftw >= kl.bs + 1) cand_idx_bits = 63 - ftw, cand_ftw = ftw;
+                if (cand_keys && cand_seg0 && bL.nqp >= 256 && ftw < 63 && 63 - ftw >= klr.bs + 1) cand_idx_bits = 63 - ftw, cand_ftw = ftw;
             }
-            launch_bkt_best(true, b.q_qs.p, b.q_sd.p, b.q_ft.p, b.bcnt.p, bnb, bL, kl.bs, (u32)ch.seq_lo, b.bccnt.p, c_ftp, c_qp, c_recp, bsp,
+            launch_bkt_best(true, b.q_qs.p, b.q_sd.p, b.q_ft.p, b.bcnt.p, bnb, bL, klr.bs, (u32)ch.seq_lo, b.bccnt.p, c_ftp, c_qp, c_recp, bsp,
                             cand_idx_bits, c->st);
             break;
         }
         // first-touch keys of the passing groups (k_ungap left the head hit's key / position in the third array)
-        if (NP) launch_first_touch(ft_walk, b.keys2.p, H, kl, ft_bits_entry, bsp, c->ref.d_off.p + ch.seq_lo, const_cast<u64*>(q_ft), NP, c->st);
+        if (NP) launch_first_touch(ft_walk, b.keys2.p, H, klr, ft_bits_entry, bsp, c->ref.d_off.p + ch.seq_lo, const_cast<u64*>(q_ft), NP, c->st);
         if (NP == 0) break;
         // best diagonal per (query, subject): sort pass records by (q, subject)
         b.pidx.ensure((size_t)NP + 2), b.pidx2.ensure((size_t)NP + 2), b.p_qs2.ensure((size_t)NP + 2);
         launch_iota(b.pidx.p, NP, c->st);
         ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(NP, 64));
-        sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, q_qs, b.p_qs2.p, b.pidx.p, b.pidx2.p, NP, kl.bs + kl.bq, c->st);
+        sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, q_qs, b.p_qs2.p, b.pidx.p, b.pidx2.p, NP, klr.bs + kl.bq, c->st);
         b.flags.ensure((size_t)NP + 4), b.gidx.ensure((size_t)NP + 4);
         c->d_small.ensure(16);
         launch_seg_flags(b.p_qs2.p, NP, b.flags.p, c->d_small.p, c->st);
         const u32* dS = scan_u32(b.flags.p, b.gidx.p, NP, false, c->d_scan_tmp.p, c->st);
         // per-query candidate segments and the longest one (d_small[0]), fetched with the candidate total
         b.qseg.ensure((size_t)b.nq + 4);
-        launch_qseg(b.p_qs2.p, NP, b.gidx.p, dS, kl.bs, b.nq, b.qseg.p, c->d_small.p, c->st);
+        launch_qseg(b.p_qs2.p, NP, b.gidx.p, dS, klr.bs, b.nq, b.qseg.p, c->d_small.p, c->st);
         d2h_pair(c, dS, maxseg, NS);
         b.shead.ensure((size_t)NS + 2);
         if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] seed pass: queries %u..%u hits %u seeds %u pass records %u candidates %u\n", qa, qb, H, K, NP, NS);
         launch_group_list(b.flags.p, b.gidx.p, NP, b.shead.p, c->st);
         b.c_ft.ensure((size_t)NS + 2), b.c_q.ensure((size_t)NS + 2), b.c_rec.ensure(4 * (size_t)NS + 8);
         c_ftp = b.c_ft.p, c_qp = b.c_q.p, c_recp = b.c_rec.p;
-        launch_best(b.p_qs2.p, b.pidx2.p, b.shead.p, NS, NP, q_sd, q_ft, (u32)ch.seq_lo, kl.bs, c_ftp, c_qp, c_recp, c->st);
+        launch_best(b.p_qs2.p, b.pidx2.p, b.shead.p, NS, NP, q_sd, q_ft, (u32)ch.seq_lo, klr.bs, c_ftp, c_qp, c_recp, c->st);
         break;
     }
     if (NS == 0) {
@@ -1382,7 +1534,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         if (Ntot) HIP_CHECK(hipMemcpyAsync(rec.data(), b.fin_rec.p, 4 * (size_t)Ntot * sizeof(u32), hipMemcpyDeviceToHost, c->st));
         HIP_CHECK(hipStreamSynchronize(c->st));
         for (u32 q = 0; q < nq; ++q) {
-            auto& dst = c->last_cands[(size_t)(b.q_lo - c->last_q_lo) + q];
+            auto& dst = c->last_cands[(size_t)(b.q_lo - c->last_q_lo) + b.qid[q]];
             dst.assign(rec.begin() + 4 * (size_t)qcoff[q], rec.begin() + 4 * (size_t)qcoff[q + 1]);
         }
     }
@@ -1433,21 +1585,32 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     // k_align runs four alignments per wave and a wave lasts as long as its longest one: every launch list is ordered by band rows,
     // longest first (one 13-bit radix sort; config 3: align rounds 33.6 -> 28.4 ms, sort included).  SOHIT_ALIGN_SORT=0: as listed.
     const bool align_sort = !(getenv("SOHIT_ALIGN_SORT") && atoi(getenv("SOHIT_ALIGN_SORT")) == 0);
-    auto sort_by_rows = [&](const u32* list, u32 n) -> const u32* {
-        if (!align_sort || n < 4096) return list;
+    // The packed 16-bit aligner takes a task whose scores fit its cells: 11 * min(rows, columns), or the smaller of the two sequences'
+    // score bounds (k_seq_bound), within range.  That is a property of the TASK: a launch list is split into the tasks it cannot take
+    // (k_task_rows clears bit 13 of their sort key, so they lead the sorted list, and counts them) and the rest.  Only batches that hold
+    // a query AND a reference sequence above the length limit can contain such tasks at all.
+    const u32 maxwin_q = std::min<u32>(b.maxqlen, LONG_SEQ), maxwin_s = std::min<u32>(c->ref.maxlen, LONG_SEQ);
+    const bool pk_on = !(getenv("SOHIT_ALIGN_PK") && atoi(getenv("SOHIT_ALIGN_PK")) == 0);
+    const bool pk_mixed = pk_on && (int)std::min(maxwin_q, maxwin_s) > align_pk_max_len();
+    auto sort_by_rows = [&](const u32* list, u32 n, u32* n_wide) -> const u32* {
+        const bool split = n_wide && pk_mixed;
+        if (n_wide) *n_wide = pk_on ? 0u : n;
+        if (!split && (!align_sort || n < 4096)) return list;
         b.tmp64.ensure((size_t)n + 2), b.c_ft2.ensure((size_t)n + 2), b.ridx2.ensure((size_t)n + 2);
         ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(n, 64));
         // (ordering inside blocks of 2^k queries instead of globally -- key = query block << 13 | rows -- was measured: 24.9-25.2 ms of
         // align rounds for k = 7 ... 13 against 24.8-25.2)
-        launch_task_rows(b.tasks.p, list, n, b.dev.d_off.p, c->ref.d_off.p, b.tmp64.p, c->st);
-        sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, list, b.ridx2.p, n, 13, c->st);
+        c->d_small.ensure(16);
+        if (split) HIP_CHECK(hipMemsetAsync(c->d_small.p + 12, 0, sizeof(u32), c->st));
+        launch_task_rows(b.tasks.p, list, n, b.dev.d_off.p, c->ref.d_off.p, b.dev.d_bound.p, c->ref.d_bound.p, align_pk_max_len(), align_pk_max_score(),
+                         split ? c->d_small.p + 12 : nullptr, b.ucount.p + 2, b.tmp64.p, c->st);
+        sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, list, b.ridx2.p, n, split ? 14 : 13, c->st);
+        if (split) *n_wide = d2h_u32(c, c->d_small.p + 12);
         return b.ridx2.p;
     };
     // banded alignments in rounds (see k_round_counts / k_stop_round_w)
-    const u32 maxwin_q = std::min<u32>(b.maxqlen, LONG_SEQ), maxwin_s = std::min<u32>(c->ref.maxlen, LONG_SEQ);
     const int maxrows = (int)std::min<u32>(std::max(maxwin_q, maxwin_s), std::min(maxwin_q, maxwin_s) + 16);
     const u32 stride = align_trace_stride(maxrows + 1);
-    const bool align_pk = !(getenv("SOHIT_ALIGN_PK") && atoi(getenv("SOHIT_ALIGN_PK")) == 0) && (int)std::min(maxwin_q, maxwin_s) <= align_pk_max_len();
     const size_t budget_words = (size_t)1 << 30;  // 4 GiB of trace scratch
     const u32 slab = (u32)std::max<size_t>(16, std::min<size_t>(std::max<u32>(NT, 1), budget_words / std::max<u32>(stride, 1)));
     b.st_state.ensure(5 * (size_t)nq + 8), b.rcnt.ensure((size_t)nq + 4), b.tcnt.ensure((size_t)nq + 4), b.roff.ensure((size_t)nq + 4);
@@ -1507,7 +1670,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             launch_round_idx_spec(b.tcnt.p, b.spcnt.p, b.roff.p, b.spoff.p, b.toff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.st_state.p, nq,
                                   b.ridx.p, b.sidx.p, c->st);
             if (NS) {
-                const u32* slist = sort_by_rows(b.sidx.p, NS);
+                const u32* slist = sort_by_rows(b.sidx.p, NS, nullptr);
                 b.spec_trace.ensure((size_t)NS * stride + 64);
                 ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
                 launch_align_traced(b.tasks.p, slist, NS, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_scls4.p,
@@ -1520,16 +1683,19 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         }
         if (NR) {
             // score-only: the stop rule needs the maximum alone; the reported rows are traced in a second pass below
-            const u32* rlist = sort_by_rows(b.ridx.p, NR);
+            u32 n_wide = 0;
+            const u32* rlist = sort_by_rows(b.ridx.p, NR, &n_wide);
             ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
-            // score-only: packed 16-bit kernel (two alignments per register) whenever the longest window's best possible score fits
-            if (align_pk)
-                launch_align_pk(b.tasks.p, rlist, NR, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_scls4.p, c->ref.d_off.p,
-                                c->d_b62c.p, b.ares.p, c->st);
-            else
-                launch_align(b.tasks.p, rlist, NR, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
+            // score-only: the packed 16-bit kernel (two alignments per register) for every task whose scores fit it, the 32-bit one for the
+            // n_wide tasks at the head of the list that do not
+            if (n_wide)
+                launch_align(b.tasks.p, rlist, n_wide, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
                              c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, b.ares.p, false, c->st);
+            if (NR > n_wide)
+                launch_align_pk(b.tasks.p, rlist + n_wide, NR - n_wide, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_scls4.p,
+                                c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->st);
             pt.stop();
+            c->cnt.align_wide += n_wide;
         }
         launch_stop_round_w(b.tasks.p, b.ares.p, b.qcoff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.toff.p, b.rcnt.p, nq,
                             b.dev.d_off.p, c->ref.d_off.p, c->d_bittab.p, so_ctx::BITTAB_N, c->ref.N, c->expect, c->max_miss, c->v, b.sel.p,
@@ -1655,7 +1821,15 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                 HIP_CHECK(hipMemcpy(c->d_p2tab.p, p2.data(), 1200 * sizeof(double), hipMemcpyHostToDevice));
             }
             c->d_hits.ensure((c->d_hits_n + NO) * sizeof(so_hit) + 256, true, c->st);
-            launch_make_hits(b.outrec.p, NO, b.q_lo, c->qry.d_off.p, c->ref.d_off.p, c->ref.N, c->d_p2tab.p, 1200,
+            const u32 *d_qid = nullptr, *d_ostart = nullptr;
+            if (b.permuted) {   // records in file order: row counts scattered to file order, scanned
+                b.d_ocnt.ensure((size_t)nq + 4), b.d_ostart.ensure((size_t)nq + 4);
+                launch_scatter_u32(b.nout.p, b.d_qid.p, nq, b.d_ocnt.p, c->st);
+                HIP_CHECK(hipMemsetAsync(b.d_ocnt.p + nq, 0, sizeof(u32), c->st));
+                scan_u32(b.d_ocnt.p, b.d_ostart.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
+                d_qid = b.d_qid.p, d_ostart = b.d_ostart.p;
+            }
+            launch_make_hits(b.outrec.p, NO, b.q_lo, d_qid, b.ooff.p, d_ostart, c->qry.d_off.p, c->ref.d_off.p, c->ref.N, c->d_p2tab.p, 1200,
                              c->d_hits.p + c->d_hits_n * sizeof(so_hit), c->st);
             c->d_hits_n += NO;
             sc.lap("phase2.emit_device");
@@ -1683,17 +1857,42 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         const double expect = c->expect;
         const i64 q_lo = b.q_lo;
         const double* p2p = p2.data();
+        // A batch that holds its queries in length-class order hands the rows over in that order; they are written in FILE order:
+        // slot s's rows, [ooff[s], ooff[s + 1]) of the download, start at row ostart[qid[s]] -- place[s] = {query, destination - source}.
+        std::shared_ptr<std::vector<std::pair<u32, i64>>> place;
+        if (b.permuted) {
+            std::vector<u32> ooff((size_t)nq + 1);
+            HIP_CHECK(hipMemcpyAsync(ooff.data(), b.ooff.p, ((size_t)nq + 1) * sizeof(u32), hipMemcpyDeviceToHost, c->st));
+            HIP_CHECK(hipStreamSynchronize(c->st));
+            std::vector<u32> ocnt((size_t)nq + 1, 0);
+            for (u32 s = 0; s < nq; ++s) ocnt[b.qid[s]] = ooff[s + 1] - ooff[s];
+            u32 run = 0;
+            for (u32 o = 0; o < nq; ++o) {
+                const u32 n = ocnt[o];
+                ocnt[o] = run;
+                run += n;
+            }
+            place = std::make_shared<std::vector<std::pair<u32, i64>>>(nq);
+            for (u32 s = 0; s < nq; ++s) (*place)[s] = {b.qid[s], (i64)ocnt[b.qid[s]] - (i64)ooff[s]};
+        }
         c->emit.base = base, c->emit.n = NO;
         c->emit.dropped.store(0);
         c->emit.active = true;
-        c->emit.th = std::thread([c, rows, dst, NO, D, expect, q_lo, p2p] {
+        c->emit.th = std::thread([c, rows, dst, NO, D, expect, q_lo, p2p, place] {
             try {
                 HIP_CHECK(hipSetDevice(c->device));
                 HIP_CHECK(hipEventSynchronize(c->ev_rows_done));  // the rows have arrived in the pinned buffer
                 parallel_for((i64)NO, [&](i64 i) {
                     const int* v = rows[i].v;
                     so_hit h;
-                    h.qidx = q_lo + v[0];
+                    i64 di = i;
+                    if (place) {
+                        const auto& pl = (*place)[(size_t)v[0]];
+                        h.qidx = q_lo + pl.first;
+                        di = i + pl.second;
+                    } else {
+                        h.qidx = q_lo + v[0];
+                    }
                     h.sidx = v[1];
                     h.aln = v[2], h.mis = v[3], h.gap = v[4], h.qst = v[5], h.qed = v[6], h.sst = v[7], h.sed = v[8], h.bit = v[9];
                     h.ungapped = v[10], h.matches = v[11];
@@ -1705,7 +1904,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                     const double pw = (h.bit >= 0 && h.bit < 1200) ? p2p[h.bit] : p_pow(2, (double)(-h.bit));
                     h.evalue = (double)(D * (i64)h.qlen * (i64)h.slen) * pw;
                     if (!(h.evalue <= expect)) c->emit.dropped.fetch_add(1);
-                    dst[i] = h;
+                    dst[di] = h;
                 });
             } catch (...) {
                 c->emit.err = std::current_exception();
@@ -1771,10 +1970,11 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
             HIP_CHECK(hipMemsetAsync(b.ccnt.p, 0, ((size_t)std::max(1, nchunks) * b.nq + 4) * sizeof(u32), c->st));
             for (int ci = 0; ci < nchunks; ++ci) seed_stage(c, b, ci);
             phase2(c, b, out);
-            unsigned long long uc[2] = {0, 0};
+            unsigned long long uc[3] = {0, 0, 0};
             HIP_CHECK(hipMemcpyAsync(uc, b.ucount.p, sizeof uc, hipMemcpyDeviceToHost, c->st));
             HIP_CHECK(hipStreamSynchronize(c->st));
             c->cnt.cells += (i64)uc[1];
+            c->cnt.cells_wide += (i64)uc[2];
             c->cnt.n_queries += b.nq;
             c->cnt.query_aa += b.h_off[b.nq];
             if (getenv("SOHIT_KEEP_MASKED")) {
@@ -1783,8 +1983,10 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
                     b.h_res.resize(b.h_off[b.nq] + 16);
                     HIP_CHECK(hipMemcpy(b.h_res.data(), b.dev.d_res.p, b.h_off[b.nq], hipMemcpyDeviceToHost));
                 }
+                const size_t m0 = c->masked.size();
+                c->masked.resize(m0 + b.nq);
                 for (u32 i = 0; i < b.nq; ++i)
-                    c->masked.emplace_back((const char*)b.h_res.data() + b.h_off[i], (size_t)(b.h_off[i + 1] - b.h_off[i]));
+                    c->masked[m0 + b.qid[i]].assign((const char*)b.h_res.data() + b.h_off[i], (size_t)(b.h_off[i + 1] - b.h_off[i]));
             }
         } catch (const SoError& e) {
             const bool oom = dynamic_cast<const DevOom*>(&e) != nullptr;
@@ -1924,7 +2126,7 @@ void query_work(so_ctx* c, i64 q_lo, i64 q_hi, u64* out) {
                 ChunkIndex& ch = *c->chunks[ci];
                 if (ch.seq_hi == ch.seq_lo || ch.E == 0 || b.nq == 0) continue;
                 const unsigned long long* qh = chunk_qhits(c, b, ci);
-                for (u32 i = 0; i < b.nq; ++i) out[b0 - st + i] += qh[i];
+                for (u32 i = 0; i < b.nq; ++i) out[b0 - st + b.qid[i]] += qh[i];
             }
         }
     } catch (...) {

@@ -230,6 +230,8 @@ __global__ __launch_bounds__(PK_THREADS) void k_align_pk(const AlnTask* __restri
 
 // largest min(rows, columns) whose scores fit the packed cells: (11 * n << 2) + 47 + 44 (one more substitution) <= 32767
 int align_pk_max_len() { return 740; }
+// ... or whose score bound does: (score << 2) + 47 + 44 <= 32767
+u32 align_pk_max_score() { return 8169; }
 
 void launch_align_pk(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
                      const u8* r_scls4, const u32* roff, const signed char* b62g, AlnRes* out, hipStream_t st) {

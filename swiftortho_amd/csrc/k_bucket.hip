@@ -7,7 +7,8 @@
 //
 //   1. tiles           a query's hit ordinals are cut into tiles of <= 1024 (k_bkt_ntiles / k_bkt_tiledesc), so a tile never
 //                      straddles two queries.
-//   2. k_bkt_pass      the seed-lookup kernel, run twice.  A BUCKET is (query, range of W = 2^wb chunk sequences); inside
+//   2. k_bkt_pass      the seed-lookup kernel, run twice.  A BUCKET is (query, range of W = 2^wb diagonal bands -- one per chunk
+//                      sequence, several for the sequences too long for one, see k_encode_band32); inside
 //                      its bucket a hit is ONE 32-bit word  subject_low | diagonal | qpos.  Pass 1 counts the hits of
 //                      every (range, tile) in a per-wave LDS histogram and stores the counts range-major; an exclusive scan
 //                      of that matrix IS the scatter plan (buckets range-major, tiles in order inside a bucket); pass 2
@@ -93,17 +94,17 @@ __global__ __launch_bounds__(256) void k_bkt_tiledesc(const u32* __restrict__ qs
     td[t] = make_uint4(q, first, k0, a);
 }
 
-// One hit: index addend c (k_encode_delta32 with ba == 0: subject << bd | (maxslen - pos); entries at offset 0 of their sequence
-// come resolved to the previous non-empty sequence, or with an all-ones diagonal field when the reference drops them,
-// fsearch.py:2685-2688) + the seed's query position -> subject range and 32-bit word.  Branch-free: the kernels' scalar unit,
-// shared by the four SIMDs of a CU, was saturated by the exec-mask bookkeeping of a per-hit slow path (round 2: 1100 scalar
-// against 800 vector instructions per tile).
+// One hit: index addend c (k_encode_band32 with ba == 0: gbase[subject] - pos, or all-ones for the offset-0 entries the reference
+// drops, fsearch.py:2685-2688) + the seed's query position = the hit's banded diagonal id G (band << bd | diagonal inside the band;
+// the addition may carry into the band bits: that is the next band of a long subject) -> band range and 32-bit word.  Branch-free:
+// the kernels' scalar unit, shared by the four SIMDs of a CU, was saturated by the exec-mask bookkeeping of a per-hit slow path
+// (round 2: 1100 scalar against 800 vector instructions per tile).
 __device__ __forceinline__ bool bk_hit(u32 c, u32 qpos, const BktLayout& L, u32& range, u32& word) {
-    const u32 dmask = (1u << L.bd) - 1u;
-    const u32 j = c >> L.bd, dp = c & dmask;
-    range = j >> L.wb;
-    word = ((j & ((1u << L.wb) - 1u)) << (L.bd + L.bp)) | ((qpos + dp) << L.bp) | qpos;
-    return dp != dmask;
+    const u32 g = c + qpos;
+    const int gb = L.wb + L.bd;
+    range = g >> gb;
+    word = ((g & ((1u << gb) - 1u)) << L.bp) | qpos;
+    return (int)c >= 0;
 }
 
 // Per-wave LDS histogram of the tile's hits per range, REPLICATED: lane l counts in copy l mod ncopy.  Hits of one seed arrive

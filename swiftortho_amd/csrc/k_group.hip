@@ -47,8 +47,12 @@ __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global
 
 enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN = 5 };
 
-template <int CPI /*chunks per loop iteration*/>
-__global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restrict__ keys, u32 H, KeyLayout kl, int ft_walk, u32 wait_n,
+// BANDS (compact index addends where some subject owns several diagonal bands, k_encode_band32): the key's subject field is a band id
+// and btab[band] = (chunk sequence, gbase) resolves it -- sst - qpos = gbase - (band << bd | diagonal); the pass records then carry
+// the sequence id and a head key rebuilt in the record layout klr (sequence bits, diagonal + klr.diag_off).  Without BANDS klr == kl.
+template <int CPI /*chunks per loop iteration*/, bool BANDS>
+__global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restrict__ keys, u32 H, KeyLayout kl, KeyLayout klr, const uint2* __restrict__ btab,
+                                                         int ft_walk, u32 wait_n,
                                                          const u8* __restrict__ q_scls, const u32* __restrict__ qoff,
                                                          const u8* __restrict__ r_scls,
                                                          const u32* __restrict__ roff /*chunk-local offsets (absolute values)*/,
@@ -166,8 +170,15 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                         hkey = k0, havekey = true;
                         gpre = k0 >> kl.sh_diag;
                         gq = (u32)((k0 >> kl.sh_q) & qall);
-                        gsubj = (u32)((k0 >> kl.sh_subj) & ((1ull << kl.bs) - 1ull));
-                        dlt = (int)(kl.diag_off - (i64)((k0 >> kl.sh_diag) & ((1ull << kl.bd) - 1ull)));  // sst - qpos
+                        if (BANDS) {
+                            const u32 G = (u32)((k0 >> kl.sh_diag) & ((1ull << (kl.bs + kl.bd)) - 1ull));
+                            const uint2 be = btab[G >> kl.bd];
+                            gsubj = be.x;
+                            dlt = (int)(be.y - G);  // sst - qpos
+                        } else {
+                            gsubj = (u32)((k0 >> kl.sh_subj) & ((1ull << kl.bs) - 1ull));
+                            dlt = (int)(kl.diag_off - (i64)((k0 >> kl.sh_diag) & ((1ull << kl.bd) - 1ull)));  // sst - qpos
+                        }
                         if (gq != cq) cq = gq, cqb = qoff[gq], cql = (int)(qoff[gq + 1] - cqb);
                         qb = cqb;
                         const u32 sb = roff[gsubj];
@@ -308,9 +319,12 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                 if (pass) {
                     const int dist = dlt;  // guess_start (2544-2553): floor(2 * (sst - qst) / 2) = the diagonal
                     const u32 i = npb + (u32)__popcll(pb & lt);
-                    s_pqs[i] = ((u64)gq << kl.bs) | gsubj;
+                    s_pqs[i] = ((u64)gq << (BANDS ? klr.bs : kl.bs)) | gsubj;
                     s_psd[i] = ((u64)(u32)scores << 32) | (u64)(u32)dist;
-                    s_pft[i] = ft_walk ? (u64)h0 : hkey;  // k_first_touch turns this into the first-touch key
+                    // k_first_touch / k_rec_scatter turn this into the first-touch key
+                    u64 hk = hkey;
+                    if (BANDS) hk = ((u64)gsubj << klr.sh_subj) | ((u64)(klr.diag_off - (i64)dlt) << klr.sh_diag) | (((hkey >> kl.sh_qpos) & pmask) << klr.sh_qpos);
+                    s_pft[i] = ft_walk ? (u64)h0 : hk;
                 }
                 npb += np;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -591,15 +605,16 @@ u32 ungap_shard_cap(u32 H) {
     return ((nblk + UG_SHARDS - 1) / UG_SHARDS) * (UW_RANGE * UW_WAVES);
 }
 
-void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, bool ft_walk, const u8* q_scls, const u32* qoff,
+void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& klr, const void* btab, bool ft_walk, const u8* q_scls, const u32* qoff,
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt, u32 shard_cap, u64* p_qs, u64* p_sd,
                   u64* p_ft, unsigned long long* group_count, hipStream_t st) {
     if (!H) return;
     // SOHIT_UG_CPI / SOHIT_UG_WAIT: tuning switches (results do not depend on them)
     const int cpi = getenv("SOHIT_UG_CPI") ? atoi(getenv("SOHIT_UG_CPI")) : UW_CPI;
     const u32 wait_n = getenv("SOHIT_UG_WAIT") ? (u32)atoi(getenv("SOHIT_UG_WAIT")) : UW_WAIT;
-    auto kern = cpi == 1 ? k_ungap<1> : cpi == 2 ? k_ungap<2> : k_ungap<3>;
-    hipLaunchKernelGGL(kern, dim3(ungap_num_blocks(H)), dim3(64 * UW_WAVES), 0, st, keys, H, kl, ft_walk ? 1 : 0, wait_n, q_scls, qoff,
+    auto kern = btab ? (cpi == 1 ? k_ungap<1, true> : cpi == 2 ? k_ungap<2, true> : k_ungap<3, true>)
+                     : (cpi == 1 ? k_ungap<1, false> : cpi == 2 ? k_ungap<2, false> : k_ungap<3, false>);
+    hipLaunchKernelGGL(kern, dim3(ungap_num_blocks(H)), dim3(64 * UW_WAVES), 0, st, keys, H, kl, klr, (const uint2*)btab, ft_walk ? 1 : 0, wait_n, q_scls, qoff,
                        r_scls, roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count);
 }
 

@@ -251,39 +251,43 @@ __global__ __launch_bounds__(256) void k_encode_delta(const u64* __restrict__ en
                         : (((u64)j << sh_subj) + ((u64)(maxslen - pos) << sh_diag) + (u64)tag);
 }
 
-// Compact form, used whenever subject, diagonal and tag fields fit 32 bits together (bs + bd + ba <= 32: every
-// protein-sized input): c = (subject << (bd + ba)) | ((maxslen - pos) << ba) | tag, i.e. the three fields in
-// key order with the (qpos, as) gap squeezed out, so that   D = ((u64)(c >> ba) << sh_diag) + (c & amask)
-// and the lookup kernel reads 4 bytes per visited hit instead of 8.
+// Compact form (4 bytes per index entry), round 4: BANDED DIAGONAL IDS.  Every (subject, diagonal) pair of the chunk gets one
+// integer  G = gbase[subject] + qpos - pos  that grows with (subject, diagonal) -- so a hit's sort key is still one addition,
+// key = kbase(seed) + (c >> ba << sh_diag) + (c & amask)  with the entry's addend  c = (gbase[subject] - pos) << ba | tag  --
+// but the number of ids a subject owns follows ITS length instead of the chunk's longest: with k = KeyLayout::bd "diagonal" bits
+// and the pass's queries shorter than 2^bp, a subject of length <= C = 2^k - 2^bp owns one band of 2^k ids (gbase = band << k | C),
+// a longer one owns ceil((length + 2^bp) / 2^k) consecutive bands (gbase = first band << k | length).  The KeyLayout's "subject" field
+// then is the BAND id, and k_ungap maps a band back to (subject, gbase) through a table when some subject owns several; when none
+// does, band == subject and the diagonal field is qpos - pos + C exactly as before round 4.  One 30 000-residue protein in a chunk
+// used to widen the diagonal field of every hit of the chunk to 16 bits, which pushed the hit word of the bucketed binning past
+// 32 bits and the whole pass to the sorted path.
 // An entry at offset 0 of its sequence is resolved HERE, once per index entry instead of once per visiting hit: the
 // reference's strict `soas[j] < x` (fsearch.py:2685-2688) attributes it to the previous non-empty sequence of the chunk at
-// sst = that sequence's length, so the addend carries that subject and (maxslen - its length).  When there is no such
-// sequence the reference resolves index -1 and the hit never scores: those entries keep an all-ones diagonal field (never a
-// real value: maxslen - pos <= maxslen < 2^bd - 1), which the lookup kernels read as "drop".
-__global__ __launch_bounds__(256) void k_encode_delta32(const u64* __restrict__ entries, u32 E, int ba, int bd, u32 maxslen,
-                                                        const u32* __restrict__ roff /*chunk-local offsets*/, u32* __restrict__ dk32) {
+// sst = that sequence's length.  When there is no such sequence the reference resolves index -1 and the hit never scores: those
+// entries are all-ones (never a real value: the host keeps band and diagonal bits + ba <= 31), which the lookup kernels read as "drop".
+__global__ __launch_bounds__(256) void k_encode_band32(const u64* __restrict__ entries, u32 E, int ba, const u32* __restrict__ gbase /*per chunk sequence*/,
+                                                       const u32* __restrict__ roff /*chunk-local offsets*/, u32* __restrict__ dk32) {
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i >= E) return;
     const u64 e = entries[i];
     u32 j = (u32)(e >> 32);
-    const u32 pos = (u32)e & 0xFFFFFFu, tag = (u32)(e >> 24) & 0xFFu;
-    const u32 dmask = (1u << bd) - 1u;
-    u32 dp = maxslen - pos;
+    u32 pos = (u32)e & 0xFFFFFFu;
+    const u32 tag = (u32)(e >> 24) & 0xFFu;
     if (pos == 0) {
         while (j > 0 && roff[j] == roff[j - 1]) --j;
         if (j == 0) {
-            j = (u32)(e >> 32), dp = dmask;
-        } else {
-            j -= 1;
-            dp = maxslen - (roff[j + 1] - roff[j]);
+            dk32[i] = 0xFFFFFFFFu;
+            return;
         }
+        j -= 1;
+        pos = roff[j + 1] - roff[j];
     }
-    dk32[i] = (j << (bd + ba)) | (dp << ba) | tag;
+    dk32[i] = ((gbase[j] - pos) << ba) | tag;
 }
 
-void launch_encode_delta32(const u64* entries, u32 E, int ba, int bd, u32 maxslen, const u32* roff, u32* dk32, hipStream_t st) {
+void launch_encode_band32(const u64* entries, u32 E, int ba, const u32* gbase, const u32* roff, u32* dk32, hipStream_t st) {
     if (!E) return;
-    hipLaunchKernelGGL(k_encode_delta32, dim3((E + 255) / 256), dim3(256), 0, st, entries, E, ba, bd, maxslen, roff, dk32);
+    hipLaunchKernelGGL(k_encode_band32, dim3((E + 255) / 256), dim3(256), 0, st, entries, E, ba, gbase, roff, dk32);
 }
 
 void launch_encode_delta(const u64* entries, u32 E, int sh_subj, int sh_diag, u32 maxslen, u64* dkeys, hipStream_t st) {

@@ -495,14 +495,24 @@ struct DevHit {
 };
 static_assert(sizeof(DevHit) == 80, "so_hit layout");
 
-__global__ __launch_bounds__(256) void k_make_hits(const int* __restrict__ rows, u32 n, long long q_lo, const u32* __restrict__ qoff_abs,
+// qid != null: the batch holds its queries in length-class order (slot v[0] is query q_lo + qid[v[0]] of the file) and the records
+// are written in FILE order: slot s's rows, [ooff[s], ooff[s + 1]) here, start at ostart[qid[s]] there.
+__global__ __launch_bounds__(256) void k_make_hits(const int* __restrict__ rows, u32 n, long long q_lo, const u32* __restrict__ qid,
+                                                   const u32* __restrict__ ooff, const u32* __restrict__ ostart, const u32* __restrict__ qoff_abs,
                                                    const u32* __restrict__ roff, long long D, const double* __restrict__ p2tab, int p2n,
                                                    DevHit* __restrict__ out) {
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const int* v = rows + 12 * (size_t)i;
     DevHit h;
-    h.qidx = q_lo + v[0];
+    u32 dst = i;
+    if (qid) {
+        const u32 s = (u32)v[0], o = qid[s];
+        h.qidx = q_lo + o;
+        dst = ostart[o] + (i - ooff[s]);
+    } else {
+        h.qidx = q_lo + v[0];
+    }
     h.sidx = v[1];
     h.aln = v[2], h.mis = v[3], h.gap = v[4], h.qst = v[5], h.qed = v[6], h.sst = v[7], h.sed = v[8], h.bit = v[9];
     h.ungapped = v[10], h.matches = v[11];
@@ -511,7 +521,13 @@ __global__ __launch_bounds__(256) void k_make_hits(const int* __restrict__ rows,
     h.identity = (double)h.matches * (100. / (double)h.aln);
     const double pw = (h.bit >= 0 && h.bit < p2n) ? p2tab[h.bit] : (h.bit < 0 ? ldexp(1.0, -h.bit) : 0.0);
     h.evalue = (double)(D * (long long)h.qlen * (long long)h.slen) * pw;
-    out[i] = h;
+    out[dst] = h;
+}
+
+// dst[idx[i]] = src[i]
+__global__ __launch_bounds__(256) void k_scatter_u32(const u32* __restrict__ src, const u32* __restrict__ idx, u32 n, u32* __restrict__ dst) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) dst[idx[i]] = src[i];
 }
 
 
@@ -608,28 +624,57 @@ void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, 
 }
 
 
-void launch_make_hits(const int* rows, u32 n, i64 q_lo, const u32* qoff_abs, const u32* roff, i64 D, const double* p2tab, int p2n, void* out,
-                      hipStream_t st) {
+void launch_make_hits(const int* rows, u32 n, i64 q_lo, const u32* qid, const u32* ooff, const u32* ostart, const u32* qoff_abs, const u32* roff, i64 D,
+                      const double* p2tab, int p2n, void* out, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_make_hits, dim3((n + 255) / 256), dim3(256), 0, st, rows, n, (long long)q_lo, qoff_abs, roff, (long long)D, p2tab, p2n,
-                       (DevHit*)out);
+    hipLaunchKernelGGL(k_make_hits, dim3((n + 255) / 256), dim3(256), 0, st, rows, n, (long long)q_lo, qid, ooff, ostart, qoff_abs, roff, (long long)D,
+                       p2tab, p2n, (DevHit*)out);
+}
+
+void launch_scatter_u32(const u32* src, const u32* idx, u32 n, u32* dst, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_scatter_u32, dim3((n + 255) / 256), dim3(256), 0, st, src, idx, n, dst);
 }
 
 // ---- alignment tasks of a launch ordered by their row count ------------------------------------------------
 // k_align runs four alignments per wave: a wave lasts as long as its longest one.  Key = 8191 - R (longest first), R = rows of the
-// band (see k_align); the launch list is then sorted on it.
+// band (see k_align); the launch list is then sorted on it.  Bit 13 of the key is clear for the tasks the packed 16-bit aligner cannot
+// take -- neither  11 * min(rows, columns)  nor the smaller of the two sequences' score bounds (k_seq_bound) fits its cells -- so
+// they sort in front of the others and the launch list splits into a k_align<false> part and a k_align_pk part; *n_wide counts them.
 __global__ __launch_bounds__(256) void k_task_rows(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 n,
-                                                   const u32* __restrict__ qoff, const u32* __restrict__ roff, u64* __restrict__ keys) {
+                                                   const u32* __restrict__ qoff, const u32* __restrict__ roff, const u32* __restrict__ qbound,
+                                                   const u32* __restrict__ rbound, int pk_len, u32 pk_score, u32* __restrict__ n_wide,
+                                                   unsigned long long* __restrict__ cells_wide, u64* __restrict__ keys) {
     const u32 t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n) return;
-    const AlnTask tk = tasks[ridx ? ridx[t] : t];
-    const int lq = min((int)(qoff[tk.q + 1] - qoff[tk.q]), (int)tk.qe), ls = min((int)(roff[tk.subj + 1] - roff[tk.subj]), (int)tk.se);
-    const int la = lq - min((int)tk.qi, lq), lb = ls - min((int)tk.qj, ls);
-    const int ncols = min(la, lb), nrows = max(la, lb);
-    keys[t] = (u64)(8191 - min(min(nrows, ncols + 16), 8191));
+    bool wide = false;
+    u32 wcells = 0;
+    if (t < n) {
+        const AlnTask tk = tasks[ridx ? ridx[t] : t];
+        const int lq = min((int)(qoff[tk.q + 1] - qoff[tk.q]), (int)tk.qe), ls = min((int)(roff[tk.subj + 1] - roff[tk.subj]), (int)tk.se);
+        const int la = lq - min((int)tk.qi, lq), lb = ls - min((int)tk.qj, ls);
+        const int ncols = min(la, lb), nrows = max(la, lb);
+        if (n_wide) wide = ncols > pk_len && min(qbound[tk.q], rbound[tk.subj]) > pk_score;
+        if (wide) {   // band cells of the task, as the aligners count them (lane l owns band offsets 2l and 2l + 1)
+            const int R = min(nrows, ncols + 16);
+            for (int l = 0; l < 16; ++l)
+                wcells += (u32)(max(0, min(R, ncols + 16 - 2 * l) - max(1, 17 - 2 * l) + 1) + max(0, min(R, ncols + 15 - 2 * l) - max(1, 16 - 2 * l) + 1));
+        }
+        keys[t] = (u64)(8191 - min(min(nrows, ncols + 16), 8191)) | (wide ? 0ull : 8192ull);
+    }
+    if (n_wide) {
+        const unsigned long long wb = __ballot(wide);
+        if (wb) {   // (wave-uniform)
+            for (int o = 32; o > 0; o >>= 1) wcells += (u32)__shfl_xor((int)wcells, o);
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(n_wide, (u32)__popcll(wb));
+                atomicAdd(cells_wide, (unsigned long long)wcells);
+            }
+        }
+    }
 }
 
-void launch_task_rows(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, u64* keys, hipStream_t st) {
+void launch_task_rows(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, const u32* qbound, const u32* rbound, int pk_len,
+                      u32 pk_score, u32* n_wide, unsigned long long* cells_wide, u64* keys, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_task_rows, dim3((n + 255) / 256), dim3(256), 0, st, tasks, ridx, n, qoff, roff, keys);
+    hipLaunchKernelGGL(k_task_rows, dim3((n + 255) / 256), dim3(256), 0, st, tasks, ridx, n, qoff, roff, qbound, rbound, pk_len, pk_score, n_wide, cells_wide,
+                       keys);
 }

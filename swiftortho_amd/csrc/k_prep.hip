@@ -84,6 +84,38 @@ __global__ __launch_bounds__(256) void k_scls(const u8* __restrict__ res, size_t
     }
 }
 
+// ---- upper bound of any local alignment score a sequence can take part in -------------------------------------
+// Every column of an alignment scores at most the row maximum of its residue's class (gaps and mismatches only lower the sum),
+// so  sum over the sequence of max(0, max_b b62[class][b])  bounds the score of every alignment the sequence is one side of.
+// The packed 16-bit aligner (k_align16.hip) takes a task when the smaller of its two sides' bounds fits its cells: protein
+// self-scores average ~5.5 per residue where the worst case (W against W) is 11, which doubles the lengths it can take.
+struct RowMax {
+    u8 v[32];
+};
+__global__ __launch_bounds__(256) void k_seq_bound(const u8* __restrict__ scls, const u32* __restrict__ off, u32 nseq, RowMax rm,
+                                                   u32* __restrict__ bound) {
+    const u32 s = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (s >= nseq) return;
+    const u32 a = off[s], e = off[s + 1];
+    u32 sum = 0;
+    for (u32 i = a + lane; i < e; i += 64) sum += rm.v[scls[i] & 31u];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += (u32)__shfl_xor((int)sum, o);
+    if (lane == 0) bound[s] = sum;
+}
+
+void launch_seq_bound(const u8* scls, const u32* off, u32 nseq, const signed char* b62c_host /*SCLS_N x SCLS_N*/, u32* bound, hipStream_t st) {
+    if (!nseq) return;
+    RowMax rm;
+    for (int a = 0; a < 32; ++a) {
+        int m = 0;
+        if (a < SCLS_N)
+            for (int b = 0; b < SCLS_N; ++b) m = std::max(m, (int)b62c_host[a * SCLS_N + b]);
+        rm.v[a] = (u8)m;
+    }
+    hipLaunchKernelGGL(k_seq_bound, dim3((nseq + 3) / 4), dim3(256), 0, st, scls, off, nseq, rm, bound);
+}
+
 // ---- SEG-like query masking (fsearch.py:2872-2928; entropy 2854-2868; Counter 157-177) ------------
 // The reference slides a 12-residue window and updates the entropy incrementally,  ent += t(leaving) ; ent +=
 // t(entering),  so its rounding depends on the order of those additions -- but each addend depends only on the
@@ -108,7 +140,7 @@ struct SegTab {
 // One wave per query, and the sequential parts run on one lane: throughput is the number of queries resident per CU, i.e. LDS per
 // block -- hence the small instance (CAP 1024, 128-step tiles: 6 KB) for the typical protein next to the 4096 / 512 one (17 KB).
 template <int CAP, int TILE>
-__global__ __launch_bounds__(64) void k_seg(const u8* __restrict__ raw, const u32* __restrict__ src_off, u32 q_lo, u32 nq,
+__global__ __launch_bounds__(64) void k_seg(const u8* __restrict__ raw, const u32* __restrict__ src_off, u32 q_lo, const u32* __restrict__ qid, u32 nq,
                                             const u32* __restrict__ dst_off, const u8* __restrict__ symmap /*256: upper-cased byte*/,
                                             const u8* __restrict__ upmap /*256*/, const SegTab* __restrict__ tab, u8* __restrict__ mk,
                                             u8* __restrict__ out, int min_len /*this instance serves lengths > min_len*/) {
@@ -121,13 +153,14 @@ __global__ __launch_bounds__(64) void k_seg(const u8* __restrict__ raw, const u3
     const int lane = threadIdx.x;
     const u32 q = blockIdx.x;
     if (q >= nq) return;
-    const int n = (int)(src_off[q_lo + q + 1] - src_off[q_lo + q]);
+    const u32 sq = q_lo + (qid ? qid[q] : q);   // the batch may hold its queries in another order than the file
+    const int n = (int)(src_off[sq + 1] - src_off[sq]);
     if (n <= 0) return;
     if ((STAGE && n > CAP) || n <= min_len) return;  // another instance serves this length
     for (int i = lane; i < 256; i += 64) s_sym[i] = symmap[i], s_up[i] = upmap[i];
     s_off[lane] = 0;
     __syncthreads();
-    const u8* Sg = raw + src_off[q_lo + q];
+    const u8* Sg = raw + src_off[sq];
     u8* o = out + dst_off[q];
     u8* mg = mk + dst_off[q];
     if (STAGE) {
@@ -243,18 +276,31 @@ __global__ __launch_bounds__(256) void k_copy_range(const u8* __restrict__ src, 
     if (i < n) dst[i] = src[i];
 }
 
-void launch_seg(const u8* raw, const u32* src_off, u32 q_lo, u32 nq, const u32* dst_off, const u8* symmap, const u8* upmap,
+void launch_seg(const u8* raw, const u32* src_off, u32 q_lo, const u32* qid, u32 nq, const u32* dst_off, const u8* symmap, const u8* upmap,
                 const void* tab, u8* mk, u8* out, u32 max_len, hipStream_t st) {
     if (!nq) return;
     // three instances over the same grid, each serving its length range: (0, 1024], (1024, 4096] staged in LDS, longer ones unstaged
-    hipLaunchKernelGGL((k_seg<SEG_STAGE_SMALL, 128>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk,
+    hipLaunchKernelGGL((k_seg<SEG_STAGE_SMALL, 128>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, qid, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk,
                        out, 0);
     if (max_len > SEG_STAGE_SMALL)
-        hipLaunchKernelGGL((k_seg<SEG_STAGE_MAX, 512>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, nq, dst_off, symmap, upmap, (const SegTab*)tab,
+        hipLaunchKernelGGL((k_seg<SEG_STAGE_MAX, 512>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, qid, nq, dst_off, symmap, upmap, (const SegTab*)tab,
                            mk, out, SEG_STAGE_SMALL);
     if (max_len > SEG_STAGE_MAX)
-        hipLaunchKernelGGL((k_seg<0, 512>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk, out,
+        hipLaunchKernelGGL((k_seg<0, 512>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, qid, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk, out,
                            SEG_STAGE_MAX);
+}
+
+// unmasked queries of a batch that holds them in another order than the file: a wave per sequence
+__global__ __launch_bounds__(256) void k_gather_seqs(const u8* __restrict__ raw, const u32* __restrict__ src_off, u32 q_lo, const u32* __restrict__ qid, u32 nq,
+                                                     const u32* __restrict__ dst_off, u8* __restrict__ out) {
+    const u32 q = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (q >= nq) return;
+    const u32 sq = q_lo + qid[q];
+    const u32 a = src_off[sq], n = src_off[sq + 1] - a, o = dst_off[q];
+    for (u32 i = lane; i < n; i += 64) out[o + i] = raw[a + i];
+}
+void launch_gather_seqs(const u8* raw, const u32* src_off, u32 q_lo, const u32* qid, u32 nq, const u32* dst_off, u8* out, hipStream_t st) {
+    if (nq) hipLaunchKernelGGL(k_gather_seqs, dim3((nq + 3) / 4), dim3(256), 0, st, raw, src_off, q_lo, qid, nq, dst_off, out);
 }
 
 void launch_copy_range(const u8* src, u8* dst, size_t n, hipStream_t st) {

@@ -296,12 +296,10 @@ struct Addend<u32> {
     static __device__ __forceinline__ u64 expand(u32 c, const KeyLayout& kl) {
         return kl.ba ? (((u64)(c >> kl.ba) << kl.sh_diag) + (u64)(c & ((1u << kl.ba) - 1u))) : ((u64)c << kl.sh_diag);
     }
-    static __device__ __forceinline__ bool offset0(u32 c, const KeyLayout& kl) {
-        const u32 m = ((1u << kl.bd) - 1u) << kl.ba;
-        return (c & m) == m;
-    }
-    static __device__ __forceinline__ u32 subj(u32 c, const KeyLayout& kl) { return c >> (kl.bd + kl.ba); }
-    static __device__ __forceinline__ u32 tag(u32 c, const KeyLayout& kl) { return c & ((1u << kl.ba) - 1u); }
+    // k_encode_band32 resolves offset-0 entries itself; the ones the reference drops are all-ones (real addends stay below 2^31)
+    static __device__ __forceinline__ bool offset0(u32 c, const KeyLayout&) { return (int)c < 0; }
+    static __device__ __forceinline__ u32 subj(u32, const KeyLayout&) { return 0u; }   // lookup_offset0_key(0, ...) = dropped
+    static __device__ __forceinline__ u32 tag(u32, const KeyLayout&) { return 0u; }
 };
 
 template <int LW_ITERS, int VAR /*0 = real; diagnostic ablations: 1 = no index read, 2 = no key write, 3 = plain (temporal) key stores*/, class ENT>

@@ -32,8 +32,12 @@ void launch_layout(const u8* res, const u32* off, u32 nseq, u32 P, u32 Ppad, con
 #define SCLS_PAD_FRONT 16
 #define SCLS_PAD_BACK 64
 void launch_scls(const u8* res, size_t n, const u8* smap, u8* scls, u8* scls4 /*nullable: class * 4*/, hipStream_t st);
-void launch_seg(const u8* raw, const u32* src_off, u32 q_lo, u32 nq, const u32* dst_off, const u8* symmap, const u8* upmap,
+// bound[s] = sum over sequence s of max(0, row maximum of its residues' score classes): no alignment the sequence takes part in scores more
+void launch_seq_bound(const u8* scls, const u32* off, u32 nseq, const signed char* b62c_host, u32* bound, hipStream_t st);
+// batch slot q holds sequence q_lo + (qid ? qid[q] : q) of the source set
+void launch_seg(const u8* raw, const u32* src_off, u32 q_lo, const u32* qid, u32 nq, const u32* dst_off, const u8* symmap, const u8* upmap,
                 const void* tab /*SegTab on the device*/, u8* mk, u8* out, u32 max_len, hipStream_t st);
+void launch_gather_seqs(const u8* raw, const u32* src_off, u32 q_lo, const u32* qid, u32 nq, const u32* dst_off, u8* out, hipStream_t st);
 void launch_copy_range(const u8* src, u8* dst, size_t n, hipStream_t st);
 
 // k_index.hip
@@ -48,7 +52,7 @@ void sort_pairs_u32_u64(void* temp, size_t temp_bytes, const u32* kin, u32* kout
 size_t sort_pairs_u32_u64_temp_bytes(size_t n, int bits);
 #define INDEX_STATS_BLOCKS 2048
 void launch_index_stats(const u32* counts, u32 NC, u64* stats_buf /*4 + 4 * INDEX_STATS_BLOCKS*/, hipStream_t st);
-void launch_encode_delta32(const u64* entries, u32 E, int ba, int bd, u32 maxslen, const u32* roff /*chunk-local*/, u32* dk32, hipStream_t st);
+void launch_encode_band32(const u64* entries, u32 E, int ba, const u32* gbase /*per chunk sequence*/, const u32* roff /*chunk-local*/, u32* dk32, hipStream_t st);
 void launch_encode_delta(const u64* entries, u32 E, int sh_subj, int sh_diag, u32 maxslen, u64* dkeys, hipStream_t st);
 void launch_index_fixlast(u64* entries, u32 lo, u32 E, hipStream_t st);
 
@@ -72,7 +76,9 @@ void launch_lookup(const u32* cs_hoff, const u32* cs_base, const u64* cs_kbase, 
 // k_group.hip
 void launch_group_list(const u32* flags, const u32* gidx, u32 H, u32* ghead, hipStream_t st);
 u32 ungap_shard_cap(u32 H);
-void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, bool ft_walk, const u8* q_scls, const u32* qoff,
+// klr: layout of the pass records (sequence bits / diagonal offset; == kl unless btab); btab: band -> (chunk sequence, gbase) when
+// some subject owns several diagonal bands (k_encode_band32), else null
+void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& klr, const void* btab, bool ft_walk, const u8* q_scls, const u32* qoff,
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt, u32 shard_cap, u64* p_qs, u64* p_sd,
                   u64* p_ft, unsigned long long* group_count, hipStream_t st);
 void launch_first_touch(bool walk, const u64* keys, u32 H, const KeyLayout& kl, int ft_bits_entry, int bsp, const u32* roff, u64* p_ft, u32 n,
@@ -101,7 +107,8 @@ void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q
                   AlnRes* out, bool with_traceback, hipStream_t st);
 
 // k_align16.hip: score-only aligner in packed 16-bit arithmetic, two alignments per register
-int align_pk_max_len();   // largest min(rows, columns) it can score
+int align_pk_max_len();   // largest min(rows, columns) it can score whatever the residues
+u32 align_pk_max_score(); // largest alignment score its cells hold
 void launch_align_pk(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
                      const u8* r_scls4, const u32* roff, const signed char* b62g, AlnRes* out, hipStream_t st);
 
@@ -124,8 +131,10 @@ void launch_selected_idx(const u32* toff, const u32* sel, const u32* nout, const
 void launch_emit_hits(const AlnTask* tasks, const AlnRes* res, const u32* toff, const u32* sel, const u32* nout, const u32* ooff,
                       const int* bits, u32 q0, u32 q1 /*queries [q0, q1) of the batch*/, int* out, hipStream_t st);
 // so_hit records on the device (80 bytes each) from k_emit_hits rows; qoff_abs = offsets of the whole loaded query set
-void launch_make_hits(const int* rows, u32 n, i64 q_lo, const u32* qoff_abs, const u32* roff, i64 D, const double* p2tab, int p2n, void* out,
-                      hipStream_t st);
+// qid / ooff / ostart (all null, or all set): batch slots in length-class order, records written in file order (k_make_hits)
+void launch_make_hits(const int* rows, u32 n, i64 q_lo, const u32* qid, const u32* ooff, const u32* ostart, const u32* qoff_abs, const u32* roff, i64 D,
+                      const double* p2tab, int p2n, void* out, hipStream_t st);
+void launch_scatter_u32(const u32* src, const u32* idx, u32 n, u32* dst, hipStream_t st);   // dst[idx[i]] = src[i]
 
 // k_bucket.hip: diagonal binning without a sort (query-aligned tiles, count -> scan -> scatter, LDS hash grouping)
 u32 bkt_tile_hits();
@@ -172,4 +181,6 @@ void launch_stop_round_w(const AlnTask* tasks, const AlnRes* res, const u32* qco
                          int bittab_n, i64 D, double expect, double max_miss, i64 v, u32* sel, u32* st_state, int* bits,
                          unsigned long long* qcells /*[nq], += cells of the round*/, hipStream_t st);
 void launch_sum_u64(const unsigned long long* x, u32 n, unsigned long long* total, hipStream_t st);
-void launch_task_rows(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, u64* keys, hipStream_t st);
+// keys[t] = 8191 - band rows of task t, | 8192 when the packed aligner can take it (n_wide != null: the others are counted there; null: all can)
+void launch_task_rows(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, const u32* qbound, const u32* rbound, int pk_len,
+                      u32 pk_score, u32* n_wide, unsigned long long* cells_wide /*+= their band cells*/, u64* keys, hipStream_t st);

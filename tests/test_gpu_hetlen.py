@@ -1,0 +1,122 @@
+"""GPU parity on LENGTH-HETEROGENEOUS protein sets (round 4): the packed 16-bit aligner is chosen per alignment task, the
+bucketed diagonal binning per seed pass of one query length class over diagonal BANDS (k_encode_band32) -- one sequence far above
+the fixed widths no longer switches a whole batch to the slow kernels.  Every case here holds sequences above 740 residues (packed
+aligner range), above 2048 (hit-word range of the pre-round-4 binning) and above 4096 (the aligner's tiled path) in ONE batch, is
+compared with the oracle row for row and candidate for candidate, and checks with the library's counters that both variants of
+both stages actually ran.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+from test_gpu_parity import fs, oracle_vs_gpu, gpu_rows  # noqa: F401  (fs is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+AA9 = "AST,CFILMVY,DN,EQ,G,H,KR,P,W"
+
+
+class _CachedOracle:
+    """the oracle's end-to-end run of one (input, flags) pair is shared by the path-switch variants of a test (40 s of CPU each)"""
+
+    def __init__(self, real):
+        self._real, self._cache = real, {}
+
+    def __getattr__(self, k):
+        return getattr(self._real, k)
+
+    def blastp(self, qry, ref, out_path, **kw):
+        import hashlib
+        key = (hashlib.md5(open(qry, "rb").read()).hexdigest(), tuple(sorted(kw.items())))
+        if key not in self._cache:
+            r = self._real.blastp(qry, ref, out_path, **kw)
+            self._cache[key] = (r, open(out_path, "rb").read())
+        r, text = self._cache[key]
+        open(out_path, "wb").write(text)
+        return r
+
+
+@pytest.fixture(scope="module")
+def coracle(oracle):
+    return _CachedOracle(oracle)
+
+
+def het_fasta(n, seed):
+    from swiftortho_amd import synthprot
+    return synthprot.synthprot(n, seed=seed, lengths="lognormal")
+
+
+def lengths_of(fa):
+    return np.array([len(x) for x in fa.split(b"\n")[1::2]])
+
+
+def test_generator_shape():
+    fa = het_fasta(3000, 11)
+    ln = lengths_of(fa)
+    assert len(ln) == 3000 and ln.max() > 29000 and 200 < np.median(ln) < 350
+    assert (ln > 740).sum() > 50 and (ln > 2048).sum() >= 3
+
+
+@pytest.mark.parametrize("env", [{}, {"SOHIT_BUCKET_MIN": "0"}, {"SOHIT_BANDS": "0"}, {"SOHIT_QCLASS": "0"}, {"SOHIT_ALIGN_PK": "0"},
+                                 {"SOHIT_BUCKET_MIN": "0", "SOHIT_BUCKET_BEST": "0"}, {"SOHIT_BUCKET_MIN": "0", "SOHIT_POISON": "0xFF"},
+                                 {"SOHIT_BATCH": "700", "SOHIT_BUCKET_MIN": "0", "SOHIT_MAX_HITS": "300000"}],
+                         ids=["default", "bucket_forced", "no_bands", "no_classes", "no_packed", "bucket_sortbest", "poison", "small_batches"])
+def test_mixed_lengths_vs_oracle(fs, coracle, tmp_path, monkeypatch, env):
+    """3000 proteins, median 277 residues, a tail to 5000 and one of 30 000: rows, candidate lists and counters equal the
+    oracle's, whatever the path switches say."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    fa = het_fasta(3000, 11)
+    kw = dict(ssd="111111", nr=AA9, ht=120000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    c, _ = oracle_vs_gpu(fs, coracle, fa, kw, tmp_path)
+    assert c["rows"] > 3000
+    if env.get("SOHIT_BUCKET_MIN") == "0" and "SOHIT_BANDS" not in env:
+        # queries below 2048 residues (two length classes) are binned by the bucketed passes, the longer ones by the sorted path
+        assert 0.5 * c["seed_hits"] < c["hits_bucketed"] < c["seed_hits"]
+    if "SOHIT_ALIGN_PK" not in env:
+        assert 0 < c["align_wide"] < 0.5 * c["alignments"] and 0 < c["cells_wide"] < c["cells"]
+
+
+def test_mixed_lengths_multi_chunk_two_seeds(fs, oracle, tmp_path, monkeypatch):
+    """several chunks (each with its own band numbering) and two seed patterns (no multi-band subjects: first-touch keys walk the hits)"""
+    monkeypatch.setenv("SOHIT_BUCKET_MIN", "0")
+    fa = het_fasta(1200, 5)
+    kw = dict(ssd="111111,1101011", nr=AA9, ht=1000003, chk=500, step=1, v=500, expect=1e-5, flt="T")
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+    kw = dict(ssd="111111", nr=AA9, ht=1000003, chk=500, step=1, v=500, expect=1e-5, flt="F")
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+
+
+def test_device_records_and_query_work_in_file_order(fs, monkeypatch):
+    """The batch holds its queries in length-class order; host rows, device-resident records and so_query_work come back in file order."""
+    monkeypatch.setenv("SOHIT_BUCKET_MIN", "0")
+    fa = het_fasta(1500, 23)
+    kw = dict(ssd="111111", nr=AA9, ht=120000000, chk=600, step=1, v=500, expect=1e-5, flt="T")
+    s = fs.Searcher(**kw)
+    s.load_ref_bytes(fa)
+    s.load_queries_bytes(fa)
+    for lo, hi in ((-1, -1), (100, 933)):
+        h = s.search(lo, hi)
+        g = h.array()
+        assert np.all(np.diff(g["qidx"]) >= 0) and len(g) > 500
+        host = h.raw_bytes()
+        h.close()
+        d = s.search_device(lo, hi)
+        assert d.tensor().cpu().numpy().tobytes() == host
+    w = s.query_work()
+    ln = lengths_of(fa)
+    assert len(w) == 1500 and np.corrcoef(w, ln)[0, 1] > 0.5   # work follows the query's length: file order kept
+    s.reset_counters()
+    s.search().close()
+    assert int(w.sum()) == s.counters()["seed_hits"]
+    # the same rows whether or not the queries are reordered inside the batch
+    a = s.search()
+    rows = b"".join(a.rows())
+    a.close()
+    s.close()
+    monkeypatch.setenv("SOHIT_QCLASS", "0")
+    s2, h2, rows2 = gpu_rows(fs, fa, fa, kw)
+    assert rows2 == rows
+    h2.close()
+    s2.close()
