@@ -737,10 +737,14 @@ struct Batch {
     DevBuf<AlnRes> ares;
     DevBuf<int> bits, outrec;
     DevBuf<u32> trace;
+    DevBuf<u32> tr_units, tr_ofs;   // trace room per task of a launch list and its exclusive scan (k_trace_units)
 };
 
-// length classes of the queries: < 1024 residues, < 2048, < 4096, longer (the aligner's tiled path)
-inline u8 query_class(u32 len) { return len < 1024 ? 0 : len < 2048 ? 1 : len < 4096 ? 2 : 3; }
+// length classes of the queries: < 512 residues, < 1024, < 2048, < 4096, longer (the aligner's tiled path).  A pass's key widths and
+// bucket ranges follow its longest query, and the seed hits a query brings to a bucket grow with its length: inside a class
+// they differ by a factor of two (eight in the first), so the grouping kernel's buckets stay near their target size.
+#define QCLASSES 5
+inline u8 query_class(u32 len) { return len < 512 ? 0 : len < 1024 ? 1 : len < 2048 ? 2 : len < 4096 ? 3 : 4; }
 
 void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
     b.q_lo = q_lo, b.q_hi = q_hi, b.nq = (u32)(q_hi - q_lo);
@@ -750,9 +754,9 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
     b.qid.resize(b.nq), b.qcls.resize(b.nq);
     {
         const bool classes_on = !(getenv("SOHIT_QCLASS") && atoi(getenv("SOHIT_QCLASS")) == 0);   // SOHIT_QCLASS=0: file order
-        u32 cnt[4] = {0, 0, 0, 0};
+        u32 cnt[QCLASSES] = {0}, at[QCLASSES] = {0};
         for (u32 i = 0; i < b.nq; ++i) cnt[classes_on ? query_class(Q.len(q_lo + i)) : 0]++;
-        u32 at[4] = {0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2]};
+        for (int k = 1; k < QCLASSES; ++k) at[k] = at[k - 1] + cnt[k - 1];
         b.permuted = false;
         for (u32 i = 0; i < b.nq; ++i) {
             const u8 k = classes_on ? query_class(Q.len(q_lo + i)) : 0;
@@ -803,9 +807,18 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
     b.qbucket.ensure(T);
     launch_qhash(b.dev.d_words.p, Ppad, c->cfg, b.dev.lut, b.qbucket.p, c->st);
     const size_t nres = b.h_off[b.nq];
-    b.ksc.ensure(nres + 1);
     b.korder.ensure(nres + 1);
-    launch_ksc_order(b.dev.d_scls.p, b.dev.d_off.p, b.nq, c->cfg.mink, c->d_b62c.p, b.ksc.p, b.korder.p, c->st);
+    {
+        // queries with more windows than the LDS sort holds use global scratch; in a class-ordered batch they are the tail
+        u32 q_long = b.nq;
+        for (u32 i = 0; i < b.nq; ++i)
+            if ((i64)(b.h_off[i + 1] - b.h_off[i]) - c->cfg.mink + 1 > (i64)ksc_lds_max()) {
+                q_long = i;
+                break;
+            }
+        if (q_long < b.nq) b.gx.ensure(nres + 4), b.gL.ensure(nres + 4), b.gR.ensure(nres + 4);
+        launch_ksc_order(b.dev.d_scls.p, b.dev.d_off.p, b.nq, q_long, c->cfg.mink, c->d_b62c.p, b.gx.p, b.gL.p, b.gR.p, b.korder.p, c->st);
+    }
     b.sbeg.ensure(T), b.scnt.ensure(T), b.eff.ensure(T + 4), b.nz.ensure(T + 4), b.hoff.ensure(T + 4), b.cidx.ensure(T + 4);
     b.pcnt.ensure(Ppad), b.mark.ensure(Ppad);
     b.counters.ensure(8);
@@ -1069,6 +1082,8 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         klr.finish();
         btab = enc->btab.p;
     }
+    // k_ungap's GALLOP variant from this query length on (SOHIT_UG_GALLOP: tuning switch)
+    static const u32 gallop_min = getenv("SOHIT_UG_GALLOP") ? (u32)atoi(getenv("SOHIT_UG_GALLOP")) : 1024u;
     const int bsp = ceil_log2((u64)ch.maxslen + 1);
     const int ft_bits_entry = (klr.bs + 1) + klr.ba + bsp;
     const bool ft_walk = AS > 1;  // several (alphabet, pattern) combinations: a group's first-touch key needs all its hits
@@ -1183,7 +1198,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         // ... and a chained ungapped score fits the 20 bits k_bkt_best packs above them (at most 11 per residue of the shorter sequence)
         bbest = !(getenv("SOHIT_BUCKET_BEST") && atoi(getenv("SOHIT_BUCKET_BEST")) == 0) && !ft_walk && (kl.ba + kl.bp + ft_bits_entry <= 44) &&
                 (u64)std::min<u32>(pmaxq, ch.maxslen) * 11ull < (1ull << 20);
-        launch_ungap(b.keys2.p, Hv, kl, klr, btab, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.shard.p,
+        launch_ungap(b.keys2.p, Hv, kl, klr, btab, pmaxq >= gallop_min, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.shard.p,
                      shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
         // the pass records are binned by (query, range of 2^wb chunk SEQUENCES): the same layout unless bands and sequences differ
         bL = L;
@@ -1225,7 +1240,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     }
     sc.lap("group.sort_keys");
     // group walk + chained ungapped extension (the kernel finds the group heads itself)
-    launch_ungap(b.keys2.p, H, kl, klr, btab, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo,
+    launch_ungap(b.keys2.p, H, kl, klr, btab, pmaxq >= gallop_min, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo,
                  c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
     };
 
@@ -1611,8 +1626,19 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     // banded alignments in rounds (see k_round_counts / k_stop_round_w)
     const int maxrows = (int)std::min<u32>(std::max(maxwin_q, maxwin_s), std::min(maxwin_q, maxwin_s) + 16);
     const u32 stride = align_trace_stride(maxrows + 1);
-    const size_t budget_words = (size_t)1 << 30;  // 4 GiB of trace scratch
+    const size_t budget_words = (size_t)1 << 30;  // 4 GiB of trace scratch for the fixed-stride slabs
     const u32 slab = (u32)std::max<size_t>(16, std::min<size_t>(std::max<u32>(NT, 1), budget_words / std::max<u32>(stride, 1)));
+    // Traces take what each task's own band needs: room per task (k_trace_units), scanned into b.tr_ofs; up to 8 GiB per launch list,
+    // beyond that the list falls back to slabs of the batch-wide stride.  (`stride` follows the longest window of the batch: one
+    // 4096-residue pair and every 300-row alignment owned 33 KB of trace, which its traceback then strode over.)
+    const size_t var_budget_words = (size_t)1 << 31;
+    const u32 TU = align_trace_unit();
+    auto trace_offsets = [&](const u32* list, u32 n) -> size_t {   // -> words the list's traces need
+        b.tr_units.ensure((size_t)n + 4), b.tr_ofs.ensure((size_t)n + 4);
+        c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)n + 1) + 8);
+        launch_trace_units(b.tasks.p, list, n, b.dev.d_off.p, c->ref.d_off.p, b.tr_units.p, c->st);
+        return (size_t)d2h_u32(c, scan_u32(b.tr_units.p, b.tr_ofs.p, (size_t)n + 1, false, c->d_scan_tmp.p, c->st)) * TU;
+    };
     b.st_state.ensure(5 * (size_t)nq + 8), b.rcnt.ensure((size_t)nq + 4), b.tcnt.ensure((size_t)nq + 4), b.roff.ensure((size_t)nq + 4);
     b.order_tmp.ensure((size_t)nq + 4);
     b.ridx.ensure((size_t)NT + 4);
@@ -1628,7 +1654,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     const char* spec_env = getenv("SOHIT_SPEC");
     const bool spec_on = spec_env ? atoi(spec_env) != 0 : NT >= (1u << 21);
     const double spec_slack = getenv("SOHIT_SPEC_SLACK") ? atof(getenv("SOHIT_SPEC_SLACK")) : 1e3;
-    u32 spec_cap = (u32)std::min<size_t>(NT, ((size_t)1 << 31) / std::max<u32>(stride, 1));   // 8 GiB of kept traces at most
+    u32 spec_cap = NT;   // (8 GiB of kept traces at most: checked on the list's actual trace sizes below)
     if (getenv("SOHIT_SPEC_CAP")) spec_cap = (u32)std::max(0, atoi(getenv("SOHIT_SPEC_CAP")));   // (tests: the round that does not fit)
     u32 nspec = 0;
     if (spec_on) {
@@ -1671,12 +1697,18 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                                   b.ridx.p, b.sidx.p, c->st);
             if (NS) {
                 const u32* slist = sort_by_rows(b.sidx.p, NS, nullptr);
-                b.spec_trace.ensure((size_t)NS * stride + 64);
+                const size_t tw = trace_offsets(slist, NS);
                 ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
-                launch_align_traced(b.tasks.p, slist, NS, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_scls4.p,
-                                    c->ref.d_off.p, c->d_b62c.p, b.spec_trace.p, stride, b.ares.p, b.tpos.p, 0u, c->st);
+                if (tw <= var_budget_words) {
+                    b.spec_trace.ensure(tw + 64);
+                    launch_align_traced(b.tasks.p, slist, NS, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_scls4.p,
+                                        c->ref.d_off.p, c->d_b62c.p, b.spec_trace.p, TU, b.tr_ofs.p, b.ares.p, b.tpos.p, 0u, c->st);
+                    nspec = NS;
+                } else {   // the traces would not fit after all: these tasks score-only, like the rest of the round
+                    launch_align(b.tasks.p, slist, NS, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
+                                 c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, nullptr, b.ares.p, false, c->st);
+                }
                 pt.stop();
-                nspec = NS;
             }
         } else if (NR) {
             launch_round_idx(b.tcnt.p, b.roff.p, b.toff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.st_state.p, nq, b.ridx.p, c->st);
@@ -1690,7 +1722,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             // n_wide tasks at the head of the list that do not
             if (n_wide)
                 launch_align(b.tasks.p, rlist, n_wide, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
-                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, b.ares.p, false, c->st);
+                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, nullptr, b.ares.p, false, c->st);
             if (NR > n_wide)
                 launch_align_pk(b.tasks.p, rlist + n_wide, NR - n_wide, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_scls4.p,
                                 c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->st);
@@ -1743,7 +1775,6 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             maxpart = 0;
             for (int p = 0; p < parts; ++p) maxpart = std::max(maxpart, part_row[p + 1] - part_row[p]);
         }
-        b.trace.ensure((size_t)std::min(slab, std::max<u32>(maxpart, 1)) * stride + 64);
         b.outrec.ensure(12 * (size_t)NO + 16);
         if (c->rows_in_flight) {  // the previous batch's rows may still be on their way out of b.outrec
             HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_rows_done, 0));
@@ -1779,27 +1810,39 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             for (int p = 1; p < parts; ++p) pb[p] = part_row[p] < NO ? v[p] : pb[parts];
             if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] kept traces %u, reported rows %u, of them without a trace %u\n", nspec, NO, pb[parts]);
         }
+        // the list aligned with traces now: the rows without a kept trace (nspec), or all rows; its traces take their own sizes
+        // (b.tr_ofs) when the whole list fits the budget, else slabs of the batch-wide stride
+        const u32* tlist = nspec ? b.sel_b.p : slist;
+        const u32 tn = nspec ? pb[parts] : NO;
+        const size_t tw = tn ? trace_offsets(tlist, tn) : 0;
+        const bool tvar = tw <= var_budget_words;
+        b.trace.ensure(tvar ? tw + 64 : (size_t)std::min(slab, std::max<u32>(maxpart, 1)) * stride + 64);
+        auto align_traced = [&](u32 t0, u32 t1) {   // tasks [t0, t1) of tlist
+            if (t1 <= t0) return;
+            if (tvar) {
+                launch_align(b.tasks.p, tlist + t0, t1 - t0, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
+                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, TU, b.tr_ofs.p + t0, b.ares.p, true, c->st);
+                return;
+            }
+            for (u32 t = t0; t < t1; t += slab) {
+                const u32 n = std::min(slab, t1 - t);
+                launch_align(b.tasks.p, tlist + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
+                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, nullptr, b.ares.p, true, c->st);
+            }
+        };
         for (int p = 0; p < parts; ++p) {
             const u32 r0 = parts > 1 ? part_row[p] : 0u, r1 = parts > 1 ? part_row[p + 1] : NO;
             const u32 qa = parts > 1 ? std::min<u32>(nq, (u32)p * qstep) : 0u, qb = parts > 1 ? std::min<u32>(nq, (u32)(p + 1) * qstep) : nq;
             if (r1 > r0 && nspec) {
                 const u32 b0 = pb[p], b1 = pb[p + 1], a0 = r0 - b0, a1 = r1 - b1;
                 ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
-                for (u32 t = b0; t < b1; t += slab) {
-                    const u32 n = std::min(slab, b1 - t);
-                    launch_align(b.tasks.p, b.sel_b.p + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p,
-                                 c->ref.d_scls.p, c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, b.ares.p, true, c->st);
-                }
-                launch_traceback(b.tasks.p, b.sel_a.p + a0, a1 - a0, b.dev.d_res.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_off.p, b.spec_trace.p, stride,
+                align_traced(b0, b1);
+                launch_traceback(b.tasks.p, b.sel_a.p + a0, a1 - a0, b.dev.d_res.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_off.p, b.spec_trace.p, TU,
                                  b.tpos.p, b.ares.p, c->st);
                 pt.stop();
             } else if (r1 > r0) {
                 ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
-                for (u32 t = r0; t < r1; t += slab) {
-                    const u32 n = std::min(slab, r1 - t);
-                    launch_align(b.tasks.p, slist + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p,
-                                 c->ref.d_scls.p, c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, b.ares.p, true, c->st);
-                }
+                align_traced(r0, r1);
                 pt.stop();
             }
             launch_emit_hits(b.tasks.p, b.ares.p, b.toff.p, b.sel.p, b.nout.p, b.ooff.p, b.bits.p, qa, qb, b.outrec.p, c->st);

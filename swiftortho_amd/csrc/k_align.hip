@@ -109,6 +109,8 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
                                                const u8* __restrict__ q_scls, const u8* __restrict__ q_scls4, const u32* __restrict__ qoff,
                                                const u8* __restrict__ r_scls, const u8* __restrict__ r_scls4, const u32* __restrict__ roff,
                                                const signed char* __restrict__ b62g, u32* __restrict__ trace, u32 trace_stride,
+                                               const u32* __restrict__ tofs /*TRACE: where launch position tid's trace starts, in units of trace_stride words
+                                                                              (k_trace_units + scan: every task takes what ITS band needs); null: tid*/,
                                                AlnRes* __restrict__ out, u32* __restrict__ tpos_out, u32 tpos_base) {
     __shared__ signed char s_b62[AL_TAB];
     for (int i = threadIdx.x; i < SCLS_N * 64; i += 256) {
@@ -130,7 +132,8 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     const u8* ccls = swp ? (r_scls4 + sb + qj) : (q_scls4 + qb + qi);  // column classes * 4
     const u8* rcls = swp ? (q_scls + qb + qi) : (r_scls + sb + qj);
     const int R = min(nrows, ncols + KB);  // rows beyond ncols + 16 have an empty band
-    u32* tr = trace + (size_t)tid * trace_stride;
+    const u32 tunit = (TRACE && tofs) ? tofs[tid] : tid;
+    u32* tr = trace + (size_t)tunit * trace_stride;
 
     // Iteration m: every lane handles ONE row i = m - l and its two band cells
     //   even cell: d = 2l   (column j0 = m + l - 16)        odd cell: d = 2l + 1   (column j0 + 1)
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
     r.maxscore = best, r.aln = 0, r.matches = 0, r.gap = 0, r.cells = ncell, r.pad = 0;
     r.qst = bi, r.qed = bj, r.sst = 0, r.sed = 0;  // (i_max, j_max) parked for k_traceback
     out[slot] = r;
-    if (TRACE && tpos_out) tpos_out[slot] = tpos_base + tid;   // where this task's trace lives (speculative traces)
+    if (TRACE && tpos_out) tpos_out[slot] = tpos_base + tunit;   // where this task's trace lives (speculative traces)
 }
 
 // Traceback from the best cell until a stop cell (1418-1443), walking through row 0 ('-'), column 0
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ ta
                                                   const u8* __restrict__ q_res, const u32* __restrict__ qoff,
                                                   const u8* __restrict__ r_res, const u32* __restrict__ roff,
                                                   const u32* __restrict__ trace, u32 trace_stride, const u32* __restrict__ tpos,
-                                                  AlnRes* __restrict__ out) {
+                                                  const u32* __restrict__ tofs, AlnRes* __restrict__ out) {
     const u32 tid = blockIdx.x * 64u + threadIdx.x;
     if (tid >= ntasks) return;
     const u32 slot = ridx ? ridx[tid] : tid;
@@ -266,7 +269,8 @@ __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ ta
     const bool swp = !(la < lb);
     const u8* craw = swp ? (r_res + sb + qj) : (q_res + qb + qi);
     const u8* rraw = swp ? (q_res + qb + qi) : (r_res + sb + qj);
-    const u32* tr = trace + (size_t)(tpos ? tpos[slot] : tid) * trace_stride;   // tpos: traces kept per task (speculative), else per launch position
+    // tpos: traces kept per task (speculative); tofs: per launch position, variable size; else one stride per launch position
+    const u32* tr = trace + (size_t)(tpos ? tpos[slot] : tofs ? tofs[tid] : tid) * trace_stride;
     const int bi = r.qst, bj = r.qed;
     // The reference derives its statistics from the two aligned STRINGS, gap columns spelled '-' (1454-1471): identity
     // compares characters, and the gap counter is a three-state machine over them (op = -1 / 0 / 1; a '-' in string 0 opens
@@ -371,33 +375,57 @@ u32 align_trace_stride(int max_cols_plus) {
     return (w + 31u) & ~31u;
 }
 
+// Trace words of one task: what a band of R rows writes (align_trace_stride(R + 1)), in units of TRACE_UNIT words.  A launch whose
+// tasks get their trace room from the exclusive scan of these (tofs) needs sum(units) instead of tasks x the longest band's stride:
+// with one 4096-row window in the batch every 300-row alignment used to own -- and its traceback to stride over -- 33 KB.
+#define TRACE_UNIT 32
+__global__ __launch_bounds__(256) void k_trace_units(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 n, const u32* __restrict__ qoff,
+                                                     const u32* __restrict__ roff, u32* __restrict__ units) {
+    const u32 t = blockIdx.x * 256u + threadIdx.x;
+    if (t > n) return;
+    if (t == n) {
+        units[t] = 0;
+        return;
+    }
+    const AlnTask tk = tasks[ridx ? ridx[t] : t];
+    const int lq = min((int)(qoff[tk.q + 1] - qoff[tk.q]), (int)tk.qe), ls = min((int)(roff[tk.subj + 1] - roff[tk.subj]), (int)tk.se);
+    const int la = lq - min((int)tk.qi, lq), lb = ls - min((int)tk.qj, ls);
+    const int R = min(max(la, lb), min(la, lb) + KB);
+    const u32 w = (u32)((R + 1 + 15) / 8 + 1) * 16u;
+    units[t] = ((w + 31u) & ~31u) / TRACE_UNIT;
+}
+u32 align_trace_unit() { return TRACE_UNIT; }
+void launch_trace_units(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, u32* units /*n + 1*/, hipStream_t st) {
+    hipLaunchKernelGGL(k_trace_units, dim3((n + 1 + 255) / 256), dim3(256), 0, st, tasks, ridx, n, qoff, roff, units);
+}
+
 // with_traceback = false: scores only (trace may be null); true: traces + traceback statistics
 void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u8* q_scls4, const u32* qoff,
                   const u8* r_res, const u8* r_scls, const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride,
-                  AlnRes* out, bool with_traceback, hipStream_t st) {
+                  const u32* tofs, AlnRes* out, bool with_traceback, hipStream_t st) {
     if (!ntasks) return;
     if (!with_traceback) {
         hipLaunchKernelGGL((k_align<false>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4,
-                           roff, b62g, trace, trace_stride, out, (u32*)nullptr, 0u);
+                           roff, b62g, trace, trace_stride, (const u32*)nullptr, out, (u32*)nullptr, 0u);
         return;
     }
     hipLaunchKernelGGL((k_align<true>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff,
-                       b62g, trace, trace_stride, out, (u32*)nullptr, 0u);
+                       b62g, trace, trace_stride, tofs, out, (u32*)nullptr, 0u);
     hipLaunchKernelGGL(k_traceback, dim3((ntasks + 63) / 64), dim3(64), 0, st, tasks, ridx, ntasks, q_res, qoff, r_res, roff, trace,
-                       trace_stride, (const u32*)nullptr, out);
+                       trace_stride, (const u32*)nullptr, tofs, out);
 }
 
 void launch_align_traced(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
-                         const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, AlnRes* out, u32* tpos_out,
-                         u32 tpos_base, hipStream_t st) {
+                         const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out,
+                         u32* tpos_out, u32 tpos_base, hipStream_t st) {
     if (!ntasks) return;
     hipLaunchKernelGGL((k_align<true>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff,
-                       b62g, trace, trace_stride, out, tpos_out, tpos_base);
+                       b62g, trace, trace_stride, tofs, out, tpos_out, tpos_base);
 }
 
 void launch_traceback(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u32* qoff, const u8* r_res, const u32* roff,
                       const u32* trace, u32 trace_stride, const u32* tpos, AlnRes* out, hipStream_t st) {
     if (!ntasks) return;
     hipLaunchKernelGGL(k_traceback, dim3((ntasks + 63) / 64), dim3(64), 0, st, tasks, ridx, ntasks, q_res, qoff, r_res, roff, trace, trace_stride, tpos,
-                       out);
+                       (const u32*)nullptr, out);
 }

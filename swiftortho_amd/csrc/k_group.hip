@@ -50,9 +50,13 @@ enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN =
 // BANDS (compact index addends where some subject owns several diagonal bands, k_encode_band32): the key's subject field is a band id
 // and btab[band] = (chunk sequence, gbase) resolves it -- sst - qpos = gbase - (band << bd | diagonal); the pass records then carry
 // the sequence id and a head key rebuilt in the record layout klr (sequence bits, diagonal + klr.diag_off).  Without BANDS klr == kl.
-template <int CPI /*chunks per loop iteration*/, bool BANDS>
-__global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restrict__ keys, u32 H, KeyLayout kl, KeyLayout klr, const uint2* __restrict__ btab,
-                                                         int ft_walk, u32 wait_n,
+// GALLOP (passes of queries of 4096 residues and more): runs of seeds that start inside the previous segment are skipped with a
+// doubling / halving search instead of one bookkeeping visit each.  The self hit of a 30 000-residue protein is a group of 30 000
+// such seeds (45 ms per chunk for that one lane); for ordinary lengths the extra code in the bookkeeping path costs more than the
+// visits it saves (measured on the 100k weight-6 set: 640 -> 699 ms with it always on), hence a template switch.
+template <int CPI /*chunks per loop iteration*/, bool BANDS, bool GALLOP>
+__global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restrict__ keys, u32 H, KeyLayout kl, int rbs, int rsh_subj, int rsh_diag, int rdoff /*klr's fields (BANDS)*/,
+                                                         const uint2* __restrict__ btab, int ft_walk, u32 wait_n,
                                                          const u8* __restrict__ q_scls, const u32* __restrict__ qoff,
                                                          const u8* __restrict__ r_scls,
                                                          const u32* __restrict__ roff /*chunk-local offsets (absolute values)*/,
@@ -213,6 +217,33 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                     const int qpos = (int)((k >> kl.sh_qpos) & pmask);
                     if (qpos == prev_qpos) {
                         ++h;  // duplicate (qst, sst) pair: dropped by lis()
+                    } else if (GALLOP && prev_qpos >= 0 && qpos <= lo) {
+                        // A later seed that starts inside the previous segment: off = lo - qpos moves its start to lo, both passes get
+                        // zero steps (2460-2476: `qlo < qst` fails) and it adds nothing -- lo, the score and the group's ends stay as
+                        // they are.  Such seeds come in runs (a homolog's diagonal is covered by its first extension; the self hit of a
+                        // 30 000-residue protein is 30 000 of them): gallop to the first hit of the group that is not covered.
+                        ++h;
+                        // (one loop for both phases of the search: first doubling steps while the probed hit is covered, then halving
+                        // them inside [h, h + step - 1], whose last hit is not)
+                        u32 step = 1;
+                        bool grow = true;
+                        for (;;) {
+                            if (!grow) {
+                                if (step <= 1u) break;
+                                step >>= 1;
+                            }
+                            const u32 t = h + step - 1u;
+                            bool cv = false;
+                            if (t < H) {
+                                const u64 kk = keys[t] & kmask;
+                                cv = (kk >> kl.sh_diag) == gpre && (int)((kk >> kl.sh_qpos) & pmask) <= lo;
+                            }
+                            if (cv) h += step;
+                            if (grow) {
+                                if (cv) step <<= 1;
+                                else grow = false;
+                            }
+                        }
                     } else {
                         prev_qpos = qpos;
                         // Fasta.ungap set-up (2455-2464): first seed unbounded, later ones bounded by the previous segment's end;
@@ -319,11 +350,11 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                 if (pass) {
                     const int dist = dlt;  // guess_start (2544-2553): floor(2 * (sst - qst) / 2) = the diagonal
                     const u32 i = npb + (u32)__popcll(pb & lt);
-                    s_pqs[i] = ((u64)gq << (BANDS ? klr.bs : kl.bs)) | gsubj;
+                    s_pqs[i] = ((u64)gq << (BANDS ? rbs : kl.bs)) | gsubj;
                     s_psd[i] = ((u64)(u32)scores << 32) | (u64)(u32)dist;
                     // k_first_touch / k_rec_scatter turn this into the first-touch key
                     u64 hk = hkey;
-                    if (BANDS) hk = ((u64)gsubj << klr.sh_subj) | ((u64)(klr.diag_off - (i64)dlt) << klr.sh_diag) | (((hkey >> kl.sh_qpos) & pmask) << klr.sh_qpos);
+                    if (BANDS) hk = ((u64)gsubj << rsh_subj) | ((u64)(u32)(rdoff - dlt) << rsh_diag) | (((hkey >> kl.sh_qpos) & pmask) << kl.sh_qpos);
                     s_pft[i] = ft_walk ? (u64)h0 : hk;
                 }
                 npb += np;
@@ -605,16 +636,17 @@ u32 ungap_shard_cap(u32 H) {
     return ((nblk + UG_SHARDS - 1) / UG_SHARDS) * (UW_RANGE * UW_WAVES);
 }
 
-void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& klr, const void* btab, bool ft_walk, const u8* q_scls, const u32* qoff,
+void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& klr, const void* btab, bool gallop, bool ft_walk, const u8* q_scls, const u32* qoff,
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt, u32 shard_cap, u64* p_qs, u64* p_sd,
                   u64* p_ft, unsigned long long* group_count, hipStream_t st) {
     if (!H) return;
     // SOHIT_UG_CPI / SOHIT_UG_WAIT: tuning switches (results do not depend on them)
     const int cpi = getenv("SOHIT_UG_CPI") ? atoi(getenv("SOHIT_UG_CPI")) : UW_CPI;
     const u32 wait_n = getenv("SOHIT_UG_WAIT") ? (u32)atoi(getenv("SOHIT_UG_WAIT")) : UW_WAIT;
-    auto kern = btab ? (cpi == 1 ? k_ungap<1, true> : cpi == 2 ? k_ungap<2, true> : k_ungap<3, true>)
-                     : (cpi == 1 ? k_ungap<1, false> : cpi == 2 ? k_ungap<2, false> : k_ungap<3, false>);
-    hipLaunchKernelGGL(kern, dim3(ungap_num_blocks(H)), dim3(64 * UW_WAVES), 0, st, keys, H, kl, klr, (const uint2*)btab, ft_walk ? 1 : 0, wait_n, q_scls, qoff,
+    auto kern = gallop ? (btab ? k_ungap<3, true, true> : k_ungap<3, false, true>)
+                : btab ? (cpi == 1 ? k_ungap<1, true, false> : cpi == 2 ? k_ungap<2, true, false> : k_ungap<3, true, false>)
+                       : (cpi == 1 ? k_ungap<1, false, false> : cpi == 2 ? k_ungap<2, false, false> : k_ungap<3, false, false>);
+    hipLaunchKernelGGL(kern, dim3(ungap_num_blocks(H)), dim3(64 * UW_WAVES), 0, st, keys, H, kl, klr.bs, klr.sh_subj, klr.sh_diag, (int)klr.diag_off, (const uint2*)btab, ft_walk ? 1 : 0, wait_n, q_scls, qoff,
                        r_scls, roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count);
 }
 

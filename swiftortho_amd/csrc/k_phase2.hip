@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void k_csort(const u32* __restrict__ rec, const
         x[i] = ((u64)(SCORE_CAP - sc) << 32) | (u32)i;
     }
     __syncthreads();
-    wave_ref_qsort(x, n, [](u64 v) { return (int)(v >> 32); }, (int)vmax, gL + c0, gR + c0, s_leaf);
+    wave_ref_qsort<WQS_LEAF, 16>(x, n, [](u64 v) { return (int)(v >> 32); }, (int)vmax, gL + c0, gR + c0, s_leaf);
     const u32 m = (u32)n < vmax ? (u32)n : vmax;
     const u32 lq = qoff[q + 1] - qoff[q];
     u32 tiles = 0;

@@ -254,17 +254,27 @@ __global__ __launch_bounds__(64) void k_seg(const u8* __restrict__ raw, const u3
         }
         __syncthreads();
     }
-    if (lane != 0) return;
+    // ---- the output walk (2918-2928): an unmasked position copies its residue and moves on by one, a masked one emits twelve 'x'
+    // and moves on by twelve; output and input positions advance together, so out[p] belongs to input position p.  All lanes: 64
+    // positions per step, the run of unmasked ones in front of the first masked one is copied at once.  (One lane walking a
+    // 30 000-residue query through global memory took 8 ms.)
+    if (!STAGE) {   // the mask was written to global memory by lane 0: make it visible to the other lanes' loads
+        __threadfence();
+        __syncthreads();
+    }
     const int Nws = n - 12 > 0 ? n - 12 : 0;
     const int tail = m[Nws];  // if mask[Nws]: mask[Nws:] = 1 ; positions past n - 12 are otherwise 0
-    int st = 0, oo = 0;
+    int st = 0;   // wave-uniform
     while (st < n) {
-        const int mv = st <= Nws ? (int)m[st] : tail;
-        if (mv == 0) {
-            o[oo++] = s_up[S[st]];
-            st += 1;
-        } else {
-            for (int k = 0; k < 12 && oo < n; ++k) o[oo++] = 'x';
+        const int p = st + lane;
+        int mv = 0;
+        if (p < n) mv = p <= Nws ? (int)m[p] : tail;
+        const unsigned long long mb = __ballot(p < n && mv != 0);
+        const int run = mb ? (int)__builtin_ctzll(mb) : min(64, n - st);   // unmasked positions in front
+        if (lane < run) o[p] = s_up[S[p]];
+        st += run;
+        if (mb) {
+            if (lane < 12 && st + lane < n) o[st + lane] = 'x';
             st += 12;
         }
     }

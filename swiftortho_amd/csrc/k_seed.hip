@@ -112,31 +112,32 @@ __global__ __launch_bounds__(64) void k_ksc_order_lds(const u8* __restrict__ q_s
     for (int i = threadIdx.x; i < nk; i += 64) korder[base + i] = s_x[i] & 0xFFFu;
 }
 
-__global__ __launch_bounds__(64) void k_ksc_order(const u8* __restrict__ q_scls, const u32* __restrict__ qoff, u32 nq, int mink,
-                                                  const signed char* __restrict__ b62c /*24x24*/, int* __restrict__ ksc,
-                                                  u32* __restrict__ korder) {
+// Queries with more than LDS_SORT_MAX windows (proteins above ~4100 residues): the same wave-parallel replay on 64-bit words
+// ((KSC_BIAS - ksc) << 32 | position) and 32-bit misfit lists in global scratch (slices at the query's residue offset).  Until
+// round 4 one THREAD sorted such a query: a 30 000-residue protein took 370 ms, seven times the whole config-3 search.
+__global__ __launch_bounds__(64) void k_ksc_order_g(const u8* __restrict__ q_scls, const u32* __restrict__ qoff, u32 q0, u32 nq, int mink,
+                                                    const signed char* __restrict__ b62c /*24x24*/, u64* __restrict__ gx, u32* __restrict__ gL,
+                                                    u32* __restrict__ gR, u32* __restrict__ korder) {
     __shared__ signed char s_self[SCLS_N];
+    __shared__ int s_leaf[2 * WQS_LEAF];
     if (threadIdx.x < SCLS_N) s_self[threadIdx.x] = b62c[threadIdx.x * SCLS_N + threadIdx.x];
     __syncthreads();
-    const u32 q = blockIdx.x * 64u + threadIdx.x;
+    const u32 q = q0 + blockIdx.x;
     if (q >= nq) return;
     const u32 base = qoff[q];
     const int ql = (int)(qoff[q + 1] - base);
     const int nk = ql - mink + 1;
     if (nk <= LDS_SORT_MAX) return;  // done by k_ksc_order_lds (or nothing to do)
     const u8* c = q_scls + base;
-    int* k = ksc + base;
-    u32* x = korder + base;
-    int sc = 0;
-    for (int i = 0; i < mink; ++i) sc += s_self[c[i]];
-    k[0] = sc;
-    x[0] = 0;
-    for (int i = 1; i < nk; ++i) {
-        sc = sc - s_self[c[i - 1]] + s_self[c[i - 1 + mink]];
-        k[i] = sc;
-        x[i] = (u32)i;
+    u64* x = gx + base;
+    for (int i = threadIdx.x; i < nk; i += 64) {
+        int sc = 0;
+        for (int j = 0; j < mink; ++j) sc += s_self[c[i + j]];
+        x[i] = ((u64)(u32)(KSC_BIAS - sc) << 32) | (u32)i;
     }
-    ref_qsort_dev(x, nk, [k](u32 i) { return -k[i]; });
+    __syncthreads();
+    wave_ref_qsort<WQS_LEAF, 16>(x, nk, [](u64 v) { return (int)(v >> 32); }, 0x7fffffff, gL + base, gR + base, s_leaf);
+    for (int i = threadIdx.x; i < nk; i += 64) korder[base + i] = (u32)x[i];
 }
 
 // ---- high-frequency cap (fsearch.py:2667-2677) ---------------------------------------------------
@@ -418,15 +419,16 @@ void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* hkey, const 
                             (const uint2*)nullptr, ubeg, NC, E, sbeg, scnt, pcnt);
 }
 
-void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, int mink, const signed char* b62c, int* ksc, u32* korder,
-                      hipStream_t st) {
+void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, u32 q_long /*first batch slot that may hold more than LDS_SORT_MAX windows*/, int mink,
+                      const signed char* b62c, u64* gx, u32* gL, u32* gR /*global scratch per residue: only when q_long < nq*/, u32* korder, hipStream_t st) {
     if (!nq) return;
     // (one wave per query: the instance for the typical protein keeps 4 KB of LDS so that a CU holds 32 of them)
     hipLaunchKernelGGL((k_ksc_order_lds<512, 0>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
     hipLaunchKernelGGL((k_ksc_order_lds<1024, 512>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
     hipLaunchKernelGGL((k_ksc_order_lds<LDS_SORT_MAX, 1024>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
-    hipLaunchKernelGGL(k_ksc_order, dim3((nq + 63) / 64), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, ksc, korder);
+    if (q_long < nq) hipLaunchKernelGGL(k_ksc_order_g, dim3(nq - q_long), dim3(64), 0, st, q_scls, qoff, q_long, nq, mink, b62c, gx, gL, gR, korder);
 }
+int ksc_lds_max() { return LDS_SORT_MAX; }
 
 void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark,
                 unsigned long long* qhits, hipStream_t st) {

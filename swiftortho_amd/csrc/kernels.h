@@ -60,8 +60,9 @@ void launch_index_fixlast(u64* entries, u32 lo, u32 E, hipStream_t st);
 void launch_qhash(const u32* words, u32 Ppad, const SeedCfg& cfg, const HashLut& lut, u32* qbucket, hipStream_t st);
 void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* hkey, const u64* hval, int hshift, u32 hmask, const u64* dir /*or null: the map*/,
                    const u32* ubeg, u32 NC, u32 E, u32* sbeg, u32* scnt, u32* pcnt, hipStream_t st);
-void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, int mink, const signed char* b62c, int* ksc, u32* korder,
-                      hipStream_t st);
+void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, u32 q_long /*first batch slot that may hold more than ksc_lds_max() windows*/, int mink,
+                      const signed char* b62c, u64* gx, u32* gL, u32* gR /*global scratch per residue: only when q_long < nq*/, u32* korder, hipStream_t st);
+int ksc_lds_max();
 void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark,
                 unsigned long long* qhits, hipStream_t st);
 void launch_effcnt(const u8* mark, const u32* scnt, u32 Ppad, int AS, u32 p_lo, u32 p_hi, u32* eff, u32* nz, hipStream_t st);
@@ -78,7 +79,8 @@ void launch_group_list(const u32* flags, const u32* gidx, u32 H, u32* ghead, hip
 u32 ungap_shard_cap(u32 H);
 // klr: layout of the pass records (sequence bits / diagonal offset; == kl unless btab); btab: band -> (chunk sequence, gbase) when
 // some subject owns several diagonal bands (k_encode_band32), else null
-void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& klr, const void* btab, bool ft_walk, const u8* q_scls, const u32* qoff,
+// gallop: the pass holds queries long enough for runs of covered seeds worth skipping in one step (k_ungap's GALLOP)
+void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& klr, const void* btab, bool gallop, bool ft_walk, const u8* q_scls, const u32* qoff,
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt, u32 shard_cap, u64* p_qs, u64* p_sd,
                   u64* p_ft, unsigned long long* group_count, hipStream_t st);
 void launch_first_touch(bool walk, const u64* keys, u32 H, const KeyLayout& kl, int ft_bits_entry, int bsp, const u32* roff, u64* p_ft, u32 n,
@@ -104,7 +106,11 @@ void launch_emit_cands(const u32* order, u32 n, const u64* sorted_key /*the fina
 u32 align_trace_stride(int max_rows);
 void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u8* q_scls4, const u32* qoff,
                   const u8* r_res, const u8* r_scls, const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride,
-                  AlnRes* out, bool with_traceback, hipStream_t st);
+                  const u32* tofs /*traces: start of launch position t's trace in units of trace_stride words, or null = t*/, AlnRes* out,
+                  bool with_traceback, hipStream_t st);
+// trace room each task of a launch list needs, in units of align_trace_unit() words (+ a 0 behind the last): scanned, they are `tofs`
+u32 align_trace_unit();
+void launch_trace_units(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, u32* units /*n + 1*/, hipStream_t st);
 
 // k_align16.hip: score-only aligner in packed 16-bit arithmetic, two alignments per register
 int align_pk_max_len();   // largest min(rows, columns) it can score whatever the residues
@@ -172,8 +178,8 @@ void launch_trace_flags(const u32* sel_idx, u32 n, const u32* tpos, u32* flags, 
 void launch_trace_split(const u32* sel_idx, u32 n, const u32* flags, const u32* fscan, u32* list_b, u32* list_a, hipStream_t st);
 // k_align.hip: the two halves of launch_align(..., true) on their own (speculative traces: the walk runs long after the alignment)
 void launch_align_traced(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
-                         const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, AlnRes* out, u32* tpos_out,
-                         u32 tpos_base, hipStream_t st);
+                         const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out,
+                         u32* tpos_out /*tofs: receives tpos_base + tofs[t]*/, u32 tpos_base, hipStream_t st);
 void launch_traceback(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u32* qoff, const u8* r_res, const u32* roff,
                       const u32* trace, u32 trace_stride, const u32* tpos, AlnRes* out, hipStream_t st);
 void launch_stop_round_w(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* ntile, const u32* roffc,

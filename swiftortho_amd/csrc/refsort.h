@@ -90,9 +90,11 @@ __device__ inline void ref_qsort_dev(T* x, int n, KeyFn key, int limit = 0x7ffff
 
 // T = element type (u32 words in LDS, or u64 words in global memory for segments that do not fit),
 // PT = position type of the misfit lists (u16 / u32).
-// LEAFCAP = capacity of the leaf list (2 ints each); when it fills up, further ranges are sorted on the spot by one lane (slow, exact):
-// the small instances of the callers trade that rare case for LDS (a 300-element list produces 20-40 leaves).
-template <int LEAFCAP = WQS_LEAF, class T, class PT, class KeyFn>
+// LEAFCAP = capacity of the leaf list (2 ints each); when it fills up the collected leaves are sorted at once and the list starts over
+// (a 300-element list produces 20-40 leaves).
+// PF = 64-element steps a scan loads before the ballots consume them: 4 for arrays in LDS, 16 for arrays in global memory (a scan over
+// a 30 000-element range is a chain of load -> ballot -> store round trips, ~2 us each: the deeper the batch, the fewer of them).
+template <int LEAFCAP = WQS_LEAF, int PF = 4, class T, class PT, class KeyFn>
 __device__ inline void wave_ref_qsort(T* x, int n, KeyFn key, int limit, PT* Lpos, PT* Rpos, int* leaf) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -104,15 +106,17 @@ __device__ inline void wave_ref_qsort(T* x, int n, KeyFn key, int limit, PT* Lpo
         const int r = stk[--sp], l = stk[--sp];
         if (r <= l || l >= limit) continue;
         const int gap = r - l + 1;
-        if (gap < WQS_PAR || nleaf >= LEAFCAP - 1) {
-            if (gap < WQS_PAR && nleaf < LEAFCAP) {
-                if (lane == 0) leaf[2 * nleaf] = l, leaf[2 * nleaf + 1] = r;
-                ++nleaf;
-            } else {  // leaf list full (cannot happen for n <= 4096): sort it right here on one lane
+        if (gap < WQS_PAR) {
+            if (nleaf == LEAFCAP) {  // leaf list full: sort the collected leaves now, one per lane (disjoint ranges, independent of
+                                     // everything still on the stack), and start a new list.  (Until round 4 a full list sent every
+                                     // further range, whatever its size, to ONE lane: a 30 000-element list took 42 ms.)
                 __syncthreads();
-                if (lane == 0) ref_qsort_range(x, l, r, key, limit);
+                for (int i = lane; i < nleaf; i += 64) ref_qsort_range(x, leaf[2 * i], leaf[2 * i + 1], key, limit);
                 __syncthreads();
+                nleaf = 0;
             }
+            if (lane == 0) leaf[2 * nleaf] = l, leaf[2 * nleaf + 1] = r;
+            ++nleaf;
             continue;
         }
         const int m = l + (int)(0.3745401188473625 * (double)gap);
@@ -126,15 +130,15 @@ __device__ inline void wave_ref_qsort(T* x, int n, KeyFn key, int limit, PT* Lpo
         int cntL = 0, cntR = 0;
         // the two scans read four 64-element steps ahead of the ballots that consume them (a load -> ballot -> store chain per step
         // leaves the wave waiting on memory once per step: the global-memory instance spent ~1 us per 64 elements)
-        for (int base = l + 1; base <= r; base += 4 * 64) {
-            T v[4];
+        for (int base = l + 1; base <= r; base += PF * 64) {
+            T v[PF];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PF; ++u) {
                 const int t = base + u * 64 + lane;
                 v[u] = x[t <= r ? t : r];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PF; ++u) {
                 const int t = base + u * 64 + lane;
                 const bool f = (t <= r) && !(key(v[u]) < p);
                 const unsigned long long bal = __ballot(f);
@@ -142,15 +146,15 @@ __device__ inline void wave_ref_qsort(T* x, int n, KeyFn key, int limit, PT* Lpo
                 cntL += __popcll(bal);
             }
         }
-        for (int base = r; base >= l; base -= 4 * 64) {
-            T v[4];
+        for (int base = r; base >= l; base -= PF * 64) {
+            T v[PF];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PF; ++u) {
                 const int t = base - u * 64 - lane;
                 v[u] = x[t >= l ? t : l];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PF; ++u) {
                 const int t = base - u * 64 - lane;
                 const bool f = (t >= l) && !(key(v[u]) > p);
                 const unsigned long long bal = __ballot(f);
