@@ -1855,6 +1855,14 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             }
         }
         sc.lap("phase2.trace_pass");
+        {   // SOHIT_TEST_OOM_PHASE2=1 (tests): the first multi-query batch of the process fails here, as a device allocation of the
+            // emission stage would -- search_loaded() reruns it as two halves
+            static bool fired = false;
+            if (!fired && nq > 1 && getenv("SOHIT_TEST_OOM_PHASE2")) {
+                fired = true;
+                throw DevOom(0);
+            }
+        }
         if (c->dev_out) {
             // device-resident results: the so_hit records are built in HBM and appended to the ctx's result buffer
             if (!c->d_p2tab.p) {
@@ -2002,6 +2010,7 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
     if (!getenv("SOHIT_BATCH")) batch_q = std::min<i64>(batch_q, std::max<i64>(1024, (i64)((double)0xE0000000ull / est_cands)));
     std::function<void(i64, i64)> run_batch = [&](i64 b0, i64 b1) {
         const so_counters keep = c->cnt;
+        const size_t keep_rows = out.n, keep_dev_rows = c->d_hits_n;   // what the batch may have appended before it failed
         try {
             if (!c->batch) c->batch = std::make_shared<Batch>();
             Batch& b = *static_cast<Batch*>(c->batch.get());
@@ -2036,8 +2045,11 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
             if (!oom && !dynamic_cast<const CandOverflow*>(&e)) throw;
             if (b1 - b0 < 2) throw SoError(oom ? std::string(e.what()) : std::string("one query collected >= 2^32 candidates"));
             (void)hipStreamSynchronize(c->st);
+            (void)hipStreamSynchronize(c->st_rows);   // row downloads the failed attempt had queued
+            c->rows_in_flight = false;
             if (oom) c->batch.reset();  // hand the batch's buffers back before the halves allocate theirs
             c->cnt = keep;
+            out.n = keep_rows, c->d_hits_n = keep_dev_rows;   // (a failure in phase 2 comes after rows of the batch may have been appended)
             const i64 mid = b0 + (b1 - b0) / 2;
             run_batch(b0, mid);
             run_batch(mid, b1);

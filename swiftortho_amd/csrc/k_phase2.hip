@@ -93,7 +93,9 @@ __global__ __launch_bounds__(64) void k_csort(const u32* __restrict__ rec, const
         x[i] = ((u64)(SCORE_CAP - sc) << 32) | (u32)i;
     }
     __syncthreads();
-    wave_ref_qsort<WQS_LEAF, 16>(x, n, [](u64 v) { return (int)(v >> 32); }, (int)vmax, gL + c0, gR + c0, s_leaf);
+    // (16-step scan batches and LDS leaf buffers, which help the k-mer order of very long queries, cost time here: 37 -> 48 ms per
+    // step on the 100k weight-6 set -- the vmax cut prunes most of the recursion, what is left are a few long scans)
+    wave_ref_qsort(x, n, [](u64 v) { return (int)(v >> 32); }, (int)vmax, gL + c0, gR + c0, s_leaf);
     const u32 m = (u32)n < vmax ? (u32)n : vmax;
     const u32 lq = qoff[q + 1] - qoff[q];
     u32 tiles = 0;

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(64) void k_ksc_order_g(const u8* __restrict__ q_scl
                                                     const signed char* __restrict__ b62c /*24x24*/, u64* __restrict__ gx, u32* __restrict__ gL,
                                                     u32* __restrict__ gR, u32* __restrict__ korder) {
     __shared__ signed char s_self[SCLS_N];
+    __shared__ u64 s_leafbuf[64 * WQS_LEAFBUF];
     __shared__ int s_leaf[2 * WQS_LEAF];
     if (threadIdx.x < SCLS_N) s_self[threadIdx.x] = b62c[threadIdx.x * SCLS_N + threadIdx.x];
     __syncthreads();
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64) void k_ksc_order_g(const u8* __restrict__ q_scl
         x[i] = ((u64)(u32)(KSC_BIAS - sc) << 32) | (u32)i;
     }
     __syncthreads();
-    wave_ref_qsort<WQS_LEAF, 16>(x, nk, [](u64 v) { return (int)(v >> 32); }, 0x7fffffff, gL + base, gR + base, s_leaf);
+    wave_ref_qsort<WQS_LEAF, 16>(x, nk, [](u64 v) { return (int)(v >> 32); }, 0x7fffffff, gL + base, gR + base, s_leaf, s_leafbuf);
     for (int i = threadIdx.x; i < nk; i += 64) korder[base + i] = (u32)x[i];
 }
 

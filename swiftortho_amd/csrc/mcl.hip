@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void k_mcl_colkeys(const u32* __restrict__ idx
     const u32 p = blockIdx.x * 256u + threadIdx.x;
     if (p < nnz) keys[p] = idx[p], pos[p] = p;
 }
-// y[c] = entries of column c summed in storage order (float32, sequential), flags: [0] some column sums to 0, [1] some sum > 0
+// y[c] = entries of column c summed in storage order (float32, sequential), flags: [0] some column sums to 0, [1] some sum > 0,
+// [2] some sum < 0, [3] the smallest column index whose sum is not 0 (atomicMin; preset to ~0)
 __global__ __launch_bounds__(256) void k_mcl_colsum(const u64* __restrict__ ckeys /*sorted columns*/, const u32* __restrict__ cpos, u32 nnz,
                                                     const float* __restrict__ val, u32 n, float* __restrict__ y, u32* __restrict__ flags) {
     const u32 c = blockIdx.x * 256u + threadIdx.x;
@@ -79,15 +80,19 @@ __global__ __launch_bounds__(256) void k_mcl_colsum(const u64* __restrict__ ckey
     if (s == 0.f) atomicOr(&flags[0], 1u);
     if (s > 0.f) atomicOr(&flags[1], 1u);
     if (s < 0.f) atomicOr(&flags[2], 1u);
+    if (s != 0.f) atomicMin(&flags[3], c);   // (NaN != 0 too, as numpy's nonzero() sees it)
 }
-// normalize(): `if y.min() == 0 and y.max() > 0: y += y.nonzero()[0].min() / 1e3` -- on a 1 x n matrix nonzero()[0] are ROW
-// indices, all 0: the addend is 0.0 -- `else: y += 1e-8`; then data /= y[column]
+// normalize() (find_cluster.py:636-646): `y = np.asarray(cs)[0]` is the 1-D vector of column sums;
+// `if y.min() == 0 and y.max() > 0: y += y.nonzero()[0].min() / 1e3` adds (index of the FIRST column with a non-zero sum) / 1000,
+// rounded to float32 like every scalar added in place to a float32 array -- 0.0 only while column 0 itself sums to something --
+// `else: y += 1e-8`; then data /= y[column].  (Round 3 had the addend fixed at 0.0: a block whose first gene has only zero-weight or
+// fully pruned edges divided 0 by 0 where the reference divides 0 by k / 1000.)
 __global__ __launch_bounds__(256) void k_mcl_divide(const u32* __restrict__ idx, float* __restrict__ val, u32 nnz, const float* __restrict__ y,
                                                     const u32* __restrict__ flags) {
     const u32 p = blockIdx.x * 256u + threadIdx.x;
     if (p >= nnz) return;
     const bool min_is_zero = flags[0] && !flags[2];
-    const float eps = (min_is_zero && flags[1]) ? 0.0f : 1e-8f;
+    const float eps = (min_is_zero && flags[1]) ? (float)((double)flags[3] / 1e3) : 1e-8f;
     val[p] = __fdiv_rn(val[p], __fadd_rn(y[idx[p]], eps));
 }
 
@@ -246,17 +251,23 @@ __global__ __launch_bounds__(64) void k_mcl_diff(const u32* __restrict__ rp, con
             slot = (slot + 1) & (T - 1);
         }
         const float t = __fsub_rn(fabsf(__fsub_rn(a, b)), __fmul_rn(rtol, fabsf(b)));
-        m = fmaxf(m, t);
+        if (m == m) m = (t != t) ? t : fmaxf(m, t);   // scipy's .max() hands a NaN on (np.maximum.reduce); fmaxf would drop it
     }
     wave_fence();
     for (u32 t = lane; t < T; t += 64) {
         if (ld_u(&keys[t]) != MCL_EMPTY && ld_u(&seen[t]) == 0u) {   // stored in x_old only
             const float b = ld_f(&vals[t]);
-            m = fmaxf(m, __fsub_rn(fabsf(b), __fmul_rn(rtol, fabsf(b))));
+            const float tt = __fsub_rn(fabsf(b), __fmul_rn(rtol, fabsf(b)));
+            if (m == m) m = (tt != tt) ? tt : fmaxf(m, tt);
         }
     }
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0 && m > 0.f) atomicMax(maxbits, __float_as_uint(m));   // non-negative floats order like their bit patterns
+    for (int o = 32; o > 0; o >>= 1) {
+        const float other = __shfl_xor(m, o);
+        m = (m != m) ? m : (other != other) ? other : fmaxf(m, other);
+    }
+    // non-negative floats order like their bit patterns, and a NaN's pattern (0x7FC00000 after fabsf) lies above every finite one's:
+    // the maximum the host reads back is NaN when any row saw one, and `NaN <= atol` is false there as in the reference
+    if (lane == 0 && (m > 0.f || m != m)) atomicMax(maxbits, __float_as_uint(fabsf(m)) | (m != m ? 0x7FC00000u : 0u));
 }
 
 struct Mcl {
@@ -277,7 +288,8 @@ struct Mcl {
         const int bits = ceil_log2((u64)x.n + 1);
         sort_tmp.ensure(sort_pairs_u64_u32_temp_bytes(x.nnz, bits) + 256);
         sort_pairs_u64_u32(sort_tmp.p, sort_tmp.cap, ck.p, ck2.p, cp.p, cp2.p, x.nnz, bits, st);   // stable: positions ascend inside a column
-        HIP_CHECK(hipMemsetAsync(flags.p, 0, 4 * sizeof(u32), st));
+        HIP_CHECK(hipMemsetAsync(flags.p, 0, 3 * sizeof(u32), st));
+        HIP_CHECK(hipMemsetAsync(flags.p + 3, 0xFF, sizeof(u32), st));
         hipLaunchKernelGGL(k_mcl_colsum, dim3((x.n + 255) / 256), dim3(256), 0, st, ck2.p, cp2.p, x.nnz, x.val.p, x.n, y.p, flags.p);
         hipLaunchKernelGGL(k_mcl_divide, dim3((x.nnz + 255) / 256), dim3(256), 0, st, x.idx.p, x.val.p, x.nnz, y.p, flags.p);
     }

@@ -94,8 +94,27 @@ __device__ inline void ref_qsort_dev(T* x, int n, KeyFn key, int limit = 0x7ffff
 // (a 300-element list produces 20-40 leaves).
 // PF = 64-element steps a scan loads before the ballots consume them: 4 for arrays in LDS, 16 for arrays in global memory (a scan over
 // a 30 000-element range is a chain of load -> ballot -> store round trips, ~2 us each: the deeper the batch, the fewer of them).
+// leafbuf (arrays in global memory): 64 x WQS_LEAFBUF elements of LDS; a lane sorts its leaf there instead of in place (an insertion
+// sort is a chain of dependent accesses: ~100 cycles each in LDS, ~1000 in global memory).
+#define WQS_LEAFBUF (WQS_PAR + 1)   // odd stride: the lanes' copies start in different banks
+template <class T, class KeyFn>
+__device__ inline void wave_sort_leaves(T* x, const int* leaf, int nleaf, KeyFn key, int limit, T* leafbuf) {
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < nleaf; i += 64) {
+        const int l = leaf[2 * i], r = leaf[2 * i + 1];
+        if (!leafbuf) {
+            ref_qsort_range(x, l, r, key, limit);
+        } else if (l < limit) {
+            T* b = leafbuf + lane * WQS_LEAFBUF;
+            for (int k = 0; k <= r - l; ++k) b[k] = x[l + k];
+            ref_qsort_range(b, 0, r - l, key, limit - l);
+            for (int k = 0; k <= r - l; ++k) x[l + k] = b[k];
+        }
+    }
+}
+
 template <int LEAFCAP = WQS_LEAF, int PF = 4, class T, class PT, class KeyFn>
-__device__ inline void wave_ref_qsort(T* x, int n, KeyFn key, int limit, PT* Lpos, PT* Rpos, int* leaf) {
+__device__ inline void wave_ref_qsort(T* x, int n, KeyFn key, int limit, PT* Lpos, PT* Rpos, int* leaf, T* leafbuf = nullptr) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int stk[2 * 40];
@@ -111,7 +130,7 @@ __device__ inline void wave_ref_qsort(T* x, int n, KeyFn key, int limit, PT* Lpo
                                      // everything still on the stack), and start a new list.  (Until round 4 a full list sent every
                                      // further range, whatever its size, to ONE lane: a 30 000-element list took 42 ms.)
                 __syncthreads();
-                for (int i = lane; i < nleaf; i += 64) ref_qsort_range(x, leaf[2 * i], leaf[2 * i + 1], key, limit);
+                wave_sort_leaves(x, leaf, nleaf, key, limit, leafbuf);
                 __syncthreads();
                 nleaf = 0;
             }
@@ -134,11 +153,13 @@ __device__ inline void wave_ref_qsort(T* x, int n, KeyFn key, int limit, PT* Lpo
             T v[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
+                if (PF > 4 && base + u * 64 > r) break;   // (wave-uniform: nothing of the range left for this step)
                 const int t = base + u * 64 + lane;
                 v[u] = x[t <= r ? t : r];
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
+                if (PF > 4 && base + u * 64 > r) break;
                 const int t = base + u * 64 + lane;
                 const bool f = (t <= r) && !(key(v[u]) < p);
                 const unsigned long long bal = __ballot(f);
@@ -150,11 +171,13 @@ __device__ inline void wave_ref_qsort(T* x, int n, KeyFn key, int limit, PT* Lpo
             T v[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
+                if (PF > 4 && base - u * 64 < l) break;
                 const int t = base - u * 64 - lane;
                 v[u] = x[t >= l ? t : l];
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
+                if (PF > 4 && base - u * 64 < l) break;
                 const int t = base - u * 64 - lane;
                 const bool f = (t >= l) && !(key(v[u]) > p);
                 const unsigned long long bal = __ballot(f);
@@ -197,6 +220,6 @@ __device__ inline void wave_ref_qsort(T* x, int n, KeyFn key, int limit, PT* Lpo
         }
     }
     __syncthreads();
-    for (int i = lane; i < nleaf; i += 64) ref_qsort_range(x, leaf[2 * i], leaf[2 * i + 1], key, limit);
+    wave_sort_leaves(x, leaf, nleaf, key, limit, leafbuf);
     __syncthreads();
 }

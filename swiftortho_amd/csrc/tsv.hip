@@ -6,8 +6,8 @@
 // Semantics are the Python ones the numpy path implements (swiftortho_amd/find_orth.py columns_from_text): a line is the bytes up to
 // (not including) its '\n'; column k of a line runs from the (k - 1)-th tab + 1 (column 0: the line start) to the k-th tab (or the
 // line end); a line with fewer than k tabs has no column k.  A numeric column is stripped of ASCII white space and, when it is a
-// PLAIN decimal number (sign, digits, '.', exponent -- what every real file holds), converted with strtod, which is correctly rounded
-// like Python's float(); anything else (empty, "inf", "1_0", hex ...) is only FLAGGED and the caller lets Python decide.
+// PLAIN decimal number (sign, digits, '.', exponent -- what every real file holds), converted with std::from_chars, which is correctly
+// rounded like Python's float() and ignores the process locale; anything else (empty, "inf", "1_0", hex ...) is only FLAGGED and the caller lets Python decide.
 #include "../../include/sohit.h"
 #include <algorithm>
 #include <charconv>
@@ -88,7 +88,6 @@ int so_tsv_scan(const char* buf, int64_t n, const int64_t* line_start, int64_t n
     for (int c = 0; c < ncols; ++c) maxcol = std::max(maxcol, (int)cols[c]);
     tsv_parallel(nline, [&](int64_t a, int64_t b) {
         std::vector<int64_t> tab((size_t)maxcol + 2);
-        std::string tmp;
         for (int64_t i = a; i < b; ++i) {
             const int64_t ls = line_start[i];
             const char* nlp = (const char*)memchr(buf + ls, '\n', (size_t)(n - ls));
@@ -120,9 +119,13 @@ int so_tsv_scan(const char* buf, int64_t n, const int64_t* line_start, int64_t n
                     double v = 0;
                     if (!have || en == st) s = 1;
                     else if (plain_number(buf + st, buf + en)) {
-                        tmp.assign(buf + st, (size_t)(en - st));
-                        v = strtod(tmp.c_str(), nullptr);
-                        s = 0;
+                        // std::from_chars: correctly rounded like Python's float() and, unlike strtod, blind to the process's LC_NUMERIC
+                        // (an embedding program that has called setlocale() under a comma-decimal locale would read "1.5" as 1.0).
+                        // It takes no leading '+'; a value out of double's range stays flagged and Python decides (inf / 0.0).
+                        const char* a = buf + st + (buf[st] == '+' ? 1 : 0);
+                        const auto r = std::from_chars(a, buf + en, v);
+                        if (r.ec == std::errc() && r.ptr == buf + en) s = 0;
+                        else v = 0;
                     }
                     if (val) val[o] = v;
                     if (status) status[o] = s;

@@ -177,3 +177,67 @@ def test_find_cluster_cli(tmp_path):
     assert os.listdir(str(tmp_path)) == []
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "find_cluster.py"), "-i", inp], capture_output=True, text=True)
     assert r.returncode == 2 and "mcl" in r.stderr      # default -a apc: not provided
+
+
+def _zero_column_cases():
+    """CSR blocks whose column 0 sums to zero in some round of the loop: (a) gene 0 has only zero-weight edges from the start;
+    (b) gene 0's column holds forty equal entries, which inflation 4 pushes below the pruning threshold after the first expansion:
+    the column holds stored zeros only from round 2 on, while the other columns keep their heavy diagonals."""
+    from scipy import sparse
+    rng = np.random.default_rng(7)
+    n = 12
+    a = np.zeros((n, n), dtype=np.float32)
+    for i in range(1, n):
+        for j in range(i, n):
+            if i == j or rng.random() < 0.5:
+                a[i, j] = a[j, i] = np.float32(rng.uniform(0.5, 3.0))
+    m = sparse.lil_matrix(a)
+    ma = sparse.csr_matrix(m)
+    # explicit zeros in row / column 0
+    ip, ix, dv = ma.indptr.astype(np.int64), ma.indices.astype(np.int32), ma.data.astype(np.float32)
+    rows = [list(zip(ix[ip[i]:ip[i + 1]], dv[ip[i]:ip[i + 1]])) for i in range(n)]
+    rows[0] = [(0, np.float32(0)), (1, np.float32(0))]
+    rows[1] = [(0, np.float32(0))] + rows[1]
+    ipa = np.cumsum([0] + [len(r) for r in rows]).astype(np.int64)
+    ixa = np.array([c for r in rows for c, _ in r], dtype=np.int32)
+    dva = np.array([v for r in rows for _, v in r], dtype=np.float32)
+    # (b): genes 1..40 on a ring with heavy self loops (their columns keep entries above the threshold), gene 0 tied to all of them:
+    # column 0 = forty equal entries, row 0 = forty weak ones, no self loop
+    n2 = 41
+    b = np.zeros((n2, n2), dtype=np.float32)
+    for i in range(1, n2):
+        b[i, i] = 10.0
+        j = 1 + (i % 40)
+        b[i, j] = b[j, i] = 1.0
+        b[i, 0] = 1.0
+        b[0, i] = 0.01
+    mb = sparse.csr_matrix(b)
+    return [("zero_weight_gene", ipa, ixa, dva, 1.5), ("pruned_column", mb.indptr.astype(np.int64), mb.indices.astype(np.int32), mb.data.astype(np.float32), 4.0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [0, 1])
+def test_device_mcl_zero_sum_first_column(case, monkeypatch):
+    """normalize() adds (index of the first column with a non-zero sum) / 1000 when some column sums to zero (find_cluster.py:636-646):
+    0.0 only while column 0 itself has a sum.  Both cases make column 0 sum to zero; the scipy oracle and the device loop must agree
+    (no NaN from 0 / 0, same convergence decision)."""
+    import mcl_scipy_oracle as mo
+    from swiftortho_amd import find_cluster as fc
+    name, ip, ix, dv, infl = _zero_column_cases()[case]
+    seen = []
+    real = mo._normalize
+
+    def spy(x):
+        y = np.asarray(x.sum(0))[0]
+        seen.append(bool(y.min() == 0 and y.max() > 0 and y[0] == 0))
+        real(x)
+    monkeypatch.setattr(mo, "_normalize", spy)
+    for rounds in (1, 2, 4, 100):
+        seen.clear()
+        got = fc.device_mcl(ip, ix, dv.copy(), infl, rounds=rounds)
+        want = mo.scipy_mcl(ip.copy(), ix.copy(), dv.copy(), infl, rounds=rounds)   # (scipy normalises the data array it is handed in place)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (name, rounds)
+        assert np.allclose(got[2], want[2], rtol=1e-6, atol=1e-12, equal_nan=True), (name, rounds)
+        assert np.isnan(got[2]).sum() == np.isnan(want[2]).sum()
+        if rounds >= 2:
+            assert any(seen), "%s: column 0 never summed to zero -- the case does not test what it says" % name

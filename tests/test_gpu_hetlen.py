@@ -120,3 +120,39 @@ def test_device_records_and_query_work_in_file_order(fs, monkeypatch):
     assert rows2 == rows
     h2.close()
     s2.close()
+
+
+def test_out_of_memory_in_phase2_reruns_the_batch_in_halves(fs):
+    """A device allocation failing late in a batch (phase 2, after the traced alignments: SOHIT_TEST_OOM_PHASE2 makes the first
+    multi-query batch of a process fail there) sends the batch through search_loaded()'s halving path: same rows, same device
+    records, counters not double counted.  Run in a child process (the hook fires once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from swiftortho_amd import fsearch, synthprot
+fa = synthprot.synthprot(900, seed=3, lengths="lognormal")
+kw = dict(ssd="111111", nr="AST,CFILMVY,DN,EQ,G,H,KR,P,W", ht=120000000, chk=400, step=1, v=500, expect=1e-5, flt="T")
+def run(device):
+    s = fsearch.Searcher(**kw)
+    s.load_ref_bytes(fa); s.load_queries_bytes(fa)
+    if device:
+        d = s.search_device(); raw = d.tensor().cpu().numpy().tobytes()
+    else:
+        h = s.search(); raw = h.raw_bytes(); h.close()
+    c = s.counters(); s.close()
+    return raw, c
+want, c0 = run(False)
+os.environ["SOHIT_TEST_OOM_PHASE2"] = "1"
+got, c1 = run(int(sys.argv[1]))
+assert got == want and len(got) > 80 * 500, (len(got), len(want))
+for k in ("rows", "seed_hits", "candidates", "alignments", "n_queries"):
+    assert c0[k] == c1[k], (k, c0[k], c1[k])
+print("OOM_RERUN_OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for device in ("0", "1"):
+        p = subprocess.run([sys.executable, "-c", code, device], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "OOM_RERUN_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])

@@ -109,3 +109,34 @@ def test_orthology_from_hit_records_on_gpu(tmp_path):
     assert times["rows"] == meta["sc_rows"]
     assert hashlib.md5(open(sc, "rb").read()).hexdigest() == meta["sc_md5"]
     assert hashlib.md5(b"".join(l + b"\n" for l in lines)).hexdigest() == meta["orth_md5"]
+
+
+@pytest.mark.gpu
+def test_run_all_fast_wrapper_clusters_the_recoded_file(tmp_path):
+    """scripts/run_all_fast.py's clustering step as the reference wrapper has it (run_all_fast.py:139-193): ids recoded to numbers by
+    first appearance (.xyz), THAT file clustered, numbers mapped back (.clsr), .grp removed.  (For -A mcl the reference calls the
+    external mcl program; here bin/find_cluster.py -a mcl clusters the same .xyz: consistency of the wrapper's own files is what
+    this checks -- the docstring of the script says what is not pinned.)"""
+    from swiftortho_amd import synthprot
+    fas = str(tmp_path / "w.fsa")
+    open(fas, "wb").write(synthprot.synthprot(1500, 150, 21))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_all_fast.py"), "-i", fas, "-s", "111111", "-a", "1", "-v", "500"],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = fas + "_results"
+    opc = [l.split("\t") for l in open(os.path.join(res, "w.fsa.opc"))]
+    xyz = [l.split("\t") for l in open(os.path.join(res, "w.fsa.xyz"))]
+    assert len(opc) == len(xyz) > 100 and not os.path.exists(os.path.join(res, "w.fsa.grp"))
+    id2n = {}
+    for (typ, q, s, sco), (a, b, z) in zip(opc, xyz):
+        for g in (q, s):
+            id2n.setdefault(g, len(id2n))
+        assert (a, b, z) == (str(id2n[q]), str(id2n[s]), sco)
+    grp = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "find_cluster.py"), "-i", os.path.join(res, "w.fsa.xyz"), "-a", "mcl", "-I", "1.5"],
+                         capture_output=True, text=True, check=True).stdout
+    n2id = {str(n): g for g, n in id2n.items()}
+    want = "".join("\t".join(n2id[k] for k in l.split("\t")) + "\n" for l in grp.split("\n") if l)
+    got = open(os.path.join(res, "w.fsa.clsr")).read()
+    assert got == want and got.count("\n") > 20
+    genes = got.split()
+    assert len(genes) == len(set(genes)) and set(genes) <= set(id2n)
