@@ -713,7 +713,7 @@ struct Batch {
     DevBuf<unsigned long long> qhits;
     DevBuf<u64> cs_kbase;
     DevBuf<u64> keys, keys2;
-    DevBuf<u32> hits32, bmat, bpart, bt0, btd, bext, bflag, bcnt, bccnt;  // bucketed binning (k_bucket.hip)
+    DevBuf<u32> hits32, hits32s, bmat, bpart, bt0, btd, bext, bflag, bcnt, bccnt;  // bucketed binning (k_bucket.hip)
     DevBuf<u32> flags, gidx, ghead;
     DevBuf<u64> p_qs, p_sd, p_ft, p_qs2, tmp64, q_qs, q_sd, q_ft;
     DevBuf<u32> shard;
@@ -1182,10 +1182,13 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         }
         t1 = wall();
         sc.lap("seed.bucket_scatter");
-        b.keys2.ensure((size_t)H + 2);
+        // the grouped hits leave as the buckets' own 32-bit words (k_ungap's W32 input) unless SOHIT_UG_W32=0 asks for the 64-bit keys
+        static const bool w32 = !(getenv("SOHIT_UG_W32") && atoi(getenv("SOHIT_UG_W32")) == 0);
+        if (w32) b.hits32s.ensure((size_t)H + 2);
+        else b.keys2.ensure((size_t)H + 2);
         b.bext.ensure((size_t)nb + 4);
         launch_bkt_extents(b.bmat.p, b.bt0.p, NT, L.R, nqp, nb, c->d_small.p + 2, b.bext.p, c->st);
-        launch_bkt_group(b.hits32.p, b.bext.p, nb, L, kl, b.keys2.p, b.bflag.p, c->st);
+        launch_bkt_group(b.hits32.p, b.bext.p, nb, L, kl, w32 ? nullptr : b.keys2.p, w32 ? b.hits32s.p : nullptr, b.bflag.p, c->st);
         // a group too large for a wave's LDS table (or pool) leaves key slots unwritten: never walk them -- sorted path instead
         const u32 refused = d2h_u32(c, b.bflag.p);
         sc.lap("group.bucket_group");
@@ -1198,8 +1201,8 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         // ... and a chained ungapped score fits the 20 bits k_bkt_best packs above them (at most 11 per residue of the shorter sequence)
         bbest = !(getenv("SOHIT_BUCKET_BEST") && atoi(getenv("SOHIT_BUCKET_BEST")) == 0) && !ft_walk && (kl.ba + kl.bp + ft_bits_entry <= 44) &&
                 (u64)std::min<u32>(pmaxq, ch.maxslen) * 11ull < (1ull << 20);
-        launch_ungap(b.keys2.p, Hv, kl, klr, btab, pmaxq >= gallop_min, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.shard.p,
-                     shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
+        launch_ungap(w32 ? nullptr : b.keys2.p, Hv, kl, klr, btab, pmaxq >= gallop_min, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo,
+                     c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st, w32 ? b.hits32s.p : nullptr, b.bext.p, nb, &L);
         // the pass records are binned by (query, range of 2^wb chunk SEQUENCES): the same layout unless bands and sequences differ
         bL = L;
         bL.R = (u32)(((u64)nseq_chunk + (1ull << wb) - 1) >> wb);

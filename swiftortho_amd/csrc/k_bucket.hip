@@ -406,8 +406,9 @@ __global__ __launch_bounds__(64) void k_bkt_colscan(u32* __restrict__ mat, u32 N
     }
 }
 
+template <bool W32 /*output: the sorted words themselves (bit 31 = first word of the bucket) instead of 64-bit keys*/>
 __global__ __launch_bounds__(BG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bkt_group(const u32* __restrict__ hits, const u32* __restrict__ bext /*nb + 1*/, u32 nb,
-                                                            BktLayout L, KeyLayout kl, u64* __restrict__ keys, u32* __restrict__ fallback) {
+                                                            BktLayout L, KeyLayout kl, u64* __restrict__ keys, u32* __restrict__ words32, u32* __restrict__ fallback) {
     __shared__ u32 s_srt[BG_CAP];          // the hits, grouped by subject
     __shared__ u32 s_bin[BG_BINS + 1];     // per subject: count -> scatter cursor (= end of its segment afterwards)
     __shared__ u32 s_big[BG_NBIG];         // work units of long segments: start | size << 12 | 64-member block << 25
@@ -532,8 +533,9 @@ __global__ __launch_bounds__(BG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                 if (e - a > BG_SMALL && !big_all) continue;
                 u32 rank = 0;
                 for (u32 k = a; k < e; ++k) rank += (s_srt[k] < x) ? 1u : 0u;
-                keys[cursor + a + rank] = kq + ((u64)(x >> sshift) << kl.sh_subj) + ((u64)((x >> L.bp) & dmask) << kl.sh_diag) +
-                                          ((u64)(x & pmask) << kl.sh_qpos);
+                if (W32) words32[cursor + a + rank] = x | ((cursor + a + rank == b0) ? 0x80000000u : 0u);
+                else keys[cursor + a + rank] = kq + ((u64)(x >> sshift) << kl.sh_subj) + ((u64)((x >> L.bp) & dmask) << kl.sh_diag) +
+                                               ((u64)(x & pmask) << kl.sh_qpos);
             }
             if (!big_all) {
                 for (u32 i = (u32)w; i < nbig; i += BG_THREADS / 64) {  // a wave per unit; every lane reads the same word (broadcast)
@@ -547,9 +549,11 @@ __global__ __launch_bounds__(BG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 #pragma unroll
                         for (int t = 0; t < 4; ++t) rank += (k + (u32)t < sz && v[t] < x) ? 1u : 0u;
                     }
-                    if (mi < sz)
-                        keys[cursor + a + rank] = kq + ((u64)(x >> sshift) << kl.sh_subj) + ((u64)((x >> L.bp) & dmask) << kl.sh_diag) +
-                                                  ((u64)(x & pmask) << kl.sh_qpos);
+                    if (mi < sz) {
+                        if (W32) words32[cursor + a + rank] = x | ((cursor + a + rank == b0) ? 0x80000000u : 0u);
+                        else keys[cursor + a + rank] = kq + ((u64)(x >> sshift) << kl.sh_subj) + ((u64)((x >> L.bp) & dmask) << kl.sh_diag) +
+                                                       ((u64)(x & pmask) << kl.sh_qpos);
+                    }
                 }
             }
             cursor += npass;
@@ -751,12 +755,13 @@ int bkt_max_wb() {
     return lg;
 }
 
-void launch_bkt_group(const u32* hits, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, u64* keys, u32* fallback,
+void launch_bkt_group(const u32* hits, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, u64* keys, u32* words32, u32* fallback,
                       hipStream_t st) {
     if (!nb) return;
     // persistent workgroups striding over the buckets, range-major: the chip writes one subject range at a time
     const u32 grid = std::min<u32>(nb, 256u * 4u);
-    hipLaunchKernelGGL(k_bkt_group, dim3(grid), dim3(BG_THREADS), 0, st, hits, bext, nb, L, kl, keys, fallback);
+    if (words32) hipLaunchKernelGGL(k_bkt_group<true>, dim3(grid), dim3(BG_THREADS), 0, st, hits, bext, nb, L, kl, keys, words32, fallback);
+    else hipLaunchKernelGGL(k_bkt_group<false>, dim3(grid), dim3(BG_THREADS), 0, st, hits, bext, nb, L, kl, keys, words32, fallback);
 }
 
 void launch_rec_count(const u64* p_qs, u32 n, int bs, const BktLayout& L, u32* bcnt, u32* rnk, hipStream_t st) {

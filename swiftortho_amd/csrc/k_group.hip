@@ -54,8 +54,14 @@ enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN =
 // doubling / halving search instead of one bookkeeping visit each.  The self hit of a 30 000-residue protein is a group of 30 000
 // such seeds (45 ms per chunk for that one lane); for ordinary lengths the extra code in the bookkeeping path costs more than the
 // visits it saves (measured on the 100k weight-6 set: 640 -> 699 ms with it always on), hence a template switch.
-template <int CPI /*chunks per loop iteration*/, bool BANDS, bool GALLOP>
-__global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restrict__ keys, u32 H, KeyLayout kl, int rbs, int rsh_subj, int rsh_diag, int rdoff /*klr's fields (BANDS)*/,
+// W32 (bucketed passes, round 4): the input is not 64-bit keys but the buckets' own 32-bit hit words, band_low << (bd + bp) | diagonal
+// << bp | qpos, in (band, diagonal, qpos) order inside each bucket as k_bkt_group leaves them, bit 31 set on the FIRST word of every
+// bucket; the bucket (query, band range) of a word follows from its position (bext).  A group = equal word >> bp inside one bucket.
+// Neither the grouping kernel writes nor this one reads the 8-byte keys (8 B per hit each way), and every per-group field is a 32-bit
+// shift instead of a 64-bit one.  Records are always written in the record layout (klr's fields), as with BANDS.
+template <int CPI /*chunks per loop iteration*/, bool BANDS, bool GALLOP, bool W32>
+__global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restrict__ keys, const u32* __restrict__ words, const u32* __restrict__ bext, u32 nb, BktLayout L,
+                                                         u32 H, KeyLayout kl, int rbs, int rsh_subj, int rsh_diag, int rdoff /*klr's fields (BANDS / W32)*/,
                                                          const uint2* __restrict__ btab, int ft_walk, u32 wait_n,
                                                          const u8* __restrict__ q_scls, const u32* __restrict__ qoff,
                                                          const u8* __restrict__ r_scls,
@@ -87,6 +93,8 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
     const u32 a0 = (u32)ra, b0 = (u32)min((u64)H, ra + UW_RANGE);
     u32* s_queue = s_queue_all[w];
     u64* s_qkey = s_qkey_all[w];
+    u32* s_qw = reinterpret_cast<u32*>(s_qkey_all[w]);   // W32: the head's word ...
+    u32* s_qr = s_qw + UW_QCAP;                          // ... and its bucket: query << 10 | band range
     u64* s_pqs = s_pb_all[w][0];
     u64* s_psd = s_pb_all[w][1];
     u64* s_pft = s_pb_all[w][2];
@@ -98,6 +106,23 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
     const u8* q_m16 = q_scls - 16;  // both class arrays have 16 readable bytes in front (left windows start up to 8 bytes early)
     const u8* r_m16 = r_scls - 16;
 
+    // W32: the bucket the scan position lies in (wave-uniform): id, its end, its query (relative to the pass) and band range
+    const u32 WM = 0x7FFFFFFFu;
+    const u32 pmask32 = (1u << L.bp) - 1u;
+    const int gb = L.wb + L.bd;
+    u32 bcur = 0, bend = 0, bqrel = 0, brange = 0;
+    if (W32) {
+        u32 lo_b = 0, hi_b = nb;   // largest b with bext[b] <= a0; a0 < H = bext[nb], so that bucket is not empty
+        while (hi_b - lo_b > 1) {
+            const u32 m = (lo_b + hi_b) >> 1;
+            if (bext[m] <= a0) lo_b = m;
+            else hi_b = m;
+        }
+        bcur = __builtin_amdgcn_readfirstlane(lo_b);
+        bend = __builtin_amdgcn_readfirstlane(bext[bcur + 1]);
+        brange = bcur / L.nqp;
+        bqrel = bcur - brange * L.nqp;
+    }
     // wave-uniform bookkeeping
     u32 cur = a0;              // next position to scan for heads
     u32 qfront = 0, qback = 0;  // ring counters
@@ -119,6 +144,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
     int prev_qpos = -1, scores = 0;
     bool single = false, havekey = false;
     u64 hkey = 0;  // the head hit's key
+    u32 hw = 0, gw = 0;  // W32: the head hit's word, and the group's word >> bp
     u32 h0 = 0;    // the head hit's position (ft_walk mode)
     u32 cq = 0xFFFFFFFFu, cqb = 0;  // last query looked up (groups arrive sorted by query)
     int cql = 0;
@@ -134,7 +160,42 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
         if (!waitb && !workb) break;
         if (waitb && (!workb || (u32)__popcll(waitb) >= wait_n)) {
             // ---- refill the head ring -----------------------------------------------------------------
-            while (qback - qfront < 64u && cur < b0) {
+            while (W32 && qback - qfront < 64u && cur < b0) {
+                const u32 pos = cur + (u32)lane;
+                const bool valid = pos < b0;
+                u32 wv = pos < H ? words[pos] : 0x80000000u;   // (past the end: reads as the start of another bucket)
+                u32 wp = (u32)__shfl_up((int)wv, 1);
+                if (lane == 0) wp = cur == 0 ? 0u : words[cur - 1];
+                const u32 wn = (u32)__shfl_down((int)wv, 1);
+                const bool head = valid && ((wv >> 31) != 0 || ((wv & WM) >> L.bp) != ((wp & WM) >> L.bp));
+                const bool sing = (lane < 63) && ((wn >> 31) != 0 || ((wn & WM) >> L.bp) != ((wv & WM) >> L.bp));
+                // buckets of the 64 positions: the scan's bucket, except behind a bucket start other than its own (rare: a bucket holds
+                // a thousand hits or more) -- those starts are walked one by one, skipping empty buckets
+                u32 lqr = ((L.qa + bqrel) << 10) | brange;
+                unsigned long long mb = __ballot(valid && (wv >> 31) != 0);
+                while (mb) {
+                    const int ml = (int)__builtin_ctzll(mb);
+                    mb &= mb - 1ull;
+                    if (cur + (u32)ml >= bend) {   // (== bend: the next non-empty bucket starts here)
+                        do {
+                            ++bcur;
+                            if (++bqrel == L.nqp) bqrel = 0, ++brange;
+                        } while (__builtin_amdgcn_readfirstlane(bext[bcur + 1]) <= cur + (u32)ml);
+                        bend = __builtin_amdgcn_readfirstlane(bext[bcur + 1]);
+                        if (lane >= ml) lqr = ((L.qa + bqrel) << 10) | brange;
+                    }
+                }
+                const unsigned long long hb = __ballot(head);
+                if (head) {
+                    const u32 slot = (qback + (u32)__popcll(hb & lt)) & (UW_QCAP - 1);
+                    s_queue[slot] = pos | (sing ? 0x80000000u : 0u);
+                    s_qw[slot] = wv & WM;
+                    s_qr[slot] = lqr;
+                }
+                qback += (u32)__popcll(hb);
+                cur += 64;
+            }
+            while (!W32 && qback - qfront < 64u && cur < b0) {
                 const u32 pos = cur + (u32)lane;
                 u64 k = ~0ull, kp = ~0ull;
                 if (pos < H) k = keys[pos] & kmask;
@@ -167,14 +228,33 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                     const u32 r = (u32)__popcll(needb & lt);
                     if (r < avail) {
                         const u32 qe = s_queue[(qfront + r) & (UW_QCAP - 1)];
-                        const u64 k0 = s_qkey[(qfront + r) & (UW_QCAP - 1)];
+                        u64 k0 = 0;
                         h = qe & 0x7FFFFFFFu;
                         h0 = h;
                         single = (qe >> 31) != 0;
-                        hkey = k0, havekey = true;
-                        gpre = k0 >> kl.sh_diag;
-                        gq = (u32)((k0 >> kl.sh_q) & qall);
-                        if (BANDS) {
+                        havekey = true;
+                        if (W32) {
+                            hw = s_qw[(qfront + r) & (UW_QCAP - 1)];
+                            const u32 qr = s_qr[(qfront + r) & (UW_QCAP - 1)];
+                            gw = hw >> L.bp;
+                            gq = qr >> 10;
+                            const u32 G = ((qr & 1023u) << gb) | gw;
+                            if (BANDS) {
+                                const uint2 be = btab[G >> L.bd];
+                                gsubj = be.x;
+                                dlt = (int)(be.y - G);  // sst - qpos
+                            } else {
+                                gsubj = G >> L.bd;
+                                dlt = (int)kl.diag_off - (int)(G & ((1u << L.bd) - 1u));
+                            }
+                        } else {
+                            k0 = s_qkey[(qfront + r) & (UW_QCAP - 1)];
+                            hkey = k0;
+                            gpre = k0 >> kl.sh_diag;
+                            gq = (u32)((k0 >> kl.sh_q) & qall);
+                        }
+                        if (W32) {
+                        } else if (BANDS) {
                             const u32 G = (u32)((k0 >> kl.sh_diag) & ((1ull << (kl.bs + kl.bd)) - 1ull));
                             const uint2 be = btab[G >> kl.bd];
                             gsubj = be.x;
@@ -205,16 +285,22 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
             if (phase == PH_HIT) {
                 bool in_group = false;
                 u64 k = 0;
+                u32 kw = 0;
                 if (havekey) {
-                    k = hkey, in_group = true, havekey = false;  // the head's key came with the hand-out
+                    k = hkey, kw = hw, in_group = true, havekey = false;  // the head's key came with the hand-out
                 } else if (h < H) {
-                    k = keys[h] & kmask;
-                    in_group = (k >> kl.sh_diag) == gpre;
+                    if (W32) {
+                        kw = words[h];
+                        in_group = (kw >> 31) == 0 && (kw >> L.bp) == gw;
+                    } else {
+                        k = keys[h] & kmask;
+                        in_group = (k >> kl.sh_diag) == gpre;
+                    }
                 }
                 if (!in_group) {
                     fin = true;
                 } else {
-                    const int qpos = (int)((k >> kl.sh_qpos) & pmask);
+                    const int qpos = W32 ? (int)(kw & pmask32) : (int)((k >> kl.sh_qpos) & pmask);
                     if (qpos == prev_qpos) {
                         ++h;  // duplicate (qst, sst) pair: dropped by lis()
                     } else if (GALLOP && prev_qpos >= 0 && qpos <= lo) {
@@ -235,8 +321,13 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                             const u32 t = h + step - 1u;
                             bool cv = false;
                             if (t < H) {
-                                const u64 kk = keys[t] & kmask;
-                                cv = (kk >> kl.sh_diag) == gpre && (int)((kk >> kl.sh_qpos) & pmask) <= lo;
+                                if (W32) {
+                                    const u32 kk = words[t];
+                                    cv = (kk >> 31) == 0 && (kk >> L.bp) == gw && (int)(kk & pmask32) <= lo;
+                                } else {
+                                    const u64 kk = keys[t] & kmask;
+                                    cv = (kk >> kl.sh_diag) == gpre && (int)((kk >> kl.sh_qpos) & pmask) <= lo;
+                                }
                             }
                             if (cv) h += step;
                             if (grow) {
@@ -350,11 +441,12 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                 if (pass) {
                     const int dist = dlt;  // guess_start (2544-2553): floor(2 * (sst - qst) / 2) = the diagonal
                     const u32 i = npb + (u32)__popcll(pb & lt);
-                    s_pqs[i] = ((u64)gq << (BANDS ? rbs : kl.bs)) | gsubj;
+                    s_pqs[i] = ((u64)gq << ((BANDS || W32) ? rbs : kl.bs)) | gsubj;
                     s_psd[i] = ((u64)(u32)scores << 32) | (u64)(u32)dist;
                     // k_first_touch / k_rec_scatter turn this into the first-touch key
                     u64 hk = hkey;
-                    if (BANDS) hk = ((u64)gsubj << rsh_subj) | ((u64)(u32)(rdoff - dlt) << rsh_diag) | (((hkey >> kl.sh_qpos) & pmask) << kl.sh_qpos);
+                    if (W32) hk = ((u64)gsubj << rsh_subj) | ((u64)(u32)(rdoff - dlt) << rsh_diag) | ((u64)(hw & pmask32) << kl.sh_qpos);
+                    else if (BANDS) hk = ((u64)gsubj << rsh_subj) | ((u64)(u32)(rdoff - dlt) << rsh_diag) | (((hkey >> kl.sh_qpos) & pmask) << kl.sh_qpos);
                     s_pft[i] = ft_walk ? (u64)h0 : hk;
                 }
                 npb += np;
@@ -638,16 +730,39 @@ u32 ungap_shard_cap(u32 H) {
 
 void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& klr, const void* btab, bool gallop, bool ft_walk, const u8* q_scls, const u32* qoff,
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt, u32 shard_cap, u64* p_qs, u64* p_sd,
-                  u64* p_ft, unsigned long long* group_count, hipStream_t st) {
+                  u64* p_ft, unsigned long long* group_count, hipStream_t st, const u32* words, const u32* bext, u32 nb, const BktLayout* L) {
     if (!H) return;
     // SOHIT_UG_CPI / SOHIT_UG_WAIT: tuning switches (results do not depend on them)
     const int cpi = getenv("SOHIT_UG_CPI") ? atoi(getenv("SOHIT_UG_CPI")) : UW_CPI;
     const u32 wait_n = getenv("SOHIT_UG_WAIT") ? (u32)atoi(getenv("SOHIT_UG_WAIT")) : UW_WAIT;
-    auto kern = gallop ? (btab ? k_ungap<3, true, true> : k_ungap<3, false, true>)
-                : btab ? (cpi == 1 ? k_ungap<1, true, false> : cpi == 2 ? k_ungap<2, true, false> : k_ungap<3, true, false>)
-                       : (cpi == 1 ? k_ungap<1, false, false> : cpi == 2 ? k_ungap<2, false, false> : k_ungap<3, false, false>);
-    hipLaunchKernelGGL(kern, dim3(ungap_num_blocks(H)), dim3(64 * UW_WAVES), 0, st, keys, H, kl, klr.bs, klr.sh_subj, klr.sh_diag, (int)klr.diag_off, (const uint2*)btab, ft_walk ? 1 : 0, wait_n, q_scls, qoff,
-                       r_scls, roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count);
+    BktLayout L0 = BktLayout();
+    L0.nqp = 1;
+    const dim3 g(ungap_num_blocks(H)), bl(64 * UW_WAVES);
+#define UG_LAUNCH(K) hipLaunchKernelGGL(K, g, bl, 0, st, keys, words, bext, nb, words ? *L : L0, H, kl, klr.bs, klr.sh_subj, klr.sh_diag, (int)klr.diag_off, (const uint2*)btab, \
+                                        ft_walk ? 1 : 0, wait_n, q_scls, qoff, r_scls, roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count)
+    if (words) {   // the buckets' 32-bit words (k_bkt_group), bucketed passes
+        if (gallop) {
+            if (btab) UG_LAUNCH((k_ungap<3, true, true, true>));
+            else UG_LAUNCH((k_ungap<3, false, true, true>));
+        } else {
+            if (btab) UG_LAUNCH((k_ungap<3, true, false, true>));
+            else UG_LAUNCH((k_ungap<3, false, false, true>));
+        }
+        return;
+    }
+    if (gallop) {
+        if (btab) UG_LAUNCH((k_ungap<3, true, true, false>));
+        else UG_LAUNCH((k_ungap<3, false, true, false>));
+    } else if (btab) {
+        if (cpi == 1) UG_LAUNCH((k_ungap<1, true, false, false>));
+        else if (cpi == 2) UG_LAUNCH((k_ungap<2, true, false, false>));
+        else UG_LAUNCH((k_ungap<3, true, false, false>));
+    } else {
+        if (cpi == 1) UG_LAUNCH((k_ungap<1, false, false, false>));
+        else if (cpi == 2) UG_LAUNCH((k_ungap<2, false, false, false>));
+        else UG_LAUNCH((k_ungap<3, false, false, false>));
+    }
+#undef UG_LAUNCH
 }
 
 void launch_shard_scan(const u32* shard_cnt, u32* shard_off, hipStream_t st) {

@@ -82,7 +82,9 @@ u32 ungap_shard_cap(u32 H);
 // gallop: the pass holds queries long enough for runs of covered seeds worth skipping in one step (k_ungap's GALLOP)
 void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& klr, const void* btab, bool gallop, bool ft_walk, const u8* q_scls, const u32* qoff,
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt, u32 shard_cap, u64* p_qs, u64* p_sd,
-                  u64* p_ft, unsigned long long* group_count, hipStream_t st);
+                  u64* p_ft, unsigned long long* group_count, hipStream_t st,
+                  // bucketed passes: instead of `keys`, the buckets' sorted 32-bit words (launch_bkt_group with words32), their extents and layout
+                  const u32* words = nullptr, const u32* bext = nullptr, u32 nb = 0, const BktLayout* L = nullptr);
 void launch_first_touch(bool walk, const u64* keys, u32 H, const KeyLayout& kl, int ft_bits_entry, int bsp, const u32* roff, u64* p_ft, u32 n,
                         hipStream_t st);
 void launch_shard_scan(const u32* shard_cnt, u32* shard_off, hipStream_t st);
@@ -154,7 +156,9 @@ void launch_bkt_extents(const u32* mat, const u32* t0, u32 NT, u32 R, u32 nqp, u
 u32 bkt_scan_blocks(u32 NT);
 void launch_bkt_colsum(const u32* mat, u32 NT, u32 R, u32* partT /*R x bkt_scan_blocks(NT)*/, hipStream_t st);
 void launch_bkt_colscan(u32* mat, u32 NT, u32 R, const u32* baseT, hipStream_t st);
-void launch_bkt_group(const u32* hits, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, u64* keys, u32* fallback,
+// keys (64-bit, (subject, diagonal, qpos) order per bucket) or, when words32 is given instead, the sorted 32-bit words themselves with
+// bit 31 set on the first word of every bucket (k_ungap's W32 input)
+void launch_bkt_group(const u32* hits, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, u64* keys, u32* words32, u32* fallback,
                       hipStream_t st);
 // best diagonal per (query, subject), bucket by bucket: pass records binned into the hit buckets (count -> scan -> scatter, first-touch
 // keys computed on the way), then one LDS reduction per bucket, run once to count the candidates and once to write them
