@@ -152,6 +152,9 @@ int64_t so_format_hit(so_ctx *ctx, const so_hit *hit, char *buf, int64_t cap);
 int so_set_profile(so_ctx *ctx, int on);
 /* NC actually in use: -M, or the reference's `bins` default when -M < 1 (fsearch.py:2228-2231) */
 int64_t so_bucket_count(const so_ctx *ctx);
+/* Host-only helper of the row formatter (tests): for v[0..n) writes "<%f of v>\t<f2s(v)>\n" lines (f2s: fsearch.py:43-61) into out;
+ * returns the bytes written or -1 when cap is too small (allow 1400 per value). */
+int64_t so_fmt_rows(const double *v, int64_t n, char *out, int64_t cap);
 int so_get_counters(const so_ctx *ctx, so_counters *out);
 int so_reset_counters(so_ctx *ctx);
 /* "stage=ms;stage=ms;..." wall-clock laps of the pipeline stages (only with params.profile) */

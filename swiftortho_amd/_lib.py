@@ -40,7 +40,7 @@ EXPORTS = ["so_abi_version", "so_create", "so_destroy", "so_last_error", "so_loa
            "so_search", "so_free_hits", "so_write_sc", "so_format_hit", "so_get_counters", "so_reset_counters", "so_timing_report",
            "so_chunk_threshold", "so_chunk_entries", "so_chunk_download", "so_masked_query", "so_query_candidates", "so_set_profile",
            "so_bucket_count", "so_ref_len", "so_search_device", "so_device_hits_copy", "so_query_work", "so_mcl", "so_mcl_free",
-           "so_mcl_last_error", "so_tsv_lines", "so_tsv_scan", "so_tsv_codes", "so_format_pairs", "so_py_repr"]
+           "so_mcl_last_error", "so_tsv_lines", "so_tsv_scan", "so_tsv_codes", "so_format_pairs", "so_py_repr", "so_fmt_rows"]
 
 
 class SoMclResult(C.Structure):
@@ -128,6 +128,8 @@ def load():
     L.so_format_pairs.argtypes = [cp, C.c_int32, vp, vp, vp, vp, vp, i64, vp, i64]
     L.so_py_repr.restype = i64
     L.so_py_repr.argtypes = [vp, i64, vp, i64]
+    L.so_fmt_rows.restype = i64
+    L.so_fmt_rows.argtypes = [vp, i64, vp, i64]
     for f in ("so_chunk_threshold", "so_chunk_entries"):
         getattr(L, f).restype = i64
         getattr(L, f).argtypes = [vp, i64]

@@ -23,6 +23,7 @@
 #include <mutex>
 #include <thread>
 #include <unordered_map>
+#include <sys/stat.h>
 
 namespace {
 
@@ -112,6 +113,7 @@ struct SeqSet {
     std::string data;            // raw file bytes
     std::vector<i64> rec;        // record offsets (idx)
     std::vector<u32> hd_beg, hd_len;  // header span of each record (without '>')
+    std::vector<u32> id_len;          // ... and of its first blank-free word (the id columns of the output)
     i64 N = 0;
     std::vector<u32> off;        // [N+1] residue offsets
     std::vector<u8> res;         // concatenated residues (raw bytes)
@@ -135,6 +137,7 @@ struct SeqSet {
         off.assign((size_t)N + 1, 0);
         hd_beg.resize((size_t)N);
         hd_len.resize((size_t)N);
+        id_len.resize((size_t)N);
         res.clear();
         res.reserve(data.size());
         maxlen = 0;
@@ -144,6 +147,10 @@ struct SeqSet {
             while (p < ed && data[p] != '\n') ++p;
             hd_beg[x] = (u32)std::min<i64>(st + 1, p);
             hd_len[x] = (u32)(p > st ? p - st - 1 : 0);
+            {
+                const void* sp = hd_len[x] ? memchr(data.data() + hd_beg[x], ' ', hd_len[x]) : nullptr;
+                id_len[x] = sp ? (u32)((const char*)sp - (data.data() + hd_beg[x])) : hd_len[x];
+            }
             ++p;
             while (p < ed) {
                 i64 q = p;
@@ -250,6 +257,8 @@ struct so_ctx {
     static const int BITTAB_N = 1 << 16;
     // sets
     SeqSet ref, qry;
+    std::string ref_path;   // file the reference was read from ("" when it came from memory) and its size / mtime then
+    long long ref_fsize = -1, ref_mtime_ns = -1;
     bool ref_loaded = false, qry_loaded = false, index_built = false;
     i64 r_lo = -1, r_hi = -1;
     std::vector<std::unique_ptr<ChunkIndex>> chunks;
@@ -296,6 +305,9 @@ struct so_ctx {
     std::map<std::string, double> tm;  // per-stage wall ms (only with params.profile)
     std::shared_ptr<void> batch;       // persistent per-batch scratch (struct Batch)
     // device-resident results (so_search_device): so_hit records stay in HBM until the caller has exchanged them
+    // the library sorts' code objects (rocPRIM: megabytes each) are loaded by their first launch: a thread started by so_create does two
+    // tiny sorts while the caller reads and parses its FASTA files; joined before the first index build
+    std::thread warm;
     bool dev_out = false;
     DevBuf<u8> d_hits;
     size_t d_hits_n = 0;
@@ -579,9 +591,36 @@ void* small_host(so_ctx* c);
 u32 d2h_u32(so_ctx* c, const u32* p);
 void ensure_sort_tmp(so_ctx* c, size_t bytes);
 
+// first launches of the library sorts (they load their code objects: ~15 ms for the device-wide unit, ~40 ms for the segmented one)
+void warm_sort_modules(int device) {
+    try {
+        HIP_CHECK(hipSetDevice(device));
+        hipStream_t st;
+        HIP_CHECK(hipStreamCreate(&st));
+        {
+            DevBuf<u32> k, k2, seg;
+            DevBuf<u64> v, v2;
+            DevBuf<u8> tmp;
+            k.ensure(8), k2.ensure(8), seg.ensure(8), v.ensure(8), v2.ensure(8);
+            HIP_CHECK(hipMemsetAsync(k.p, 0, 8 * sizeof(u32), st));
+            HIP_CHECK(hipMemsetAsync(v.p, 0, 8 * sizeof(u64), st));
+            const u32 sg[2] = {0, 2};
+            HIP_CHECK(hipMemcpyAsync(seg.p, sg, sizeof sg, hipMemcpyHostToDevice, st));
+            tmp.ensure(std::max(sort_pairs_u32_u64_temp_bytes(2, 8), sort_keys_u64_seg_temp_bytes(2, 1, 0, 8)) + 256);
+            sort_pairs_u32_u64(tmp.p, tmp.cap, k.p, k2.p, v.p, v2.p, 2, 8, st);
+            sort_keys_u64_seg(tmp.p, tmp.cap, v.p, v2.p, 2, 1, seg.p, 0, 8, st);
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        (void)hipStreamDestroy(st);
+    } catch (...) {
+        // a failure here is the caller's business at its own first sort
+    }
+}
+
 void build_index(so_ctx* c) {
     if (!c->ref_loaded) throw SoError("so_build_index: no reference loaded");
     if (c->index_built) return;
+    if (c->warm.joinable()) c->warm.join();
     const double t0 = wall();
     c->chunks.clear();
     const i64 N = c->ref.N;
@@ -589,6 +628,15 @@ void build_index(so_ctx* c) {
     i64 End = c->r_hi == -1 ? N : c->r_hi;
     const u32 NC = (u32)c->nc;
     c->cnt.index_entries = 0;
+    const bool dbg = getenv("SOHIT_DEBUG_INDEX") != nullptr;   // wall laps of the build's steps (stderr)
+    double tl = wall();
+    auto dlap = [&](const char* what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(c->st);
+        const double n = wall();
+        fprintf(stderr, "[sohit index] %-28s %.3f ms\n", what, (n - tl) * 1e3);
+        tl = n;
+    };
     for (i64 s = Start; s < End; s += c->chunk) {
         std::unique_ptr<ChunkIndex> ch;
         if (!c->spare_chunks.empty()) {
@@ -615,10 +663,12 @@ void build_index(so_ctx* c) {
         const u32 npos = ch->p_hi - ch->p_lo;
         c->ix_pcount.ensure((size_t)npos + 4);
         c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)npos + 1) + 8);
+        dlap("alloc pcount / scan tmp");
         launch_index_windows(false, c->ref.d_words.p, c->ref.d_pseq.p, c->ref.d_off.p, ch->p_lo, ch->p_hi, c->ref.Ppad, (u32)ch->seq_lo, c->cfg,
                              c->ref.lut, (u32)c->step, c->ix_pcount.p, nullptr, nullptr, c->st);
         u32 E = 0;
         if (npos) E = d2h_u32(c, scan_u32(c->ix_pcount.p, c->ix_pcount.p, npos, false, c->d_scan_tmp.p, c->st));
+        dlap("windows (count) + scan");
         if ((u64)E >= (1ull << 29)) throw SoError("chunk index exceeds 2^29 entries (the lookup kernel addresses 8-byte slots with 32-bit byte offsets); lower -c");
         ch->E = E;
         ch->U = 0;
@@ -626,12 +676,16 @@ void build_index(so_ctx* c) {
         u64 s2 = 0;
         if (E) {
             c->ix_bkt.ensure((size_t)E + 4), c->ix_bkt2.ensure((size_t)E + 4), c->ix_ent.ensure((size_t)E + 4);
+            dlap("alloc entries / pairs");
             launch_index_windows(true, c->ref.d_words.p, c->ref.d_pseq.p, c->ref.d_off.p, ch->p_lo, ch->p_hi, c->ref.Ppad, (u32)ch->seq_lo, c->cfg,
                                  c->ref.lut, (u32)c->step, c->ix_pcount.p, c->ix_bkt.p, c->ix_ent.p, c->st);
             // 2. group by bucket id (ascending): the slot layout of the reference's CSR
             const int bbits = ceil_log2((u64)NC);
+            dlap("windows (emit)");
             ensure_sort_tmp(c, sort_pairs_u32_u64_temp_bytes(E, bbits));
+            dlap("alloc sort tmp");
             sort_pairs_u32_u64(c->d_sort_tmp.p, c->d_sort_tmp.cap, c->ix_bkt.p, c->ix_bkt2.p, c->ix_ent.p, ch->entries.p, E, bbits, c->st);
+            dlap("pair sort");
             // 3. runs -> occupied bucket list, first slots, sizes
             c->ix_flags.ensure((size_t)E + 4), c->ix_ridx.ensure((size_t)E + 4);
             c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)E + 1) + 8);
@@ -640,6 +694,7 @@ void build_index(so_ctx* c) {
             ch->U = U;
             ch->ub.ensure((size_t)U + 4), ch->ubeg.ensure((size_t)U + 4), ch->ucnt.ensure((size_t)U + 4);
             launch_run_list(c->ix_bkt2.p, c->ix_flags.p, c->ix_ridx.p, E, U, ch->ub.p, ch->ubeg.p, ch->ucnt.p, c->st);
+            dlap("run heads / list");
             // 4. threshold statistics over the occupied buckets (sum c = E, sum c^2, count = U)
             launch_index_stats(ch->ucnt.p, U, c->d_stats.p, c->st);
             u64* stats = (u64*)small_host(c);
@@ -649,6 +704,7 @@ void build_index(so_ctx* c) {
             HIP_CHECK(hipStreamSynchronize(c->st));
             s2 = stats[1];
             const u32 last_lo = *last_lo_h;
+            dlap("stats");
             // 5. bucket directory: bitmap + rank table over the NC bucket ids, or (very large -M) an open-addressed map, load <= 1/2
             if (ch->use_dir) {
                 const size_t nd = (size_t)NC / 32 + 2;
@@ -676,6 +732,7 @@ void build_index(so_ctx* c) {
             ch->hshift = 22, ch->hmask = 1023;
             HIP_CHECK(hipMemsetAsync(ch->hkey.p, 0xFF, 1024 * sizeof(u32), c->st));
         }
+        dlap("directory + fixlast");
         ch->threshold = chunk_threshold(c, ch->ucnt.p, (u64)E, s2, (u64)ch->U);
         ch->s2 = s2;
         HIP_CHECK(hipStreamSynchronize(c->st));
@@ -2067,14 +2124,54 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
 // ---------------------------------------------------------------------------------------------
 // Row formatting (entry_point, fsearch.py:3234-3243; f2s 43-61)
 // ---------------------------------------------------------------------------------------------
-std::string fmt_f(double x) {
-    char buf[400];
-    snprintf(buf, sizeof buf, "%f", x);
-    return buf;
+// "%f" of a double, as glibc prints it: six decimals, the EXACT binary value rounded half-to-even.  Done with 128-bit integers for
+// |x| < 1e15 (x = m * 2^e exactly; m * 10^6 fits 74 bits) -- three of these per row were most of the 0.25 us a row took in snprintf;
+// anything else (huge, inf, nan) goes through snprintf.  Returns the number of characters written (no terminator).
+int fmt_f6(double x, char* out) {
+    if (!(std::fabs(x) < 1e15)) return snprintf(out, 400, "%f", x);
+    char* o = out;
+    if (std::signbit(x)) *o++ = '-', x = -x;
+    unsigned __int128 q = 0;
+    if (x != 0) {
+        int ex;
+        const double fr = frexp(x, &ex);                  // x = fr * 2^ex, 0.5 <= fr < 1
+        const u64 m = (u64)ldexp(fr, 53);                 // 53-bit integer mantissa
+        const int e = ex - 53;
+        const unsigned __int128 P = (unsigned __int128)m * 1000000u;
+        if (e >= 0) {
+            q = P << e;                                   // (x < 1e15 < 2^50: e <= -3 in fact)
+        } else if (-e < 100) {
+            const int sh = -e;
+            q = P >> sh;
+            const unsigned __int128 rem = P & (((unsigned __int128)1 << sh) - 1), half = (unsigned __int128)1 << (sh - 1);
+            if (rem > half || (rem == half && (q & 1))) ++q;
+        }                                                 // else: below 2^-26 of a unit of the last place: 0
+    }
+    const u64 ip = (u64)(q / 1000000u);
+    u32 fp = (u32)(q % 1000000u);
+    char tmp[24];
+    int n = 0;
+    u64 v = ip;
+    do tmp[n++] = (char)('0' + v % 10), v /= 10;
+    while (v);
+    while (n) *o++ = tmp[--n];
+    *o++ = '.';
+    for (int k = 5; k >= 0; --k) o[k] = (char)('0' + fp % 10), fp /= 10;
+    o += 6;
+    return (int)(o - out);
 }
 
-std::string f2s(double e) {
-    if (e <= 0) return "0";
+std::string fmt_f(double x) {
+    char buf[400];
+    return std::string(buf, (size_t)fmt_f6(x, buf));
+}
+
+// f2s (fsearch.py:43-61) into `out`; returns the length
+int f2s_into(double e, char* out) {
+    if (e <= 0) {
+        out[0] = '0';
+        return 1;
+    }
     if (e < 1e-3) {
         double a = p_log10(e);
         a -= (double)(i64)a;
@@ -2082,30 +2179,73 @@ std::string f2s(double e) {
             double t = 1 + a;
             a = (t != 0) ? t : a;
         }
-        double b = p_pow(10, a);
-        std::string s = fmt_f(p_log10(e / b));
-        size_t d = s.find('.');
-        s = s.substr(0, d == std::string::npos ? 0 : d);
-        std::string p = fmt_f(b);
-        d = p.find('.');
-        p = p.substr(0, d == std::string::npos ? 2 : d + 3);
-        return p + "e" + s;
+        const double b = p_pow(10, a);
+        char sb[400], pb[400];
+        const int sl = fmt_f6(p_log10(e / b), sb), pl = fmt_f6(b, pb);
+        const char* sd = (const char*)memchr(sb, '.', (size_t)sl);
+        const int sn = sd ? (int)(sd - sb) : 0;                          // the exponent: everything in front of the point
+        const char* pd = (const char*)memchr(pb, '.', (size_t)pl);
+        const int pn = std::min(pl, pd ? (int)(pd - pb) + 3 : 2);       // the mantissa cut behind its second decimal
+        memcpy(out, pb, (size_t)pn);
+        out[pn] = 'e';
+        memcpy(out + pn + 1, sb, (size_t)sn);
+        return pn + 1 + sn;
     }
-    return fmt_f(e);
+    return fmt_f6(e, out);
+}
+
+std::string f2s(double e) {
+    char buf[900];
+    return std::string(buf, (size_t)f2s_into(e, buf));
+}
+
+inline char* put_int(char* o, long long v) {
+    if (v < 0) *o++ = '-', v = -v;   // (never LLONG_MIN here)
+    char tmp[24];
+    int n = 0;
+    do tmp[n++] = (char)('0' + v % 10), v /= 10;
+    while (v);
+    while (n) *o++ = tmp[--n];
+    return o;
+}
+
+// one row of the 16-column file appended to `out` (entry_point, fsearch.py:3234-3243)
+void format_hit_into(so_ctx* c, const so_hit& h, std::vector<char>& out) {
+    if (h.qidx < 0 || h.qidx >= c->qry.N || h.sidx < 0 || h.sidx >= c->ref.N) throw SoError("so_format_hit: hit does not belong to the loaded files");
+    const SeqSet &Q = c->qry, &R = c->ref;
+    const size_t ql = Q.id_len[(size_t)h.qidx], sl = R.id_len[(size_t)h.sidx], hl = R.hd_len[(size_t)h.sidx];
+    const size_t at = out.size();
+    out.resize(at + ql + sl + hl + 1400);   // two ids, the header, 14 numbers (three of them doubles: up to 400 characters each)
+    char* o = out.data() + at;
+    memcpy(o, Q.data.data() + Q.hd_beg[(size_t)h.qidx], ql), o += ql, *o++ = '\t';
+    memcpy(o, R.data.data() + R.hd_beg[(size_t)h.sidx], sl), o += sl, *o++ = '\t';
+    {   // identity: "%f" cut behind its second decimal
+        char b[400];
+        const int n = fmt_f6(h.identity, b);
+        const char* d = (const char*)memchr(b, '.', (size_t)n);
+        const int k = std::min(n, d ? (int)(d - b) + 3 : 2);
+        memcpy(o, b, (size_t)k), o += k, *o++ = '\t';
+    }
+    for (int v : {h.aln, h.mis, h.gap, h.qst, h.qed, h.sst, h.sed}) o = put_int(o, v), *o++ = '\t';
+    o += f2s_into(h.evalue, o), *o++ = '\t';
+    o = put_int(o, h.bit), *o++ = '\t';
+    o = put_int(o, h.qlen), *o++ = '\t';
+    o = put_int(o, h.slen), *o++ = '\t';
+    o = put_int(o, (long long)h.qidx), *o++ = '\t';
+    memcpy(o, R.data.data() + R.hd_beg[(size_t)h.sidx], hl), o += hl, *o++ = '\n';
+    out.resize((size_t)(o - out.data()));
 }
 
 std::string format_hit(so_ctx* c, const so_hit& h) {
-    if (h.qidx < 0 || h.qidx >= c->qry.N || h.sidx < 0 || h.sidx >= c->ref.N) throw SoError("so_format_hit: hit does not belong to the loaded files");
-    std::string idy = fmt_f(h.identity);
-    size_t d = idy.find('.');
-    idy = idy.substr(0, d == std::string::npos ? 2 : d + 3);
-    char nums[256];
-    snprintf(nums, sizeof nums, "%d\t%d\t%d\t%d\t%d\t%d\t%d", h.aln, h.mis, h.gap, h.qst, h.qed, h.sst, h.sed);
-    char tail[128];
-    snprintf(tail, sizeof tail, "%d\t%d\t%d\t%lld", h.bit, h.qlen, h.slen, (long long)h.qidx);
-    std::string row = c->qry.ident(h.qidx) + "\t" + c->ref.ident(h.sidx) + "\t" + idy + "\t" + nums + "\t" + f2s(h.evalue) + "\t" + tail +
-                      "\t" + c->ref.header(h.sidx) + "\n";
-    return row;
+    std::vector<char> v;
+    format_hit_into(c, h, v);
+    return std::string(v.data(), v.size());
+}
+
+void file_stamp(const char* path, long long& size, long long& mtime_ns) {
+    struct stat sb;
+    size = mtime_ns = -1;
+    if (stat(path, &sb) == 0) size = (long long)sb.st_size, mtime_ns = (long long)sb.st_mtim.tv_sec * 1000000000ll + sb.st_mtim.tv_nsec;
 }
 
 bool read_file(const char* path, std::string& out) {
@@ -2121,9 +2261,9 @@ bool read_file(const char* path, std::string& out) {
 }
 
 // queries: parse, make the raw residues resident, and prepare the device SEG symbol folding
-void load_queries_common(so_ctx* c) {
+void load_queries_common(so_ctx* c, bool parsed = false) {
     SeqSet& Q = c->qry;
-    Q.parse();
+    if (!parsed) Q.parse();
     const size_t nres = Q.res.size();
     Q.d_res.ensure(nres + 64);
     Q.d_off.ensure((size_t)Q.N + 1);
@@ -2237,6 +2377,7 @@ so_ctx* so_create(int device, const so_params* params) {
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_rows_done, hipEventDisableTiming));
         upload_constants(c);
+        if (!(getenv("SOHIT_WARM") && atoi(getenv("SOHIT_WARM")) == 0)) c->warm = std::thread(warm_sort_modules, device);
         g_create_err.clear();
         return c;
     } catch (const std::exception& e) {
@@ -2248,6 +2389,7 @@ so_ctx* so_create(int device, const so_params* params) {
 
 void so_destroy(so_ctx* c) {
     if (!c) return;
+    if (c->warm.joinable()) c->warm.join();
     (void)hipSetDevice(c->device);
     if (c->st) (void)hipStreamSynchronize(c->st);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -2269,6 +2411,8 @@ int so_load_ref(so_ctx* c, const char* path, int64_t r_lo, int64_t r_hi) {
     return guarded(c, [&] {
         if (!read_file(path, c->ref.data)) throw SoError(std::string("cannot read reference FASTA ") + path);
         load_ref_common(c, r_lo, r_hi);
+        c->ref_path = path;
+        file_stamp(path, c->ref_fsize, c->ref_mtime_ns);
     });
 }
 
@@ -2276,6 +2420,7 @@ int so_load_ref_mem(so_ctx* c, const char* bytes, int64_t n, int64_t r_lo, int64
     return guarded(c, [&] {
         c->ref.data.assign(bytes, (size_t)n);
         load_ref_common(c, r_lo, r_hi);
+        c->ref_path.clear();
     });
 }
 
@@ -2293,6 +2438,17 @@ int so_drop_index(so_ctx* c) {
 
 int so_load_queries(so_ctx* c, const char* path) {
     return guarded(c, [&] {
+        // an all-vs-all run names ONE file twice: its parsed form is copied from the reference side instead of read and parsed again
+        long long fs = -1, fm = -1;
+        if (path) file_stamp(path, fs, fm);
+        if (c->ref_loaded && path && c->ref_path == path && fs >= 0 && fs == c->ref_fsize && fm == c->ref_mtime_ns) {
+            const SeqSet& R = c->ref;
+            SeqSet& Q = c->qry;
+            Q.data = R.data, Q.rec = R.rec, Q.hd_beg = R.hd_beg, Q.hd_len = R.hd_len, Q.id_len = R.id_len, Q.N = R.N, Q.off = R.off, Q.res = R.res,
+            Q.maxlen = R.maxlen;
+            load_queries_common(c, true);
+            return;
+        }
         if (!read_file(path, c->qry.data)) throw SoError(std::string("cannot read query FASTA ") + path);
         load_queries_common(c);
     });
@@ -2385,43 +2541,65 @@ int so_write_sc(so_ctx* c, const so_hit* hits, int64_t n, const char* path, cons
     return guarded(c, [&] {
         FILE* f = fopen(path, (mode && mode[0] == 'a') ? "ab" : "wb");
         if (!f) throw SoError(std::string("cannot open output ") + path);
-        // rows are formatted in slabs of 32768 by a few threads (f2s is log10 / pow / snprintf per row: 1.6 M rows took longer to
-        // print than to search), written in order
-        const int64_t SLAB = 32768;
-        const unsigned nt = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())), (n + SLAB - 1) / SLAB));
-        bool ok = true;
+        // Rows are formatted in slabs of 16384 by a few threads that take slabs in order from a counter; the calling thread writes
+        // every slab as soon as it and all slabs before it are done, so formatting and writing overlap and the threads live as long
+        // as the call (round 3 started eight threads per 262144 rows and wrote between the groups).
+        const int64_t SLAB = 16384;
+        const int64_t nslab = (n + SLAB - 1) / SLAB;
+        const unsigned nt = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())), nslab));
+        std::vector<std::vector<char>> bufs((size_t)nslab);
+        std::vector<std::atomic<int>> ready((size_t)nslab);
+        for (auto& r : ready) r.store(0);
+        std::atomic<int64_t> next(0);
+        std::atomic<bool> failed(false);
         std::exception_ptr err;
         std::mutex mu;
-        try {
-            for (int64_t base = 0; base < n && ok; base += SLAB * nt) {
-                std::vector<std::string> bufs(nt);
-                std::vector<std::thread> th;
-                for (unsigned t = 0; t < nt; ++t) {
-                    const int64_t lo = base + (int64_t)t * SLAB, hi = std::min<int64_t>(n, lo + SLAB);
-                    if (lo >= hi) break;
-                    th.emplace_back([&, t, lo, hi] {
-                        try {
-                            std::string& b = bufs[t];
-                            b.reserve((size_t)(hi - lo) * 96);
-                            for (int64_t i = lo; i < hi; ++i) b += format_hit(c, hits[i]);
-                        } catch (...) {
-                            std::lock_guard<std::mutex> g(mu);
-                            if (!err) err = std::current_exception();
-                        }
-                    });
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&] {
+                for (;;) {
+                    const int64_t k = next.fetch_add(1);
+                    if (k >= nslab || failed.load()) break;
+                    try {
+                        std::vector<char>& b = bufs[(size_t)k];
+                        const int64_t lo = k * SLAB, hi = std::min<int64_t>(n, lo + SLAB);
+                        b.reserve((size_t)(hi - lo) * 128);
+                        for (int64_t i = lo; i < hi; ++i) format_hit_into(c, hits[i], b);
+                    } catch (...) {
+                        std::lock_guard<std::mutex> g(mu);
+                        if (!err) err = std::current_exception();
+                        failed.store(true);
+                    }
+                    ready[(size_t)k].store(1, std::memory_order_release);
                 }
-                for (auto& x : th) x.join();
-                if (err) std::rethrow_exception(err);
-                for (unsigned t = 0; t < nt && ok; ++t)
-                    if (!bufs[t].empty()) ok = fwrite(bufs[t].data(), 1, bufs[t].size(), f) == bufs[t].size();
-            }
-        } catch (...) {
-            fclose(f);
-            throw;
+            });
+        bool ok = true;
+        for (int64_t k = 0; k < nslab && !failed.load(); ++k) {
+            while (!ready[(size_t)k].load(std::memory_order_acquire) && !failed.load()) std::this_thread::yield();
+            if (failed.load()) break;
+            std::vector<char>& b = bufs[(size_t)k];
+            if (ok && !b.empty()) ok = fwrite(b.data(), 1, b.size(), f) == b.size();
+            std::vector<char>().swap(b);
         }
+        for (auto& x : th) x.join();
         if (fclose(f) != 0) ok = false;
+        if (err) std::rethrow_exception(err);
         if (!ok) throw SoError(std::string("short write to ") + path + " (disk full or I/O error)");
     });
+}
+
+// "%f" of v[0..n) (the library's own exact formatter) and f2s (fsearch.py:43-61) of the same values, one per line: "<%f>\t<f2s>\n".
+// Host-only (no ctx, no GPU): lets the CPU tests compare the formatter with printf over millions of values.
+int64_t so_fmt_rows(const double* v, int64_t n, char* out, int64_t cap) {
+    int64_t w = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (cap - w < 1400) return -1;
+        w += fmt_f6(v[i], out + w);
+        out[w++] = '\t';
+        w += f2s_into(v[i], out + w);
+        out[w++] = '\n';
+    }
+    return w;
 }
 
 int so_set_profile(so_ctx* c, int on) {

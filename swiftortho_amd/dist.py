@@ -9,8 +9,11 @@ order, like the reference's block files) balanced by a per-query WEIGHT: the num
 the query visits (Searcher.query_work(): one bounds + cap pre-pass) plus its residues -- seed hits,
 ungapped extensions and alignments all grow with the size of the query's family, residues do not.
 The exchange is a size-exact gatherv of records that are still in HBM: one all_gather of byte counts,
-then grouped send/recv into ONE destination buffer of sum(sizes) bytes on rank 0 (no padding to the
-largest rank), and a single device-to-host copy there.
+then ONE collective with uneven splits (all_to_all_single: every rank sends its records to rank 0 and
+nothing to the others -- RCCL runs it as one group of point-to-point transfers, which is what a gatherv
+is on xGMI's point-to-point links) into ONE destination buffer of sum(sizes) bytes on rank 0 (no padding
+to the largest rank), and a device-to-host copy there in pinned slabs.  SOHIT_GATHER=p2p selects the
+hand-written isend / irecv batch of rounds 2-3 instead (same bytes, same buffer).
 """
 import numpy as np
 
@@ -53,14 +56,40 @@ class GatheredDevice:
         self._host = None
 
     def to_host(self):
-        """-> uint8 numpy array of all records (one device-to-host copy through a pinned buffer)."""
+        """-> uint8 numpy array of all records.  Up to 1 GiB: one copy into a reusable pinned buffer, returned as is; larger results (a
+        1 M-protein search gathers 24 GB) go through two pinned 256 MiB slabs into ordinary memory -- pinning tens of GB is slow
+        and can fail."""
         if self._host is None:
             if self.buf.is_cuda:
                 import torch
-                host = _staging("recv", self.buf.numel(), True)
-                host[:self.buf.numel()].copy_(self.buf, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
-                self._host = host[:self.buf.numel()].numpy()
+                n = self.buf.numel()
+                if n <= SLAB_LIMIT:
+                    host = _staging("recv", n, True)
+                    host[:n].copy_(self.buf, non_blocking=True)
+                    torch.cuda.current_stream().synchronize()
+                    self._host = host[:n].numpy()
+                else:
+                    out = np.empty(n, dtype=np.uint8)
+                    slabs = [_staging("slab%d" % k, SLAB_BYTES, True) for k in (0, 1)]
+                    evs = [torch.cuda.Event(), torch.cuda.Event()]
+                    pend = [None, None]   # (offset, bytes) in flight per slab
+                    k = 0
+                    for off in range(0, n, SLAB_BYTES):
+                        m = min(SLAB_BYTES, n - off)
+                        if pend[k]:
+                            evs[k].synchronize()
+                            o, mm = pend[k]
+                            out[o:o + mm] = slabs[k][:mm].numpy()
+                        slabs[k][:m].copy_(self.buf[off:off + m], non_blocking=True)
+                        evs[k].record()
+                        pend[k] = (off, m)
+                        k ^= 1
+                    for j in (k, k ^ 1):
+                        if pend[j]:
+                            evs[j].synchronize()
+                            o, mm = pend[j]
+                            out[o:o + mm] = slabs[j][:mm].numpy()
+                    self._host = out
             else:
                 self._host = self.buf.numpy()
         return self._host
@@ -71,13 +100,19 @@ class GatheredDevice:
         return [h[offs[r]:offs[r + 1]] for r in range(len(self.sizes))]
 
 
+SLAB_LIMIT = 1 << 30
+SLAB_BYTES = 1 << 28
+
+
 def gather_device_records(t, dst=0):
     """Gather one uint8 torch tensor of packed hit records per rank to rank `dst`, size-exact.
 
-    With the RCCL backend `t` is a device tensor and nothing touches the host: all_gather of the byte counts, then one
-    grouped batch of point-to-point transfers (isend on the sources, irecv into disjoint slices of a single
-    sum(sizes)-byte device buffer on `dst`) -- xGMI links are point to point, so this is what a gatherv is on this
-    fabric anyway.  With gloo (CPU tests / one-GPU functional runs) the same flow runs on host tensors."""
+    With the RCCL backend `t` is a device tensor and nothing touches the host: all_gather of the byte counts, then ONE
+    all_to_all_single with uneven splits (a rank's input goes to `dst` whole, `dst` receives every rank's bytes into disjoint
+    slices of a single sum(sizes)-byte device buffer).  A collective every rank enters with the communicator the all_gather
+    has already used: no point-to-point pair is set up lazily on the first exchange.  SOHIT_GATHER=p2p: the same transfers as
+    an isend / irecv batch.  With gloo (CPU tests / one-GPU functional runs) the same flow runs on host tensors."""
+    import os
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -90,6 +125,12 @@ def gather_device_records(t, dst=0):
     sizes_t = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(sizes_t, torch.tensor([n], dtype=torch.int64, device=dev))
     sizes = [int(x) for x in sizes_t.cpu().tolist()]
+    if os.environ.get("SOHIT_GATHER", "alltoall") != "p2p":
+        total = sum(sizes) if rank == dst else 0
+        recv = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)[:total]
+        dist.all_to_all_single(recv, t, output_split_sizes=sizes if rank == dst else [0] * world,
+                               input_split_sizes=[n if r == dst else 0 for r in range(world)])
+        return GatheredDevice(recv, sizes) if rank == dst else None
     if rank == dst:
         total = sum(sizes)
         recv = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)[:total]
@@ -105,6 +146,38 @@ def gather_device_records(t, dst=0):
         for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, dst)]):
             w.wait()
     return None
+
+
+def allgather_ragged(arr):
+    """int64 numpy array per rank (any lengths) -> their concatenation in rank order, on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    on_gpu = dist.get_backend() == "nccl"
+    dev = "cuda" if on_gpu else "cpu"
+    a = np.ascontiguousarray(arr, dtype=np.int64)
+    sizes_t = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes_t, torch.tensor([len(a)], dtype=torch.int64, device=dev))
+    sizes = [int(x) for x in sizes_t.cpu().tolist()]
+    m = max(max(sizes), 1)
+    mine = torch.zeros(m, dtype=torch.int64, device=dev)
+    if len(a):
+        mine[:len(a)] = torch.from_numpy(a).to(dev)
+    allt = torch.empty(world * m, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allt, mine)
+    h = allt.cpu().numpy()
+    return np.concatenate([h[r * m:r * m + sizes[r]] for r in range(world)]) if sum(sizes) else np.zeros(0, dtype=np.int64)
+
+
+def sharded_query_work(searcher, lens, st, ed):
+    """Per-query seed-hit work of queries [st, ed) (Searcher.query_work) with the pre-pass itself split over the ranks: every rank
+    hashes / bounds / caps a residue-balanced share of the queries, one small all_gather puts the shares together.  (Until round 4
+    every rank ran the pre-pass over ALL queries before the shards existed.)"""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_queries(lens, world, st, ed)[rank]
+    mine = searcher.query_work(lo, hi) if hi > lo else np.zeros(0, dtype=np.int64)
+    return allgather_ragged(mine)
 
 
 _pinned = {}  # reusable pinned staging tensors, keyed by role

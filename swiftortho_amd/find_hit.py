@@ -85,18 +85,35 @@ def query_range(start, end, n_queries, ncpu=1):
 
 
 def run_single(p):
+    import time
+    laps, t0 = [], time.perf_counter()
+
+    def lap(name):   # SOHIT_TIMING=1: where the wall time of one command goes (stderr)
+        nonlocal t0
+        t1 = time.perf_counter()
+        laps.append((name, t1 - t0))
+        t0 = t1
     from . import fsearch
+    lap('import')
     s = fsearch.Searcher(**searcher_kwargs(p))
+    lap('create')
     try:
         s.load_ref(p['ref'], p['rstart'], p['rend'])
+        lap('load_ref')
         s.load_queries(p['qry'])
+        lap('load_queries')
         st, ed = query_range(p['start'], p['end'], s.num_queries, p['ngpu'])
         hits = s.search(st, ed)
+        lap('index+search')
         hits.write(p['outfile'], 'w')
+        lap('write')
         n = len(hits)
         hits.close()
     finally:
         s.close()
+    lap('close')
+    if os.environ.get('SOHIT_TIMING'):
+        sys.stderr.write('[find_hit] ' + ' '.join('%s=%.3f' % kv for kv in laps) + ' rows=%d\n' % n)
     return n
 
 
@@ -124,7 +141,7 @@ def run_rank(p):
         # shards balanced by per-query work (index entries visited + residues), not residues alone: family sizes are skewed
         weights = lens.copy()
         if ed > st:
-            weights[st:ed] += s.query_work(st, ed)
+            weights[st:ed] += sdist.sharded_query_work(s, lens, st, ed)   # the pre-pass itself is split over the ranks
         lo, hi = sdist.shard_queries(weights, world, st, ed)[rank]
         dev = s.search_device(lo, hi)   # hi == lo: an empty result, still takes part in the exchange
         g = sdist.gather_device_records(dev.tensor())

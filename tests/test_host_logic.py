@@ -115,6 +115,12 @@ lo, hi = sdist.shard_queries(lens, world)[rank]
 recs = np.zeros((hi - lo, 10), dtype=np.int64); recs[:, 0] = np.arange(lo, hi)
 if rank == 1: recs = recs[:0] if os.environ.get("EMPTY1") else recs
 parts = sdist.gather_bytes(recs.tobytes())
+# the work pre-pass split over the ranks: a stand-in searcher whose "work" of query i is 3 i + 1
+class S:
+    def query_work(self, a, b): return np.arange(a, b, dtype=np.int64) * 3 + 1
+w = sdist.sharded_query_work(S(), lens, 10, 90)
+assert np.array_equal(w, np.arange(10, 90) * 3 + 1), w[:5]
+assert len(sdist.sharded_query_work(S(), lens, 40, 40)) == 0
 if rank == 0:
     allr = np.frombuffer(b"".join(parts), dtype=np.int64).reshape(-1, 10)
     print("GATHERED", len(allr), int(allr[:, 0].sum()), bool(np.all(np.diff(allr[:, 0]) > 0)))
@@ -157,3 +163,31 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert p.stderr.count("bench.py needs a GPU") >= 1, p.stderr[-3000:]
     assert "local_rank: 1" in p.stderr, p.stderr[-3000:]
     assert '"metric"' not in p.stdout
+
+
+def test_row_formatter_equals_printf_and_oracle_f2s(oracle):
+    """The library formats "%f" itself (exact 128-bit integer arithmetic, round-half-even like glibc) and builds f2s (fsearch.py:43-61)
+    on it: identical to Python's '%f' and to the oracle's f2s over identities, mantissas, near-integers, exact ties (odd / 128),
+    e-values of every magnitude, negative values and the snprintf fallbacks (huge, inf, nan)."""
+    import ctypes as C
+    import numpy as np
+    from swiftortho_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(5)
+    aln = rng.integers(1, 5000, 200000)
+    parts = [rng.integers(0, aln + 1) * (100. / aln),                       # identities
+             10 ** rng.random(100000), -rng.random(50000) * 330, np.round(-rng.random(50000) * 330) + rng.normal(0, 1e-9, 50000),
+             (2 * rng.integers(0, 10 ** 6, 50000) + 1) / 128.0, -(2 * rng.integers(0, 10 ** 4, 5000) + 1) / 128.0,   # exact ties
+             10 ** rng.uniform(-320, 3, 200000), 10 ** rng.uniform(-6, 1, 50000), rng.random(50000) * 1e-6, rng.random(20000) * 1e14,
+             np.array([0.0, -0.0, 1e-3, 9.9999e-4, 1e-5, 2.88e-261, 0.5, 1e15, 1e16, 1e300, np.inf, -np.inf, np.nan, 5e-324, 999999.9999995, 0.9999995, 9.9999995]),
+             rng.integers(0, 2 ** 63, size=100000, dtype=np.uint64).view(np.float64)]
+    v = np.ascontiguousarray(np.concatenate(parts), dtype=np.float64)
+    out = np.empty(len(v) * 1400, dtype=np.uint8)
+    w = L.so_fmt_rows(C.c_void_p(v.ctypes.data), len(v), C.c_void_p(out.ctypes.data), len(out))
+    assert w > 0
+    rows = out[:w].tobytes().decode().split("\n")[:-1]
+    assert len(rows) == len(v)
+    for x, row in zip(v.tolist(), rows):
+        f, e = row.split("\t")
+        assert f == "%f" % x, (x, f)
+        assert e == oracle.f2s(x), (x, e, oracle.f2s(x))
