@@ -56,6 +56,14 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
+// the same ordering point when the tables live in LDS: nothing has to reach, or be re-read from, memory.  (The agent-scope pair above
+// writes the L2 back and invalidates the vector cache; the expansion kernel executed it once per matrix entry of every row, tables in
+// LDS or not -- 2.3 ms per pass over config 5's 89 k short rows where the arithmetic needs a tenth of that.)
+__device__ __forceinline__ void wave_fence_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 // ---- column normalisation ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mcl_colkeys(const u32* __restrict__ idx, u32 nnz, u64* __restrict__ keys, u32* __restrict__ pos) {
@@ -118,18 +126,18 @@ __global__ __launch_bounds__(256) void k_mcl_products(const u32* __restrict__ rp
 #define MCL_BIG_P 2048u
 #define MCL_BIG_T 4096u
 template <bool WRITE, int TIER /*0: <= MCL_SMALL_P products, 1: <= MCL_LDS_P, 2: the rest*/>
-__global__ __launch_bounds__(64) void k_mcl_spgemm(const u32* __restrict__ rp, const u32* __restrict__ idx, const float* __restrict__ val, u32 row_lo,
-                                                   u32 row_hi, const u32* __restrict__ P, const u64* __restrict__ soff, u32* __restrict__ scratch,
+__global__ __launch_bounds__(64) void k_mcl_spgemm(const u32* __restrict__ rp, const u32* __restrict__ idx, const float* __restrict__ val,
+                                                   const u32* __restrict__ rows /*the rows of this instance's tier (host-built list)*/, u32 nrows,
+                                                   const u32* __restrict__ P, const u64* __restrict__ soff, u32* __restrict__ scratch,
                                                    u32* __restrict__ ccnt, const u32* __restrict__ crp, u32* __restrict__ cidx, float* __restrict__ cval) {
     constexpr u32 TL = TIER == 0 ? MCL_SMALL_T : TIER == 1 ? MCL_LDS_T : MCL_BIG_T, PL = TIER == 0 ? MCL_SMALL_P : TIER == 1 ? MCL_LDS_P : MCL_BIG_P;
     __shared__ u32 s_keys[TL];
     __shared__ float s_sums[TL];
     __shared__ u32 s_ord[PL];
-    const u32 i = row_lo + blockIdx.x;
-    if (i >= row_hi) return;
+    if (blockIdx.x >= nrows) return;
+    const u32 i = rows[blockIdx.x];
     const u32 lane = threadIdx.x;
     const u32 Pi = P[i];
-    if (TIER == 0 ? Pi > MCL_SMALL_P : TIER == 1 ? (Pi <= MCL_SMALL_P || Pi > MCL_LDS_P) : Pi <= MCL_LDS_P) return;   // another instance's row
     u32 *keys, *ord;
     float* sums;
     u32 T;
@@ -141,34 +149,51 @@ __global__ __launch_bounds__(64) void k_mcl_spgemm(const u32* __restrict__ rp, c
         u32* base = scratch + soff[i];
         keys = base, sums = reinterpret_cast<float*>(base + T), ord = base + 2 * (size_t)T;
     }
+    const bool in_lds = Pi <= PL;   // (wave-uniform)
     for (u32 t = lane; t < T; t += 64) st_u(&keys[t], MCL_EMPTY), st_f(&sums[t], 0.f);
     for (u32 t = lane; t < Pi; t += 64) st_u(&ord[t], MCL_EMPTY);
-    wave_fence();
+    if (in_lds) wave_fence_lds();
+    else wave_fence();
+    // The entries a_ij of row i are consumed one after the other (scipy's accumulation order), but their descriptors -- column j, value,
+    // extent of row j -- are fetched 64 at a time by the lanes and handed out by lane index: per entry only row j's own entries are
+    // still a dependent load (round 3 walked three dependent loads deep per entry: a short row cost ~100 us of pure latency).
     u32 stepbase = 0;
-    for (u32 jj = rp[i]; jj < rp[i + 1]; ++jj) {
-        const u32 j = idx[jj];
-        const float v = val[jj];
-        const u32 rb = rp[j], rc = rp[j + 1] - rb;
-        for (u32 kk0 = 0; kk0 < rc; kk0 += 64) {
-            const u32 kk = kk0 + lane;
-            if (kk < rc) {
-                const u32 k = idx[rb + kk];
-                const float prod = __fmul_rn(v, val[rb + kk]);
-                u32 slot = mcl_hash(k, T - 1);
-                for (;;) {
-                    const u32 cur = atomicCAS(&keys[slot], MCL_EMPTY, k);
-                    if (cur == MCL_EMPTY) {
-                        st_u(&ord[stepbase + kk], slot);   // first touch of column k: its ordinal in scipy's linked list
-                        break;
-                    }
-                    if (cur == k) break;
-                    slot = (slot + 1) & (T - 1);
-                }
-                st_f(&sums[slot], __fadd_rn(ld_f(&sums[slot]), prod));   // the columns of one row are distinct: no other lane owns this slot now
-            }
+    const u32 r0 = rp[i], rn = rp[i + 1] - r0;
+    for (u32 eb = 0; eb < rn; eb += 64) {
+        u32 mrb = 0, mrc = 0;
+        float mv = 0.f;
+        if (eb + lane < rn) {
+            const u32 j = idx[r0 + eb + lane];
+            mv = val[r0 + eb + lane];
+            mrb = rp[j];
+            mrc = rp[j + 1] - mrb;
         }
-        wave_fence();
-        stepbase += rc;
+        const u32 cnt = min(64u, rn - eb);
+        for (u32 t = 0; t < cnt; ++t) {
+            const u32 rb = (u32)__shfl((int)mrb, (int)t), rc = (u32)__shfl((int)mrc, (int)t);
+            const float v = __shfl(mv, (int)t);
+            for (u32 kk0 = 0; kk0 < rc; kk0 += 64) {
+                const u32 kk = kk0 + lane;
+                if (kk < rc) {
+                    const u32 k = idx[rb + kk];
+                    const float prod = __fmul_rn(v, val[rb + kk]);
+                    u32 slot = mcl_hash(k, T - 1);
+                    for (;;) {
+                        const u32 cur = atomicCAS(&keys[slot], MCL_EMPTY, k);
+                        if (cur == MCL_EMPTY) {
+                            st_u(&ord[stepbase + kk], slot);   // first touch of column k: its ordinal in scipy's linked list
+                            break;
+                        }
+                        if (cur == k) break;
+                        slot = (slot + 1) & (T - 1);
+                    }
+                    st_f(&sums[slot], __fadd_rn(ld_f(&sums[slot]), prod));   // the columns of one row are distinct: no other lane owns this slot now
+                }
+            }
+            if (in_lds) wave_fence_lds();
+            else wave_fence();
+            stepbase += rc;
+        }
     }
     // output in reverse first-touch order, exact zeros dropped
     u32 outn = 0;
@@ -222,7 +247,8 @@ __global__ __launch_bounds__(64) void k_mcl_diff(const u32* __restrict__ rp, con
         keys = base, vals = reinterpret_cast<float*>(base + T), seen = base + 2 * (size_t)T;
     }
     for (u32 t = lane; t < T; t += 64) st_u(&keys[t], MCL_EMPTY), st_u(&seen[t], 0u);
-    wave_fence();
+    if (oc <= MCL_LDS_P) wave_fence_lds();
+    else wave_fence();
     for (u32 e = lane; e < oc; e += 64) {
         const u32 k = oidx[ob + e];
         u32 slot = mcl_hash(k, T - 1);
@@ -233,7 +259,8 @@ __global__ __launch_bounds__(64) void k_mcl_diff(const u32* __restrict__ rp, con
         }
         st_f(&vals[slot], oval[ob + e]);
     }
-    wave_fence();
+    if (oc <= MCL_LDS_P) wave_fence_lds();
+    else wave_fence();
     float m = 0.f;
     for (u32 e = lane; e < xc; e += 64) {
         const u32 k = idx[xb + e];
@@ -253,7 +280,8 @@ __global__ __launch_bounds__(64) void k_mcl_diff(const u32* __restrict__ rp, con
         const float t = __fsub_rn(fabsf(__fsub_rn(a, b)), __fmul_rn(rtol, fabsf(b)));
         if (m == m) m = (t != t) ? t : fmaxf(m, t);   // scipy's .max() hands a NaN on (np.maximum.reduce); fmaxf would drop it
     }
-    wave_fence();
+    if (oc <= MCL_LDS_P) wave_fence_lds();
+    else wave_fence();
     for (u32 t = lane; t < T; t += 64) {
         if (ld_u(&keys[t]) != MCL_EMPTY && ld_u(&seen[t]) == 0u) {   // stored in x_old only
             const float b = ld_f(&vals[t]);
@@ -273,7 +301,8 @@ __global__ __launch_bounds__(64) void k_mcl_diff(const u32* __restrict__ rp, con
 struct Mcl {
     hipStream_t st = nullptr;
     DevBuf<u64> ck, ck2;
-    DevBuf<u32> cp, cp2, flags, P, ccnt, scratch, small;
+    DevBuf<u32> cp, cp2, flags, P, ccnt, scratch, small, rows;
+    std::vector<u32> tier_rows;
     DevBuf<u64> soff;
     DevBuf<float> y;
     DevBuf<u8> sort_tmp;
@@ -346,14 +375,49 @@ struct Mcl {
         }
         scratch.ensure(maxw + 64);
         HIP_CHECK(hipMemcpyAsync(soff.p, hoff.data(), (size_t)n * sizeof(u64), hipMemcpyHostToDevice, st));
-        for (auto& r : ranges)
-            if (r.second > r.first)
-            {
-                const dim3 g(r.second - r.first), bl(64);
-                hipLaunchKernelGGL((k_mcl_spgemm<false, 0>), g, bl, 0, st, x.rp.p, x.idx.p, x.val.p, r.first, r.second, P.p, soff.p, scratch.p, ccnt.p, nullptr, nullptr, nullptr);
-                hipLaunchKernelGGL((k_mcl_spgemm<false, 1>), g, bl, 0, st, x.rp.p, x.idx.p, x.val.p, r.first, r.second, P.p, soff.p, scratch.p, ccnt.p, nullptr, nullptr, nullptr);
-                hipLaunchKernelGGL((k_mcl_spgemm<false, 2>), g, bl, 0, st, x.rp.p, x.idx.p, x.val.p, r.first, r.second, P.p, soff.p, scratch.p, ccnt.p, nullptr, nullptr, nullptr);
+        // The three instances of the kernel each get the LIST of their rows (by products per row, known on the host anyway).  Until
+        // round 4 every instance was launched over all rows and a workgroup of another tier left at once: after the first rounds
+        // nearly every row of a Markov matrix is a tier-0 row, and the two big-table instances spent 1.6 ms each per pass starting
+        // 89 k workgroups (40 KB of LDS apiece) that had nothing to do -- two thirds of the loop's time on config 5.
+        // tier_rows = [tier 0 | tier 1 | tier 2] per range of rows; tier_at[range][t] = (first, count)
+        tier_rows.assign(n, 0);
+        std::vector<std::array<std::pair<u32, u32>, 3>> tier_at(ranges.size());
+        {
+            u32 at = 0;
+            for (size_t ri = 0; ri < ranges.size(); ++ri)
+                for (int t = 0; t < 3; ++t) {
+                    const u32 first = at;
+                    for (u32 i = ranges[ri].first; i < ranges[ri].second; ++i) {
+                        const u32 Pi = hP[i];
+                        const int ti = Pi <= MCL_SMALL_P ? 0 : Pi <= MCL_LDS_P ? 1 : 2;
+                        if (ti == t) tier_rows[at++] = i;
+                    }
+                    tier_at[ri][t] = {first, at - first};
+                }
+        }
+        rows.ensure((size_t)n + 4);
+        if (n) HIP_CHECK(hipMemcpyAsync(rows.p, tier_rows.data(), (size_t)n * sizeof(u32), hipMemcpyHostToDevice, st));
+        auto launch_tiers = [&](bool write, size_t ri) {
+            for (int t = 0; t < 3; ++t) {
+                const u32 first = tier_at[ri][t].first, cnt = tier_at[ri][t].second;
+                if (!cnt) continue;
+                const dim3 g(cnt), bl(64);
+                const u32* rl = rows.p + first;
+#define MCL_GO(W, T) hipLaunchKernelGGL((k_mcl_spgemm<W, T>), g, bl, 0, st, x.rp.p, x.idx.p, x.val.p, rl, cnt, P.p, soff.p, scratch.p, ccnt.p, \
+                                        W ? c.rp.p : nullptr, W ? c.idx.p : nullptr, W ? c.val.p : nullptr)
+                if (write) {
+                    if (t == 0) MCL_GO(true, 0);
+                    else if (t == 1) MCL_GO(true, 1);
+                    else MCL_GO(true, 2);
+                } else {
+                    if (t == 0) MCL_GO(false, 0);
+                    else if (t == 1) MCL_GO(false, 1);
+                    else MCL_GO(false, 2);
+                }
+#undef MCL_GO
             }
+        };
+        for (size_t ri = 0; ri < ranges.size(); ++ri) launch_tiers(false, ri);
         HIP_CHECK(hipMemsetAsync(ccnt.p + n, 0, sizeof(u32), st));
         scan_tmp.ensure(scan_u32_temp_elems((size_t)n + 1) + 8);
         const u32* tot = scan_u32(ccnt.p, c.rp.p, (size_t)n + 1, false, scan_tmp.p, st);
@@ -362,14 +426,7 @@ struct Mcl {
         HIP_CHECK(hipStreamSynchronize(st));
         c.nnz = nnz;
         c.idx.ensure((size_t)nnz + 2), c.val.ensure((size_t)nnz + 2);
-        for (auto& r : ranges)
-            if (r.second > r.first)
-            {
-                const dim3 g(r.second - r.first), bl(64);
-                hipLaunchKernelGGL((k_mcl_spgemm<true, 0>), g, bl, 0, st, x.rp.p, x.idx.p, x.val.p, r.first, r.second, P.p, soff.p, scratch.p, ccnt.p, c.rp.p, c.idx.p, c.val.p);
-                hipLaunchKernelGGL((k_mcl_spgemm<true, 1>), g, bl, 0, st, x.rp.p, x.idx.p, x.val.p, r.first, r.second, P.p, soff.p, scratch.p, ccnt.p, c.rp.p, c.idx.p, c.val.p);
-                hipLaunchKernelGGL((k_mcl_spgemm<true, 2>), g, bl, 0, st, x.rp.p, x.idx.p, x.val.p, r.first, r.second, P.p, soff.p, scratch.p, ccnt.p, c.rp.p, c.idx.p, c.val.p);
-            }
+        for (size_t ri = 0; ri < ranges.size(); ++ri) launch_tiers(true, ri);
     }
 
     bool converged(const Csr& x, const Csr& old, float rtol, float atol) {
