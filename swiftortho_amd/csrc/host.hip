@@ -1090,14 +1090,14 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     ChunkIndex& ch = *c->chunks[ci];
     const u32 p_lo = b.h_off[qa] + qa, p_hi = b.h_off[qb] + qb;
     const int AS = c->cfg.A * c->cfg.S;
-    const u32 Ppad = b.dev.Ppad;
-    const size_t T = (size_t)AS * Ppad;
     const u32 nseq_chunk = (u32)(ch.seq_hi - ch.seq_lo);
     u32* qcnt = b.ccnt.p + (size_t)ci * b.nq;
-    launch_effcnt(b.mark.p, b.scnt.p, Ppad, AS, p_lo, p_hi, b.eff.p, b.nz.p, c->st);
-    const u32* dH = scan_u32(b.eff.p, b.hoff.p, T, false, c->d_scan_tmp.p, c->st);
+    // hit counts, their scan (hit ordinals) and the seed compaction run over the pass's own seed slots [t_lo, t_lo + Tp)
+    const size_t t_lo = (size_t)AS * p_lo, Tp = (size_t)AS * (p_hi - p_lo);
+    launch_effcnt(b.mark.p, b.scnt.p, AS, p_lo, p_hi, b.eff.p, b.nz.p, c->st);
+    const u32* dH = scan_u32(b.eff.p + t_lo, b.hoff.p + t_lo, Tp, false, c->d_scan_tmp.p, c->st);
     stash_u32(c, dH, 0);  // the scan's total lives in d_scan_tmp: park it before the next scan
-    const u32* dK = scan_u32(b.nz.p, b.cidx.p, T, false, c->d_scan_tmp.p, c->st);
+    const u32* dK = scan_u32(b.nz.p + t_lo, b.cidx.p + t_lo, Tp, false, c->d_scan_tmp.p, c->st);
     u32 H, K;
     d2h_pair(c, dK, H, K);
     sc.lap("seed.bounds_cap_scan");
@@ -1148,7 +1148,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     if (klr.sh_subj + klr.bs > 64) throw SoError("pass-record key exceeds 64 bits: sequences too long for this build");
     if (kl.ba + kl.bp + ft_bits_entry > 64) throw SoError("first-touch key exceeds 64 bits: sequences too long for this build");
     b.cs_hoff.ensure((size_t)K + 2), b.cs_beg.ensure((size_t)K + 2), b.cs_kbase.ensure((size_t)K + 2);
-    launch_compact_seeds(b.eff.p, b.hoff.p, b.cidx.p, b.sbeg.p, b.dev.d_pseq.p, b.dev.d_off.p, Ppad, AS, kl, b.cs_hoff.p, b.cs_beg.p,
+    launch_compact_seeds(b.eff.p, b.hoff.p, b.cidx.p, b.sbeg.p, b.dev.d_pseq.p, b.dev.d_off.p, p_lo, p_hi, AS, kl, b.cs_hoff.p, b.cs_beg.p,
                          b.cs_kbase.p, c->st);
     // per-entry key addends: the 4-byte compact form whenever the fields fit, else 8-byte ones for this layout
     const u32* dk32 = compact ? enc->dk32.p : nullptr;
@@ -1202,7 +1202,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         const u32 nb = L.R * nqp;
         // tiles: <= 1024 consecutive hit ordinals of one query
         b.qseg.ensure((size_t)b.nq + 4);
-        launch_query_segments(b.hoff.p, T, b.dev.d_off.p, b.nq, AS, H, b.qseg.p, c->st);
+        launch_query_segments(b.hoff.p, b.dev.d_off.p, qa, qb, AS, H, b.qseg.p, c->st);
         const u32* qseg = b.qseg.p + qa;
         b.bt0.ensure((size_t)nqp + 4);
         launch_bkt_ntiles(qseg, nqp, b.bt0.p, c->st);
@@ -1291,7 +1291,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     const u32 nseg = qb - qa;
     if (seg_mode && nseg >= 256) {
         b.qseg.ensure((size_t)b.nq + 4);
-        launch_query_segments(b.hoff.p, T, b.dev.d_off.p, b.nq, AS, H, b.qseg.p, c->st);
+        launch_query_segments(b.hoff.p, b.dev.d_off.p, qa, qb, AS, H, b.qseg.p, c->st);
         ensure_sort_tmp(c, sort_keys_u64_seg_temp_bytes(H, nseg, kl.sh_diag, kl.sh_q));
         sort_keys_u64_seg(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.keys.p, b.keys2.p, H, nseg, b.qseg.p + qa, kl.sh_diag, kl.sh_q, c->st);
     } else {
@@ -1383,7 +1383,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         const u32* dS = scan_u32(b.flags.p, b.gidx.p, NP, false, c->d_scan_tmp.p, c->st);
         // per-query candidate segments and the longest one (d_small[0]), fetched with the candidate total
         b.qseg.ensure((size_t)b.nq + 4);
-        launch_qseg(b.p_qs2.p, NP, b.gidx.p, dS, klr.bs, b.nq, b.qseg.p, c->d_small.p, c->st);
+        launch_qseg(b.p_qs2.p, NP, b.gidx.p, dS, klr.bs, qa, qb, b.qseg.p, c->d_small.p, c->st);
         d2h_pair(c, dS, maxseg, NS);
         b.shead.ensure((size_t)NS + 2);
         if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] seed pass: queries %u..%u hits %u seeds %u pass records %u candidates %u\n", qa, qb, H, K, NP, NS);
@@ -1407,7 +1407,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         if ((u64)base + NS >= (lim ? (u64)atoll(lim) : 0xFFFFFFF0ull)) throw CandOverflow();
         b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
         b.cand_rec.ensure(4 * ((size_t)base + NS) + 16, true, c->st);
-        launch_cand_order_lds(c_ftp, c_recp, b.qseg.p, b.nq, maxseg, bsp, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, c->st);
+        launch_cand_order_lds(c_ftp, c_recp, b.qseg.p, qa, qb, maxseg, bsp, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, c->st);
         b.chunk_base.back() = base + NS;
         c->cnt.candidates += NS;
         sc.lap("group.best_order");

@@ -631,8 +631,9 @@ __global__ __launch_bounds__(256) void k_seg_counts(const u32* __restrict__ out_
 // the same copy -- knows whether every segment fits the LDS sort; k_cand_order_lds then does, in ONE launch, what the library
 // path needs an index fill, a key build, a 7-pass device-wide radix sort, a gather and a count kernel for.
 __global__ __launch_bounds__(256) void k_qseg(const u64* __restrict__ sorted_qs, u32 n, const u32* __restrict__ gidx, const u32* __restrict__ total,
-                                              int bs, u32 nq, u32* __restrict__ seg /*nq + 1*/, u32* __restrict__ maxseg) {
-    const u32 q = blockIdx.x * 256u + threadIdx.x;
+                                              int bs, u32 q0, u32 nq /*queries [q0, nq) of the batch: the pass's*/, u32* __restrict__ seg /*entries [q0, nq]*/,
+                                              u32* __restrict__ maxseg) {
+    const u32 q = q0 + blockIdx.x * 256u + threadIdx.x;
     auto first_cand = [&](u32 qq) -> u32 {
         const u64 key = (u64)qq << bs;
         u32 lo = 0, hi = n;
@@ -657,10 +658,10 @@ __global__ __launch_bounds__(256) void k_qseg(const u64* __restrict__ sorted_qs,
 // One wave per query: sort word = (first-touch word << LB) | position in the segment (unique: ties keep the (query, subject) order,
 // as the stable library sort does), bitonic network over the next power of two, then the records are gathered in that order.
 template <int CAP, int LB>
-__global__ __launch_bounds__(64) void k_cand_order_lds(const u64* __restrict__ c_ft, const u32* __restrict__ c_rec, const u32* __restrict__ seg,
+__global__ __launch_bounds__(64) void k_cand_order_lds(const u64* __restrict__ c_ft, const u32* __restrict__ c_rec, const u32* __restrict__ seg, u32 q0,
                                                        int bsp, u32* __restrict__ out_q, u32* __restrict__ out_rec, u32* __restrict__ qcnt) {
     __shared__ u64 s_key[CAP];
-    const u32 q = blockIdx.x, lane = threadIdx.x;
+    const u32 q = q0 + blockIdx.x, lane = threadIdx.x;
     const u32 a = seg[q], n = seg[q + 1] - a;
     if (!n) return;
     if (lane == 0) qcnt[q] = n;
@@ -702,17 +703,17 @@ __global__ __launch_bounds__(64) void k_cand_order_lds(const u64* __restrict__ c
 int cand_order_lds_max() { return 2048; }
 int cand_order_lds_key_bits() { return 64 - 11; }  // widest first-touch word the packed sort word holds
 
-void launch_qseg(const u64* sorted_qs, u32 n, const u32* gidx, const u32* total, int bs, u32 nq, u32* seg, u32* maxseg, hipStream_t st) {
-    hipLaunchKernelGGL(k_qseg, dim3((nq + 1 + 255) / 256), dim3(256), 0, st, sorted_qs, n, gidx, total, bs, nq, seg, maxseg);
+void launch_qseg(const u64* sorted_qs, u32 n, const u32* gidx, const u32* total, int bs, u32 q0, u32 q1, u32* seg, u32* maxseg, hipStream_t st) {
+    hipLaunchKernelGGL(k_qseg, dim3((q1 - q0 + 1 + 255) / 256), dim3(256), 0, st, sorted_qs, n, gidx, total, bs, q0, q1, seg, maxseg);
 }
 
-void launch_cand_order_lds(const u64* c_ft, const u32* c_rec, const u32* seg, u32 nq, u32 maxseg, int bsp, u32* out_q, u32* out_rec, u32* qcnt,
+void launch_cand_order_lds(const u64* c_ft, const u32* c_rec, const u32* seg, u32 q0, u32 q1, u32 maxseg, int bsp, u32* out_q, u32* out_rec, u32* qcnt,
                            hipStream_t st) {
-    if (!nq) return;
+    if (q1 <= q0) return;
     if (maxseg <= 256)
-        hipLaunchKernelGGL((k_cand_order_lds<256, 11>), dim3(nq), dim3(64), 0, st, c_ft, c_rec, seg, bsp, out_q, out_rec, qcnt);
+        hipLaunchKernelGGL((k_cand_order_lds<256, 11>), dim3(q1 - q0), dim3(64), 0, st, c_ft, c_rec, seg, q0, bsp, out_q, out_rec, qcnt);
     else
-        hipLaunchKernelGGL((k_cand_order_lds<2048, 11>), dim3(nq), dim3(64), 0, st, c_ft, c_rec, seg, bsp, out_q, out_rec, qcnt);
+        hipLaunchKernelGGL((k_cand_order_lds<2048, 11>), dim3(q1 - q0), dim3(64), 0, st, c_ft, c_rec, seg, q0, bsp, out_q, out_rec, qcnt);
 }
 
 // ---- launch wrappers -------------------------------------------------------------------------------

@@ -185,12 +185,14 @@ __global__ __launch_bounds__(256) void k_cap(const u32* __restrict__ korder, con
 }
 
 // ---- effective per-seed hit counts + compaction of non-empty seeds --------------------------------
-__global__ __launch_bounds__(256) void k_effcnt(const u8* __restrict__ mark, const u32* __restrict__ scnt, u32 Ppad, int AS,
-                                                u32 p_lo, u32 p_hi, u32* __restrict__ eff, u32* __restrict__ nz) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (size_t)AS * Ppad) return;
+// (a pass touches the seed slots of ITS queries only, [AS * p_lo, AS * p_hi): with several passes per chunk -- one per query length
+// class -- whole-batch sweeps per pass added up)
+__global__ __launch_bounds__(256) void k_effcnt(const u8* __restrict__ mark, const u32* __restrict__ scnt, int AS, size_t t_lo, size_t t_hi,
+                                                u32* __restrict__ eff, u32* __restrict__ nz) {
+    const size_t t = t_lo + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= t_hi) return;
     const u32 p = (u32)(t / AS);
-    u32 c = (mark[p] && p >= p_lo && p < p_hi) ? scnt[t] : 0u;  // [p_lo, p_hi): packed range of the query sub-range
+    u32 c = mark[p] ? scnt[t] : 0u;
     eff[t] = c;
     nz[t] = c ? 1u : 0u;
 }
@@ -202,11 +204,11 @@ __global__ __launch_bounds__(256) void k_effcnt(const u8* __restrict__ mark, con
 //   key = kbase + D(entry)      (k_index.hip: k_encode_delta).
 __global__ __launch_bounds__(256) void k_compact_seeds(const u32* __restrict__ eff, const u32* __restrict__ hoff,
                                                        const u32* __restrict__ cidx, const u32* __restrict__ sbeg,
-                                                       const u32* __restrict__ q_pseq, const u32* __restrict__ qoff, u32 Ppad, int AS,
+                                                       const u32* __restrict__ q_pseq, const u32* __restrict__ qoff, size_t t_lo, size_t t_hi, int AS,
                                                        KeyLayout kl, u32* __restrict__ cs_hoff, u32* __restrict__ cs_base,
                                                        u64* __restrict__ cs_kbase) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (size_t)AS * Ppad) return;
+    const size_t t = t_lo + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= t_hi) return;
     if (!eff[t]) return;
     const u32 as = (u32)(t % AS), p = (u32)(t / AS);
     const u32 k = cidx[t];
@@ -437,18 +439,18 @@ void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32*
     hipLaunchKernelGGL(k_cap, dim3((nq + 3) / 4), dim3(256), 0, st, korder, qoff, nq, mink, pcnt, threshold, mark, qhits);
 }
 
-void launch_effcnt(const u8* mark, const u32* scnt, u32 Ppad, int AS, u32 p_lo, u32 p_hi, u32* eff, u32* nz, hipStream_t st) {
-    size_t T = (size_t)AS * Ppad;
-    if (!T) return;
-    hipLaunchKernelGGL(k_effcnt, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, mark, scnt, Ppad, AS, p_lo, p_hi, eff, nz);
+void launch_effcnt(const u8* mark, const u32* scnt, int AS, u32 p_lo, u32 p_hi, u32* eff, u32* nz, hipStream_t st) {
+    const size_t t_lo = (size_t)AS * p_lo, t_hi = (size_t)AS * p_hi;
+    if (t_hi <= t_lo) return;
+    hipLaunchKernelGGL(k_effcnt, dim3((unsigned)((t_hi - t_lo + 255) / 256)), dim3(256), 0, st, mark, scnt, AS, t_lo, t_hi, eff, nz);
 }
 
 void launch_compact_seeds(const u32* eff, const u32* hoff, const u32* cidx, const u32* sbeg, const u32* q_pseq, const u32* qoff,
-                          u32 Ppad, int AS, const KeyLayout& kl, u32* cs_hoff, u32* cs_base, u64* cs_kbase, hipStream_t st) {
-    size_t T = (size_t)AS * Ppad;
-    if (!T) return;
-    hipLaunchKernelGGL(k_compact_seeds, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, eff, hoff, cidx, sbeg, q_pseq, qoff,
-                       Ppad, AS, kl, cs_hoff, cs_base, cs_kbase);
+                          u32 p_lo, u32 p_hi, int AS, const KeyLayout& kl, u32* cs_hoff, u32* cs_base, u64* cs_kbase, hipStream_t st) {
+    const size_t t_lo = (size_t)AS * p_lo, t_hi = (size_t)AS * p_hi;
+    if (t_hi <= t_lo) return;
+    hipLaunchKernelGGL(k_compact_seeds, dim3((unsigned)((t_hi - t_lo + 255) / 256)), dim3(256), 0, st, eff, hoff, cidx, sbeg, q_pseq, qoff,
+                       t_lo, t_hi, AS, kl, cs_hoff, cs_base, cs_kbase);
 }
 
 u32 lookup_num_blocks(u32 H) { return (H + 64u * lw_iters() - 1) / (64u * lw_iters()); }  // number of lookup WAVES

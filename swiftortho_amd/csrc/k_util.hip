@@ -195,15 +195,15 @@ void fill_u32(u32* p, size_t n, u32 v, hipStream_t st) {
 
 // first hit ordinal of every query of the batch (position-major seed ordinals): the segments of the per-query sorts and the tiles of the
 // bucketed passes.  (Lives here, not next to the segmented sorts: launching it must not load their large code object.)
-__global__ __launch_bounds__(256) void k_query_segments(const u32* __restrict__ hoff, size_t T, const u32* __restrict__ qoff, u32 nq, int AS,
-                                                        u32 H, u32* __restrict__ seg /*nq + 1*/) {
-    const u32 q = blockIdx.x * 256u + threadIdx.x;
-    if (q > nq) return;
+__global__ __launch_bounds__(256) void k_query_segments(const u32* __restrict__ hoff, const u32* __restrict__ qoff, u32 qa, u32 qb, int AS,
+                                                        u32 H, u32* __restrict__ seg /*entries [qa, qb] written*/) {
+    const u32 q = qa + blockIdx.x * 256u + threadIdx.x;
+    if (q > qb) return;
     const size_t t = ((size_t)qoff[q] + q) * (size_t)AS;  // first seed slot of query q (position-major ordinals)
-    seg[q] = t < T ? hoff[t] : H;
+    seg[q] = q < qb ? hoff[t] : H;                        // (hoff: the pass's exclusive scan, valid on the pass's slots)
 }
 
-void launch_query_segments(const u32* hoff, size_t T, const u32* qoff, u32 nq, int AS, u32 H, u32* seg, hipStream_t st) {
-    hipLaunchKernelGGL(k_query_segments, dim3((nq + 1 + 255) / 256), dim3(256), 0, st, hoff, T, qoff, nq, AS, H, seg);
+void launch_query_segments(const u32* hoff, const u32* qoff, u32 qa, u32 qb, int AS, u32 H, u32* seg, hipStream_t st) {
+    hipLaunchKernelGGL(k_query_segments, dim3((qb - qa + 1 + 255) / 256), dim3(256), 0, st, hoff, qoff, qa, qb, AS, H, seg);
 }
 

@@ -12,7 +12,8 @@ void fill_u32(u32* p, size_t n, u32 v, hipStream_t st);
 // k_sort.hip
 size_t sort_keys_u64_temp_bytes(size_t n, int bits);
 void sort_keys_u64(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, int begin_bit, int end_bit, hipStream_t st);
-void launch_query_segments(const u32* hoff, size_t T, const u32* qoff, u32 nq, int AS, u32 H, u32* seg, hipStream_t st);
+// seg[q] = first hit ordinal of batch query q in the pass, q in [qa, qb] (seg[qb] = H)
+void launch_query_segments(const u32* hoff, const u32* qoff, u32 qa, u32 qb, int AS, u32 H, u32* seg, hipStream_t st);
 size_t sort_keys_u64_seg_temp_bytes(size_t n, u32 nseg, int begin_bit, int end_bit);
 void sort_keys_u64_seg(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* seg, int begin_bit,
                        int end_bit, hipStream_t st);
@@ -65,9 +66,10 @@ void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, u32 q_long /*fi
 int ksc_lds_max();
 void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark,
                 unsigned long long* qhits, hipStream_t st);
-void launch_effcnt(const u8* mark, const u32* scnt, u32 Ppad, int AS, u32 p_lo, u32 p_hi, u32* eff, u32* nz, hipStream_t st);
+// (these two work on the pass's seed slots only, [AS * p_lo, AS * p_hi))
+void launch_effcnt(const u8* mark, const u32* scnt, int AS, u32 p_lo, u32 p_hi, u32* eff, u32* nz, hipStream_t st);
 void launch_compact_seeds(const u32* eff, const u32* hoff, const u32* cidx, const u32* sbeg, const u32* q_pseq, const u32* qoff,
-                          u32 Ppad, int AS, const KeyLayout& kl, u32* cs_hoff, u32* cs_beg, u64* cs_kbase, hipStream_t st);
+                          u32 p_lo, u32 p_hi, int AS, const KeyLayout& kl, u32* cs_hoff, u32* cs_beg, u64* cs_kbase, hipStream_t st);
 u32 lookup_num_blocks(u32 H);
 void launch_lookup_blockfirst(const u32* cs_hoff, u32 K, u32 H, u32* wave_first, hipStream_t st);
 void launch_lookup(const u32* cs_hoff, const u32* cs_base, const u64* cs_kbase, const u32* wave_first, u32 K, u32 H,
@@ -93,8 +95,9 @@ void launch_compact_shards(const u32* shard_cnt, u32* shard_off, u32 shard_cap, 
 void launch_seg_flags(const u64* sorted_qs, u32 n, u32* flags, u32* zero_word /*set to 0 (may be null)*/, hipStream_t st);
 int cand_order_lds_max();
 int cand_order_lds_key_bits();
-void launch_qseg(const u64* sorted_qs, u32 n, const u32* gidx, const u32* total, int bs, u32 nq, u32* seg, u32* maxseg, hipStream_t st);
-void launch_cand_order_lds(const u64* c_ft, const u32* c_rec, const u32* seg, u32 nq, u32 maxseg, int bsp, u32* out_q, u32* out_rec, u32* qcnt,
+// (both over the pass's queries [q0, q1) of the batch)
+void launch_qseg(const u64* sorted_qs, u32 n, const u32* gidx, const u32* total, int bs, u32 q0, u32 q1, u32* seg, u32* maxseg, hipStream_t st);
+void launch_cand_order_lds(const u64* c_ft, const u32* c_rec, const u32* seg, u32 q0, u32 q1, u32 maxseg, int bsp, u32* out_q, u32* out_rec, u32* qcnt,
                            hipStream_t st);
 void launch_best(const u64* sorted_qs, const u32* idx, const u32* shead, u32 nseg, u32 n, const u64* p_sd, const u64* p_ft,
                  u32 seq_lo, int bs, u64* c_ft, u32* c_q, u32* c_rec, hipStream_t st);
