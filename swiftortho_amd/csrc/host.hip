@@ -795,6 +795,7 @@ struct Batch {
     DevBuf<int> bits, outrec;
     DevBuf<u32> trace;
     DevBuf<u32> tr_units, tr_ofs;   // trace room per task of a launch list and its exclusive scan (k_trace_units)
+    DevBuf<u32> tl_sorted, al_sorted;   // the trace pass's lists ordered by band rows (mixed-length batches)
 };
 
 // length classes of the queries: < 512 residues, < 1024, < 2048, < 4096, longer (the aligner's tiled path).  A pass's key widths and
@@ -1874,6 +1875,35 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         // (b.tr_ofs) when the whole list fits the budget, else slabs of the batch-wide stride
         const u32* tlist = nspec ? b.sel_b.p : slist;
         const u32 tn = nspec ? pb[parts] : NO;
+        const u32* alist = b.sel_a.p;   // (nspec) rows that only need the walk
+        // On a batch of mixed lengths the lists are ordered by band rows inside each emission range: k_align runs four alignments per
+        // wave and k_traceback sixty-four walks, and either lasts as long as its longest (on uniform lengths the sort costs more than
+        // it saves -- config 3: 9.1 -> 9.9 ms -- hence the test).  The traces' offsets follow the ordered list.
+        const bool order_rows = (b.permuted || (u64)b.maxqlen * b.nq > 3ull * b.h_off[b.nq] / 2) &&
+                                !(getenv("SOHIT_TRACE_SORT") && atoi(getenv("SOHIT_TRACE_SORT")) == 0);
+        if (order_rows) {
+            auto order_list = [&](const u32* in, u32 t0, u32 t1, u32* out) {   // [t0, t1) of `in`, longest band first, to the same range of `out`
+                const u32 n = t1 - t0;
+                if (!n) return;
+                b.tmp64.ensure((size_t)n + 2), b.c_ft2.ensure((size_t)n + 2);
+                ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(n, 64));
+                launch_task_rows(b.tasks.p, in + t0, n, b.dev.d_off.p, c->ref.d_off.p, b.dev.d_bound.p, c->ref.d_bound.p, 0, 0u, nullptr, nullptr, b.tmp64.p, c->st);
+                sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, in + t0, out + t0, n, 13, c->st);
+            };
+            b.tl_sorted.ensure((size_t)tn + 4);
+            if (nspec) b.al_sorted.ensure((size_t)(NO - tn) + 4);
+            for (int p = 0; p < parts; ++p) {
+                const u32 r0 = parts > 1 ? part_row[p] : 0u, r1 = parts > 1 ? part_row[p + 1] : NO;
+                if (nspec) {
+                    order_list(tlist, pb[p], pb[p + 1], b.tl_sorted.p);
+                    order_list(alist, r0 - pb[p], r1 - pb[p + 1], b.al_sorted.p);
+                } else {
+                    order_list(tlist, r0, r1, b.tl_sorted.p);
+                }
+            }
+            tlist = b.tl_sorted.p;
+            if (nspec) alist = b.al_sorted.p;
+        }
         const size_t tw = tn ? trace_offsets(tlist, tn) : 0;
         const bool tvar = tw <= var_budget_words;
         b.trace.ensure(tvar ? tw + 64 : (size_t)std::min(slab, std::max<u32>(maxpart, 1)) * stride + 64);
@@ -1897,7 +1927,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                 const u32 b0 = pb[p], b1 = pb[p + 1], a0 = r0 - b0, a1 = r1 - b1;
                 ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
                 align_traced(b0, b1);
-                launch_traceback(b.tasks.p, b.sel_a.p + a0, a1 - a0, b.dev.d_res.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_off.p, b.spec_trace.p, TU,
+                launch_traceback(b.tasks.p, alist + a0, a1 - a0, b.dev.d_res.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_off.p, b.spec_trace.p, TU,
                                  b.tpos.p, b.ares.p, c->st);
                 pt.stop();
             } else if (r1 > r0) {

@@ -1,0 +1,21 @@
+#!/bin/bash
+# randomised GPU-vs-oracle differentials (tools/diag/fuzz_parity.py) under the path switches that matter:
+#   bash tools/diag/fuzz.sh <cases per mode> <seed> [modes...]      modes: default bucket poison long het hetbucket w64 nobands
+N=${1:-30}; SEED=${2:-1}; shift; shift
+MODES=${@:-default bucket het hetbucket}
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+for m in $MODES; do
+  case $m in
+    default)   E="";;
+    bucket)    E="SOHIT_BUCKET_MIN=0";;
+    poison)    E="SOHIT_POISON=0xFF SOHIT_BUCKET_MIN=0";;
+    long)      E="FUZZ_LONG=1";;
+    het)       E="FUZZ_HET=1";;
+    hetbucket) E="FUZZ_HET=1 SOHIT_BUCKET_MIN=0 SOHIT_POISON=0xA5";;
+    w64)       E="FUZZ_HET=1 SOHIT_BUCKET_MIN=0 SOHIT_UG_W32=0";;
+    nobands)   E="FUZZ_HET=1 SOHIT_BUCKET_MIN=0 SOHIT_BANDS=0";;
+  esac
+  env $E python3 tools/diag/fuzz_parity.py $N $SEED > gpurun_out/fuzz_$m.log 2>&1
+  echo "$m rc=$? ok=$(grep -c ' ok ' gpurun_out/fuzz_$m.log) fail=$(grep -c FAIL gpurun_out/fuzz_$m.log)"
+  grep -B3 FAIL gpurun_out/fuzz_$m.log | tail -8
+done

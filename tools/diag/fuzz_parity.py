@@ -21,7 +21,11 @@ for case in range(ncase):
     if os.environ.get("FUZZ_LONG"):  # few, long sequences: tiled alignments, wide position fields
         N = int(rng.integers(20, 120)); L = int(rng.integers(500, 6000))
     uniform = rng.random() < 0.25
-    fa = (synthprot.uniform_proteins if uniform else synthprot.synthprot)(N, L, int(rng.integers(1, 1 << 30)))
+    if os.environ.get("FUZZ_HET") and rng.random() < 0.7:  # log-normal lengths with a tail and one 30 000-residue protein: every length class in one batch
+        N = int(rng.integers(120, 900))
+        fa = synthprot.synthprot(N, seed=int(rng.integers(1, 1 << 30)), lengths="lognormal")
+    else:
+        fa = (synthprot.uniform_proteins if uniform else synthprot.synthprot)(N, L, int(rng.integers(1, 1 << 30)))
     if rng.random() < 0.35:  # odd residues: gap / stop characters, masked and ambiguous letters, lower case, a '\r'
         lines = fa.split(b"\n")
         odd = b"-*xXUuBZJO.a" + b"lkde\r"
