@@ -11,7 +11,7 @@
 // also carries the query bits).
 // rocPRIM ships no tuned segmented-sort configuration for gfx950 and falls back to its generic one (6-bit digits,
 // 128 x 17 keys per block: four passes over our 24 bits).  Measured on config 2 (247 M keys, 10 k segments;
-// tools/diag/sort_sweep.sh): generic 5.09 ms; 8-bit digits with 256 x 8 keys 4.16, 256 x 16 keys 3.97-4.06 (default
+// generic 5.09 ms; 8-bit digits with 256 x 8 keys 4.16, 256 x 16 keys 3.97-4.06 (default
 // here), 256 x 32 6.0, 512 x 16 4.64, 1024 x 8 4.35.  SOHIT_SEG_CFG selects (0 = library default).
 template <int IPT, int BLOCK = 256, int BITS = 8>
 using SegCfg = rocprim::segmented_radix_sort_config<BITS, rocprim::kernel_config<BLOCK, IPT>, rocprim::WarpSortConfig<8, 4, 256, 64, 16, 8, 256>, true>;

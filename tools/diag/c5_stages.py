@@ -1,5 +1,5 @@
 """BASELINE config 5 (100k-protein find_hit -> find_orth -> find_cluster -a mcl -I 1.5): stage wall times on the GPU box, the three
-drop-in CLIs and the in-process flow that hands hit RECORDS to find_orth.   python tools/diag/r03_c5_stages.py [proteins]"""
+drop-in CLIs and the in-process flow that hands hit RECORDS to find_orth.   python tools/diag/c5_stages.py [proteins]"""
 import hashlib, json, os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -1,4 +1,4 @@
-"""where find_cluster's time goes on config 5: python tools/diag/r03_mclprof.py prepare <dir>  /  ... run <dir>"""
+"""where find_cluster's time goes on config 5: python tools/diag/mclprof.py prepare <dir>  /  ... run <dir>"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
