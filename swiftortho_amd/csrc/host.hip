@@ -220,7 +220,7 @@ struct ChunkIndex {
     // compact (4-byte) addends, one set per key layout in use -- k_encode_band32.  A layout = (tag bits, query-position bits, diagonal
     // bits k): the chunk's (subject, diagonal) pairs are numbered in bands of 2^k ids, one band for a sequence of length <= C =
     // 2^k - 2^bp, several for a longer one.  A search with queries of several length classes alternates between a few layouts per
-    // chunk, so the sets are kept (at most four, least recently used first out).
+    // chunk, so the sets are kept (at most six, least recently used first out).
     struct BandEnc {
         int ba = -1, bp = -1, k = -1;
         bool multi_ok = false;   // built with several bands per long subject allowed (one alphabet x one pattern only)
@@ -993,7 +993,7 @@ ChunkIndex::BandEnc* band_encoding(so_ctx* c, ChunkIndex& ch, int ba, int bp, bo
     ChunkIndex::BandEnc* e = nullptr;
     for (auto& x : ch.encs)
         if (x->k < 0) e = x.get();
-    if (!e && ch.encs.size() < 4) {
+    if (!e && ch.encs.size() < 6) {
         ch.encs.push_back(std::make_unique<ChunkIndex::BandEnc>());
         e = ch.encs.back().get();
     }
