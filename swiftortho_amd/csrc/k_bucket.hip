@@ -729,7 +729,10 @@ void launch_bkt_pass(bool scatter, const void* td, const u32* qseg, u32 NT, cons
     const BkHist HL = bk_hist_layout(L.R, staged, skewed);
     if (!scatter) hipLaunchKernelGGL((k_bkt_pass<false, false>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
     else if (staged) {
-        static const int wpe = getenv("SOHIT_BK_WPE") ? atoi(getenv("SOHIT_BK_WPE")) : 5;   // waves per SIMD the register budget is cut for: 5 = 93 VGPRs, no spill (6: 80 + 4 spilled dwords, 4-5 % slower on the 100k set; 4: slower)
+        // waves per SIMD the register budget is cut for.  Round 3: 5 (93 VGPRs; 6 spilled four dwords and was 4-5 % slower).  Round 4: the
+        // banded hit word needs fewer registers -- 6 fits in 80 VGPRs without a spill and is 6 % faster (1.89 -> 1.77 ms per 928 M-hit
+        // launch: 0.49 -> 0.52-0.53 of the HBM roofline); a budget of 7 cannot be met (the compiler falls back to 5 waves: 1.88 ms)
+        static const int wpe = getenv("SOHIT_BK_WPE") ? atoi(getenv("SOHIT_BK_WPE")) : 6;
         if (wpe == 5) hipLaunchKernelGGL((k_bkt_pass<true, true, 5>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
         else if (wpe == 4) hipLaunchKernelGGL((k_bkt_pass<true, true, 4>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
         else hipLaunchKernelGGL((k_bkt_pass<true, true, 6>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
