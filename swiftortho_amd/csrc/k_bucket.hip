@@ -727,6 +727,7 @@ void launch_bkt_pass(bool scatter, const void* td, const u32* qseg, u32 NT, cons
     static const bool skewed = !(getenv("SOHIT_BK_SKEW") && atoi(getenv("SOHIT_BK_SKEW")) == 0);
     const bool staged = scatter && staged_on && L.R <= BK_STAGE_RMAX;
     const BkHist HL = bk_hist_layout(L.R, staged, skewed);
+    // (the count pass at a budget of 8 waves per SIMD cannot be met either -- LDS, not registers, bounds it at 7: 0.752 against 0.749 ms)
     if (!scatter) hipLaunchKernelGGL((k_bkt_pass<false, false>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
     else if (staged) {
         // waves per SIMD the register budget is cut for.  Round 3: 5 (93 VGPRs; 6 spilled four dwords and was 4-5 % slower).  Round 4: the
