@@ -23,7 +23,7 @@ SOURCES = ["k_util.hip", "k_sort.hip", "k_sortseg.hip", "k_prep.hip", "k_index.h
 # -ffp-contract=off: host-side SEG/threshold arithmetic must round exactly like the reference's
 # (no fused multiply-add), and device fp64 compares stay IEEE.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-result", "-I", CSRC, "-I", INCLUDE]
+         "-Wno-unused-result", "-I", CSRC, "-I", INCLUDE] + os.environ.get("SOHIT_CXXFLAGS", "").split()   # (diagnostic builds: -DUG_STATS)
 
 
 def _deps_mtime():
