@@ -220,7 +220,7 @@ struct ChunkIndex {
     // compact (4-byte) addends, one set per key layout in use -- k_encode_band32.  A layout = (tag bits, query-position bits, diagonal
     // bits k): the chunk's (subject, diagonal) pairs are numbered in bands of 2^k ids, one band for a sequence of length <= C =
     // 2^k - 2^bp, several for a longer one.  A search with queries of several length classes alternates between a few layouts per
-    // chunk, so the sets are kept (at most six, least recently used first out).
+    // chunk, so the sets are kept (at most ten, least recently used first out).
     struct BandEnc {
         int ba = -1, bp = -1, k = -1;
         bool multi_ok = false;   // built with several bands per long subject allowed (one alphabet x one pattern only)
@@ -280,6 +280,10 @@ struct so_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t st_rows = nullptr;  // result rows leave on their own stream: the download of one batch overlaps the next batch's kernels
     hipEvent_t ev_rows = nullptr, ev_rows_done = nullptr;
+    // the k-mer order of queries too long for the LDS sort (one wave each, milliseconds for a 30 000-residue protein) runs beside the
+    // batch's other preparation and the seed passes of the shorter length classes
+    hipStream_t st_side = nullptr;
+    hipEvent_t ev_side_go = nullptr, ev_korder = nullptr;
     bool rows_in_flight = false;
     size_t max_hits_per_pass = (size_t)1 << 30;
     u32 max_batch = 131072;  // queries per device batch.  Round 3, config 3 (100k queries), same box: 25000 64.1 ms, 33334 63.0, 2 x 50000 63.0,
@@ -761,6 +765,10 @@ struct Batch {
     std::vector<u32> qid;
     std::vector<u8> qcls;    // length class per slot (query_class)
     bool permuted = false;
+    // slots [q_defer, nq): the length class whose longest members' k-mer order is still being computed on the side stream; their
+    // frequency cap (and everything after it) waits for ev_korder, the classes before them do not
+    u32 q_defer = 0;
+    bool korder_async = false;
     DevBuf<u32> d_qid, d_ocnt, d_ostart;
     SeqSet dev;              // device arrays only (d_res = masked raw, d_scls, d_off, d_words, d_pseq)
     DevBuf<u32> qbucket, korder, sbeg, scnt, pcnt, eff, nz, hoff, cidx;
@@ -805,6 +813,8 @@ struct Batch {
 inline u8 query_class(u32 len) { return len < 512 ? 0 : len < 1024 ? 1 : len < 2048 ? 2 : len < 4096 ? 3 : 4; }
 
 void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
+    if (b.korder_async) HIP_CHECK(hipStreamSynchronize(c->st_side));   // (a batch that never reached its long queries' passes)
+    b.korder_async = false;
     b.q_lo = q_lo, b.q_hi = q_hi, b.nq = (u32)(q_hi - q_lo);
     const SeqSet& Q = c->qry;
     b.h_off.assign((size_t)b.nq + 1, 0);
@@ -875,7 +885,21 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
                 break;
             }
         if (q_long < b.nq) b.gx.ensure(nres + 4), b.gL.ensure(nres + 4), b.gR.ensure(nres + 4);
-        launch_ksc_order(b.dev.d_scls.p, b.dev.d_off.p, b.nq, q_long, c->cfg.mink, c->d_b62c.p, b.gx.p, b.gL.p, b.gR.p, b.korder.p, c->st);
+        // in a class-ordered batch the long ones are the tail of the last class: their order is computed on the side stream
+        // (SOHIT_KSC_ASYNC=0: on the batch's stream)
+        static const bool async_on = !(getenv("SOHIT_KSC_ASYNC") && atoi(getenv("SOHIT_KSC_ASYNC")) == 0);
+        bool ordered = true;
+        for (u32 i = 1; i < b.nq && ordered; ++i) ordered = b.qcls[i] >= b.qcls[i - 1];
+        b.korder_async = async_on && q_long < b.nq && ordered && b.qcls[q_long] != b.qcls[0];
+        if (b.korder_async) {
+            b.q_defer = q_long;
+            while (b.q_defer > 0 && b.qcls[b.q_defer - 1] == b.qcls[q_long]) --b.q_defer;
+            HIP_CHECK(hipEventRecord(c->ev_side_go, c->st));   // the batch's class arrays are on the device
+            HIP_CHECK(hipStreamWaitEvent(c->st_side, c->ev_side_go, 0));
+        }
+        launch_ksc_order(b.dev.d_scls.p, b.dev.d_off.p, b.nq, q_long, c->cfg.mink, c->d_b62c.p, b.gx.p, b.gL.p, b.gR.p, b.korder.p, c->st,
+                         b.korder_async ? c->st_side : c->st);
+        if (b.korder_async) HIP_CHECK(hipEventRecord(c->ev_korder, c->st_side));
     }
     b.sbeg.ensure(T), b.scnt.ensure(T), b.eff.ensure(T + 4), b.nz.ensure(T + 4), b.hoff.ensure(T + 4), b.cidx.ensure(T + 4);
     b.pcnt.ensure(Ppad), b.mark.ensure(Ppad);
@@ -993,7 +1017,7 @@ ChunkIndex::BandEnc* band_encoding(so_ctx* c, ChunkIndex& ch, int ba, int bp, bo
     ChunkIndex::BandEnc* e = nullptr;
     for (auto& x : ch.encs)
         if (x->k < 0) e = x.get();
-    if (!e && ch.encs.size() < 6) {
+    if (!e && ch.encs.size() < 10) {   // (one per query-position width in use: 7 ... 15 bits; fewer slots than widths and a step that cycles through them misses every time)
         ch.encs.push_back(std::make_unique<ChunkIndex::BandEnc>());
         e = ch.encs.back().get();
     }
@@ -1053,16 +1077,29 @@ const unsigned long long* chunk_qhits(so_ctx* c, Batch& b, int ci) {
     i64 threshold = ch.threshold;
     if (c->thr >= 1 || threshold == 0) threshold = c->thr;  // `thr < 1 and DB.threshold or thr`, fsearch.py:2992
     b.qhits.ensure((size_t)b.nq + 2);
-    launch_cap(b.korder.p, b.dev.d_off.p, b.nq, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, c->st);
+    const u32 n1 = b.korder_async ? b.q_defer : b.nq;   // (the last length class follows in chunk_qhits_deferred)
+    launch_cap(b.korder.p, b.dev.d_off.p, 0, n1, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, c->st);
     if (c->h_qhits_cap < b.nq) {  // pinned: a pageable read of this array costs more than the kernels around it
         if (c->h_qhits) (void)hipHostFree(c->h_qhits);
         c->h_qhits_cap = (size_t)b.nq + 1024;
         HIP_CHECK(hipHostMalloc((void**)&c->h_qhits, c->h_qhits_cap * sizeof(unsigned long long), hipHostMallocDefault));
     }
     unsigned long long* qh = c->h_qhits;
-    HIP_CHECK(hipMemcpyAsync(qh, b.qhits.p, (size_t)b.nq * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
+    HIP_CHECK(hipMemcpyAsync(qh, b.qhits.p, (size_t)n1 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
     HIP_CHECK(hipStreamSynchronize(c->st));
     return qh;
+}
+
+// ... and of the length class that waited for the side stream's k-mer orders (once per batch: later chunks find them done)
+void chunk_qhits_deferred(so_ctx* c, Batch& b, int ci) {
+    ChunkIndex& ch = *c->chunks[ci];
+    HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_korder, 0));
+    b.korder_async = false;
+    i64 threshold = ch.threshold;
+    if (c->thr >= 1 || threshold == 0) threshold = c->thr;
+    launch_cap(b.korder.p, b.dev.d_off.p, b.q_defer, b.nq, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, c->st);
+    HIP_CHECK(hipMemcpyAsync(c->h_qhits + b.q_defer, b.qhits.p + b.q_defer, (size_t)(b.nq - b.q_defer) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
+    HIP_CHECK(hipStreamSynchronize(c->st));
 }
 
 void seed_stage(so_ctx* c, Batch& b, int ci) {
@@ -1077,6 +1114,7 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     const unsigned long long budget = c->max_hits_per_pass;
     u32 qa = 0;
     while (qa < b.nq) {
+        if (b.korder_async && qa >= b.q_defer) chunk_qhits_deferred(c, b, ci);
         unsigned long long acc = 0;
         u32 qb = qa;
         while (qb < b.nq && (qb == qa || (acc + qh[qb] <= budget && b.qcls[qb] == b.qcls[qa]))) acc += qh[qb++];
@@ -2136,6 +2174,7 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
             if (b1 - b0 < 2) throw SoError(oom ? std::string(e.what()) : std::string("one query collected >= 2^32 candidates"));
             (void)hipStreamSynchronize(c->st);
             (void)hipStreamSynchronize(c->st_rows);   // row downloads the failed attempt had queued
+            (void)hipStreamSynchronize(c->st_side);
             c->rows_in_flight = false;
             if (oom) c->batch.reset();  // hand the batch's buffers back before the halves allocate theirs
             c->cnt = keep;
@@ -2354,6 +2393,7 @@ void query_work(so_ctx* c, i64 q_lo, i64 q_hi, u64* out) {
                 ChunkIndex& ch = *c->chunks[ci];
                 if (ch.seq_hi == ch.seq_lo || ch.E == 0 || b.nq == 0) continue;
                 const unsigned long long* qh = chunk_qhits(c, b, ci);
+                if (b.korder_async) chunk_qhits_deferred(c, b, ci);
                 for (u32 i = 0; i < b.nq; ++i) out[b0 - st + b.qid[i]] += qh[i];
             }
         }
@@ -2406,6 +2446,9 @@ so_ctx* so_create(int device, const so_params* params) {
         HIP_CHECK(hipStreamCreateWithFlags(&c->st_rows, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_rows_done, hipEventDisableTiming));
+        HIP_CHECK(hipStreamCreateWithFlags(&c->st_side, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&c->ev_side_go, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&c->ev_korder, hipEventDisableTiming));
         upload_constants(c);
         if (!(getenv("SOHIT_WARM") && atoi(getenv("SOHIT_WARM")) == 0)) c->warm = std::thread(warm_sort_modules, device);
         g_create_err.clear();
@@ -2430,6 +2473,9 @@ void so_destroy(so_ctx* c) {
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
     if (c->ev_rows_done) (void)hipEventDestroy(c->ev_rows_done);
     if (c->st_rows) (void)hipStreamDestroy(c->st_rows);
+    if (c->ev_side_go) (void)hipEventDestroy(c->ev_side_go);
+    if (c->ev_korder) (void)hipEventDestroy(c->ev_korder);
+    if (c->st_side) (void)hipStreamDestroy(c->st_side);
     if (c->st) (void)hipStreamDestroy(c->st);
     delete c;
     g_hit_cache.clear();

@@ -145,10 +145,10 @@ __global__ __launch_bounds__(64) void k_ksc_order_g(const u8* __restrict__ q_scl
 // Positions are taken in korder until the running bucket total exceeds threshold * len; the test precedes the
 // add, so position r is taken iff the total of the positions before it is <= the limit: a prefix of the order.
 // One wave per query: 64 counts per step, wave prefix sum (u64), carried total; also returns the query's hits.
-__global__ __launch_bounds__(256) void k_cap(const u32* __restrict__ korder, const u32* __restrict__ qoff, u32 nq, int mink,
+__global__ __launch_bounds__(256) void k_cap(const u32* __restrict__ korder, const u32* __restrict__ qoff, u32 q0, u32 nq, int mink,
                                              const u32* __restrict__ pcnt, i64 threshold, u8* __restrict__ mark,
                                              unsigned long long* __restrict__ qhits) {
-    const u32 q = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const u32 q = q0 + blockIdx.x * 4u + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= nq) return;
     const u32 base = qoff[q];
@@ -423,20 +423,21 @@ void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* hkey, const 
 }
 
 void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, u32 q_long /*first batch slot that may hold more than LDS_SORT_MAX windows*/, int mink,
-                      const signed char* b62c, u64* gx, u32* gL, u32* gR /*global scratch per residue: only when q_long < nq*/, u32* korder, hipStream_t st) {
+                      const signed char* b62c, u64* gx, u32* gL, u32* gR /*global scratch per residue: only when q_long < nq*/, u32* korder, hipStream_t st,
+                      hipStream_t st_long /*where the global-scratch instance runs (the caller orders it against st)*/) {
     if (!nq) return;
     // (one wave per query: the instance for the typical protein keeps 4 KB of LDS so that a CU holds 32 of them)
     hipLaunchKernelGGL((k_ksc_order_lds<512, 0>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
     hipLaunchKernelGGL((k_ksc_order_lds<1024, 512>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
     hipLaunchKernelGGL((k_ksc_order_lds<LDS_SORT_MAX, 1024>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
-    if (q_long < nq) hipLaunchKernelGGL(k_ksc_order_g, dim3(nq - q_long), dim3(64), 0, st, q_scls, qoff, q_long, nq, mink, b62c, gx, gL, gR, korder);
+    if (q_long < nq) hipLaunchKernelGGL(k_ksc_order_g, dim3(nq - q_long), dim3(64), 0, st_long, q_scls, qoff, q_long, nq, mink, b62c, gx, gL, gR, korder);
 }
 int ksc_lds_max() { return LDS_SORT_MAX; }
 
-void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark,
+void launch_cap(const u32* korder, const u32* qoff, u32 q0, u32 nq /*queries [q0, nq)*/, int mink, const u32* pcnt, i64 threshold, u8* mark,
                 unsigned long long* qhits, hipStream_t st) {
-    if (!nq) return;
-    hipLaunchKernelGGL(k_cap, dim3((nq + 3) / 4), dim3(256), 0, st, korder, qoff, nq, mink, pcnt, threshold, mark, qhits);
+    if (nq <= q0) return;
+    hipLaunchKernelGGL(k_cap, dim3((nq - q0 + 3) / 4), dim3(256), 0, st, korder, qoff, q0, nq, mink, pcnt, threshold, mark, qhits);
 }
 
 void launch_effcnt(const u8* mark, const u32* scnt, int AS, u32 p_lo, u32 p_hi, u32* eff, u32* nz, hipStream_t st) {

@@ -62,9 +62,10 @@ void launch_qhash(const u32* words, u32 Ppad, const SeedCfg& cfg, const HashLut&
 void launch_bounds(const u32* qbucket, u32 Ppad, int AS, const u32* hkey, const u64* hval, int hshift, u32 hmask, const u64* dir /*or null: the map*/,
                    const u32* ubeg, u32 NC, u32 E, u32* sbeg, u32* scnt, u32* pcnt, hipStream_t st);
 void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, u32 q_long /*first batch slot that may hold more than ksc_lds_max() windows*/, int mink,
-                      const signed char* b62c, u64* gx, u32* gL, u32* gR /*global scratch per residue: only when q_long < nq*/, u32* korder, hipStream_t st);
+                      const signed char* b62c, u64* gx, u32* gL, u32* gR /*global scratch per residue: only when q_long < nq*/, u32* korder, hipStream_t st,
+                      hipStream_t st_long /*stream of the global-scratch instance: st, or a side stream the caller orders against st*/);
 int ksc_lds_max();
-void launch_cap(const u32* korder, const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark,
+void launch_cap(const u32* korder, const u32* qoff, u32 q0, u32 nq /*batch slots [q0, nq)*/, int mink, const u32* pcnt, i64 threshold, u8* mark,
                 unsigned long long* qhits, hipStream_t st);
 // (these two work on the pass's seed slots only, [AS * p_lo, AS * p_hi))
 void launch_effcnt(const u8* mark, const u32* scnt, int AS, u32 p_lo, u32 p_hi, u32* eff, u32* nz, hipStream_t st);
