@@ -8,8 +8,8 @@ import sys; sys.path.insert(0,'.')
 from swiftortho_amd import synthprot
 open('/tmp/os.fsa','wb').write(synthprot.synthprot($N, 300))"
 for k in 1 2 3; do
-  T0=$(date +%s.%N)
+  T0=$(date +%s%N)
   SOHIT_TIMING=1 python3 bin/find_hit.py -p blastp -i /tmp/os.fsa -d /tmp/os.fsa -o /tmp/os.sc -e 1e-5 -s $S -a 1 -j 1 -v 500 2>&1 | tail -2
-  echo "wall $(echo "$(date +%s.%N) - $T0" | bc) s"
+  echo "wall $(( ($(date +%s%N) - T0) / 1000000 )) ms"
 done
 wc -l /tmp/os.sc; md5sum /tmp/os.sc
