@@ -2,7 +2,8 @@
 bucketed diagonal binning per seed pass of one query length class over diagonal BANDS (k_encode_band32) -- one sequence far above
 the fixed widths no longer switches a whole batch to the slow kernels.  Every case here holds sequences above 740 residues (packed
 aligner range), above 2048 (hit-word range of the pre-round-4 binning) and above 4096 (the aligner's tiled path) in ONE batch, is
-compared with the oracle row for row and candidate for candidate, and checks with the library's counters that both variants of
+compared with the oracle row for row and candidate for candidate (the 30 000-residue query's k-mer order comes from the side stream in
+the default setting), and checks with the library's counters that both variants of
 both stages actually ran.
 
 Run on the GPU box:  python -m pytest tests -m gpu -x -q
@@ -60,8 +61,9 @@ def test_generator_shape():
 
 @pytest.mark.parametrize("env", [{}, {"SOHIT_BUCKET_MIN": "0"}, {"SOHIT_BANDS": "0"}, {"SOHIT_QCLASS": "0"}, {"SOHIT_ALIGN_PK": "0"},
                                  {"SOHIT_BUCKET_MIN": "0", "SOHIT_BUCKET_BEST": "0"}, {"SOHIT_BUCKET_MIN": "0", "SOHIT_POISON": "0xFF"},
-                                 {"SOHIT_BATCH": "700", "SOHIT_BUCKET_MIN": "0", "SOHIT_MAX_HITS": "300000"}],
-                         ids=["default", "bucket_forced", "no_bands", "no_classes", "no_packed", "bucket_sortbest", "poison", "small_batches"])
+                                 {"SOHIT_BATCH": "700", "SOHIT_BUCKET_MIN": "0", "SOHIT_MAX_HITS": "300000"}, {"SOHIT_KSC_ASYNC": "0"}],
+                         ids=["default", "bucket_forced", "no_bands", "no_classes", "no_packed", "bucket_sortbest", "poison", "small_batches",
+                              "kmer_order_on_main_stream"])
 def test_mixed_lengths_vs_oracle(fs, coracle, tmp_path, monkeypatch, env):
     """3000 proteins, median 277 residues, a tail to 5000 and one of 30 000: rows, candidate lists and counters equal the
     oracle's, whatever the path switches say."""
