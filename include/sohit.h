@@ -196,7 +196,8 @@ const char *so_mcl_last_error(void);
  *   so_tsv_scan   for every line and each requested column cols[c]: [beg, beg + len) of the field (numeric columns: stripped of ASCII
  *                 white space), the number of tabs of the line, and for numeric columns the value with status 0 = plain decimal
  *                 number (strtod), 1 = empty or missing, 2 = anything else (the caller applies Python's float()).  Arrays are
- *                 [ncols][nline].  Returns 0.
+ *                 [ncols][nline].  numeric[c]: 0 = text column (bounds), 1 = number (bounds, value, status), 2 = number, status only,
+ *                 3 = number, value and status -- what is not asked for is not written.  Returns 0.
  *   so_tsv_codes  two columns of byte strings -> codes into their sorted distinct list (byte order, a proper prefix first: numpy's
  *                 order of fixed-width byte strings); returns the number of distinct strings, or minus it when cap is too small. */
 int64_t so_tsv_lines(const char *buf, int64_t n, int64_t *line_start, int64_t cap);

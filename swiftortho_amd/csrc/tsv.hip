@@ -127,8 +127,10 @@ int so_tsv_scan(const char* buf, int64_t n, const int64_t* line_start, int64_t n
                         if (r.ec == std::errc() && r.ptr == buf + en) s = 0;
                         else v = 0;
                     }
-                    if (val) val[o] = v;
+                    if (val && numeric[c] != 2) val[o] = v;
                     if (status) status[o] = s;
+                    if (numeric[c] >= 2) continue;   // 2: status only, 3: value + status -- the field's bounds are not stored (a caller that
+                                                     // does not read them never touches those pages of its arrays)
                 }
                 beg[o] = st;
                 len[o] = (int32_t)(en - st);

@@ -443,6 +443,16 @@ def main(argv=None):
     if alg != 'mcl':
         sys.stderr.write('find_cluster: only -a mcl is provided (the reference\'s affinity-propagation modes are not)\n')
         return 2
+    # the HIP runtime and the Markov kernels' code object take ~0.25 s to come up: a thread brings them up on a 1 x 1 matrix while
+    # this one reads the edges and finds the components (failures there are left to the real call, which reports them)
+    import threading
+
+    def warm():
+        try:
+            device_mcl(np.array([0, 1]), np.array([0]), np.array([1.], dtype=np.float32), ifl, rounds=1)
+        except Exception:
+            pass
+    threading.Thread(target=warm, daemon=True).start()
     with open(qry, 'r') as f:
         groups = cnc(f, ifl)
     w = sys.stdout.write
