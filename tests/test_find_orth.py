@@ -72,6 +72,33 @@ def test_native_tokeniser_leaves_odd_fields_to_python(monkeypatch):
             assert np.array_equal(getattr(nat, k), getattr(ref, k)), k
 
 
+def test_scanner_writes_only_what_a_column_asks_for():
+    """so_tsv_scan's per-column modes (include/sohit.h): 0 = text (bounds), 1 = number (bounds, value, status), 2 = status only,
+    3 = value + status -- arrays a mode does not cover keep what they held (find_orth's [14][n] buffers are np.empty and stay untouched
+    there)"""
+    import ctypes as C
+    import numpy as np
+    from swiftortho_amd import _lib
+    L = _lib.load()
+    data = b"id1\t1.5\t7\t 2e3 \nid22\tx\t8\t4\n"
+    buf = np.frombuffer(data, dtype=np.uint8)
+    ptr = lambda a: C.c_void_p(a.ctypes.data)
+    n = data.count(b"\n")
+    ls = np.empty(n + 1, dtype=np.int64)
+    assert L.so_tsv_lines(ptr(buf), len(data), ptr(ls), n + 1) == n
+    cols = np.arange(4, dtype=np.int32)
+    numeric = np.array([0, 1, 2, 3], dtype=np.uint8)
+    ntab = np.empty(n, dtype=np.int32)
+    beg, ln = np.full((4, n), -7, dtype=np.int64), np.full((4, n), -7, dtype=np.int32)
+    val, st = np.full((4, n), -7.0), np.full((4, n), 9, dtype=np.uint8)
+    assert L.so_tsv_scan(ptr(buf), len(data), ptr(ls), n, 4, ptr(cols), ptr(numeric), ptr(ntab), ptr(beg), ptr(ln), ptr(val), ptr(st)) == 0
+    assert ntab.tolist() == [3, 3]
+    assert [data[b:b + l] for b, l in zip(beg[0], ln[0])] == [b"id1", b"id22"] and (val[0] == -7).all() and (st[0] == 9).all()   # text
+    assert [data[b:b + l] for b, l in zip(beg[1], ln[1])] == [b"1.5", b"x"] and val[1].tolist() == [1.5, 0.0] and st[1].tolist() == [0, 2]
+    assert (beg[2] == -7).all() and (ln[2] == -7).all() and (val[2] == -7).all() and st[2].tolist() == [0, 0]                 # status only
+    assert (beg[3] == -7).all() and (ln[3] == -7).all() and val[3].tolist() == [2000.0, 4.0] and st[3].tolist() == [0, 0]    # value + status
+
+
 def test_native_repr_equals_python_repr():
     """so_py_repr / so_format_pairs print a score the way Python's repr() does (shortest round-trip digits, fixed notation while the
     decimal point lies within (-4, 16], two-digit exponents, '.0' on integers, inf / nan): random magnitudes and raw bit patterns"""
