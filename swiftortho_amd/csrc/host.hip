@@ -1704,7 +1704,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     // (k_task_rows clears bit 13 of their sort key, so they lead the sorted list, and counts them) and the rest.  Only batches that hold
     // a query AND a reference sequence above the length limit can contain such tasks at all.
     const u32 maxwin_q = std::min<u32>(b.maxqlen, LONG_SEQ), maxwin_s = std::min<u32>(c->ref.maxlen, LONG_SEQ);
-    const bool pk_on = !(getenv("SOHIT_ALIGN_PK") && atoi(getenv("SOHIT_ALIGN_PK")) == 0);
+    const bool pk_on = !(getenv("SOHIT_ALIGN_PK") && atoi(getenv("SOHIT_ALIGN_PK")) == 0) && align_pk_supported(c->st);
     const bool pk_mixed = pk_on && (int)std::min(maxwin_q, maxwin_s) > align_pk_max_len();
     auto sort_by_rows = [&](const u32* list, u32 n, u32* n_wide) -> const u32* {
         const bool split = n_wide && pk_mixed;

@@ -228,6 +228,32 @@ __global__ __launch_bounds__(PK_THREADS) void k_align_pk(const AlnTask* __restri
     }
 }
 
+// k_align_pk joins its two alignments' table entries with ds_read_u16_d16_hi + OR, which needs the d16 load to CLEAR the half it does
+// not write.  That is what a part with SRAM ECC does (every MI300 / MI355X; the compiler never emits d16_hi for such a target because
+// of it); a part that PRESERVES the other half would leave the register's old bits under alignment A's entry.  Asked once per process:
+// one lane loads into a register holding all ones.  false -> the host sends every score-only alignment to k_align<false>.
+__global__ void k_d16_probe(u32* __restrict__ out) {
+    __shared__ u32 s_w[2];
+    s_w[0] = 0x12345678u, s_w[1] = 0u;
+    __syncthreads();
+    u32 v = 0xFFFFFFFFu;
+    asm volatile("ds_read_u16_d16_hi %0, %1\n\ts_waitcnt lgkmcnt(0)" : "+v"(v) : "v"((u32)(uintptr_t)s_w));
+    out[0] = v;
+}
+bool align_pk_supported(hipStream_t st) {
+    static int state = -1;   // (one device kind per process)
+    if (state < 0) {
+        u32* d = nullptr;
+        u32 h = 0;
+        if (hipMalloc((void**)&d, sizeof(u32)) != hipSuccess) return false;
+        hipLaunchKernelGGL(k_d16_probe, dim3(1), dim3(1), 0, st, d);
+        const bool ok = hipMemcpyAsync(&h, d, sizeof(u32), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+        (void)hipFree(d);
+        state = (ok && h == 0x56780000u) ? 1 : 0;
+    }
+    return state == 1;
+}
+
 // largest min(rows, columns) whose scores fit the packed cells: (11 * n << 2) + 47 + 44 (one more substitution) <= 32767
 int align_pk_max_len() { return 740; }
 // ... or whose score bound does: (score << 2) + 47 + 44 <= 32767

@@ -119,6 +119,7 @@ u32 align_trace_unit();
 void launch_trace_units(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, u32* units /*n + 1*/, hipStream_t st);
 
 // k_align16.hip: score-only aligner in packed 16-bit arithmetic, two alignments per register
+bool align_pk_supported(hipStream_t st);   // the d16 load behaviour k_align_pk relies on (probed once per process)
 int align_pk_max_len();   // largest min(rows, columns) it can score whatever the residues
 u32 align_pk_max_score(); // largest alignment score its cells hold
 void launch_align_pk(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
