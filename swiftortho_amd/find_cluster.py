@@ -61,6 +61,31 @@ class _Graph:
         self.adj[u][v] = 1
         self.adj[v][u] = 1
 
+    @classmethod
+    def from_pairs(cls, pairs):
+        """the graph after `add_edge(u, v)` for every (u, v) of `pairs` in order, built column-wise: a node's place is its first
+        appearance in the sequence u0, v0, u1, v1, ...; its neighbour dict holds the other ends of its edges in that same order
+        (a repeated edge keeps its first place, as a repeated assignment does)"""
+        g = cls()
+        if isinstance(pairs, tuple) and len(pairs) == 2 and isinstance(pairs[0], np.ndarray):
+            e = np.stack(pairs, axis=1)        # (u column, v column)
+        else:
+            e = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+        if not len(e):
+            return g
+        src = e.reshape(-1)                    # u0, v0, u1, v1, ...
+        dst = e[:, ::-1].reshape(-1)           # v0, u0, v1, u1, ...
+        order = np.argsort(src, kind='stable')
+        s_sorted = src[order]
+        starts = np.flatnonzero(np.r_[True, s_sorted[1:] != s_sorted[:-1]])
+        ends = np.r_[starts[1:], len(src)]
+        first = order[starts]                  # a node's first position in the sequence
+        d_sorted = dst[order].tolist()
+        nodes = s_sorted[starts].tolist()
+        for k in np.argsort(first, kind='stable').tolist():
+            g.adj[nodes[k]] = dict.fromkeys(d_sorted[starts[k]:ends[k]], 1)
+        return g
+
     def components(self):
         seen = set()
         for s in self.adj:
@@ -195,19 +220,23 @@ def surviving_pairs(indptr, indices, data, prune=1e-5):
     """The reference's read-out of the final matrix (find_cluster.py:686-689): the coordinates of the entries that are not zero, paired
     IN ORDER with the raw data array -- which still holds the pruned zeros when the loop ran out of rounds, so the pairing can be
     shifted -- and kept where that value exceeds the threshold."""
+    r, c = surviving_pair_columns(indptr, indices, data, prune)
+    return list(zip(r.tolist(), c.tolist()))
+
+
+def surviving_pair_columns(indptr, indices, data, prune=1e-5):
+    """surviving_pairs as two arrays"""
     rows = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr))
     nz = data != 0
     r, c = rows[nz], indices[nz]
     keep = data[:len(r)] > np.float32(prune)
-    return list(zip(r[keep].tolist(), c[keep].tolist()))
+    return r[keep].astype(np.int64), c[keep].astype(np.int64)
 
 
 def mcl_block(edge_lines, inflation, mcl=device_mcl):
     """one batch of edges -> groups (lists of gene ids) in the reference's order"""
     names, indptr, indices, data = block_matrix(edge_lines)
-    g = _Graph()
-    for a, b in surviving_pairs(*mcl(indptr, indices, data, inflation)):
-        g.add_edge(a, b)
+    g = _Graph.from_pairs(surviving_pair_columns(*mcl(indptr, indices, data, inflation)))
     for comp in g.components():
         yield [names[e] for e in comp]
 
@@ -217,9 +246,7 @@ def mcl_block_arrays(gx, gy, z, gene_names, inflation, mcl=device_mcl):
     if len(gx) == 0:
         return
     names, indptr, indices, data = block_matrix_arrays(gx, gy, z, gene_names)
-    g = _Graph()
-    for a, b in surviving_pairs(*mcl(indptr, indices, data, inflation)):
-        g.add_edge(a, b)
+    g = _Graph.from_pairs(surviving_pair_columns(*mcl(indptr, indices, data, inflation)))
     for comp in g.components():
         yield [names[e] for e in comp]
 
