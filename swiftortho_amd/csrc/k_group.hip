@@ -38,7 +38,7 @@ __device__ __forceinline__ u64 load8u(const u8* p) {  // unaligned 8-byte global
 // compaction inside the wave).   p_qs = (q << bs) | subject_local, p_sd = (score << 32) | (u32)dist,
 // p_ft = the head hit's key (or its position when ft_walk): k_first_touch turns it into the first-touch key.
 #define UW_WAVES 4
-#define UW_RANGE 4096   // head positions owned by one wave
+#define UW_RANGE 4096   // head positions owned by one wave (large passes; launch_ungap gives the waves of a small pass shorter ranges)
 #define UW_QCAP 128     // group-head ring (u32 hit indices)
 #define UW_PCAP 64     // buffered pass records per wave
 #define UW_WAIT 20      // run the bookkeeping part when this many lanes wait for it
@@ -62,7 +62,7 @@ enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN =
 template <int CPI /*chunks per loop iteration*/, bool BANDS, bool GALLOP, bool W32>
 __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restrict__ keys, const u32* __restrict__ words, const u32* __restrict__ bext, u32 nb, BktLayout L,
                                                          u32 H, KeyLayout kl, int rbs, int rsh_subj, int rsh_diag, int rdoff /*klr's fields (BANDS / W32)*/,
-                                                         const uint2* __restrict__ btab, int ft_walk, u32 wait_n,
+                                                         const uint2* __restrict__ btab, int ft_walk, u32 wait_n, u32 range /*head positions per wave*/,
                                                          const u8* __restrict__ q_scls, const u32* __restrict__ qoff,
                                                          const u8* __restrict__ r_scls,
                                                          const u32* __restrict__ roff /*chunk-local offsets (absolute values)*/,
@@ -88,9 +88,9 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const u32 wid = blockIdx.x * UW_WAVES + w;
-    const u64 ra = (u64)wid * UW_RANGE;
+    const u64 ra = (u64)wid * range;
     if (ra >= H) return;
-    const u32 a0 = (u32)ra, b0 = (u32)min((u64)H, ra + UW_RANGE);
+    const u32 a0 = (u32)ra, b0 = (u32)min((u64)H, ra + range);
     u32* s_queue = s_queue_all[w];
     u64* s_qkey = s_qkey_all[w];
     u32* s_qw = reinterpret_cast<u32*>(s_qkey_all[w]);   // W32: the head's word ...
@@ -738,9 +738,17 @@ void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& 
     const u32 wait_n = getenv("SOHIT_UG_WAIT") ? (u32)atoi(getenv("SOHIT_UG_WAIT")) : UW_WAIT;
     BktLayout L0 = BktLayout();
     L0.nqp = 1;
-    const dim3 g(ungap_num_blocks(H)), bl(64 * UW_WAVES);
+    // A wave walks its range's groups one after the other on each lane: with 4096 positions per wave a pass of a few million hits (the
+    // long length classes of a mixed batch) fills a fraction of the 8192 wave slots and lasts as long as one wave does.  Passes below
+    // half a fill get shorter ranges, down to 256 positions (heterogeneous 100 k set: 14.4 -> 13.0 ms of extension per step; config 3's
+    // passes keep 4096 -- shorter ranges there only add table set-ups).  SOHIT_UG_RANGE: a fixed range.
+    u32 range = UW_RANGE;
+    if (const char* e = getenv("SOHIT_UG_RANGE")) range = (u32)std::max(64, atoi(e));
+    else
+        while (range > 256u && (u64)H / range < 4096ull) range >>= 1;
+    const dim3 g((unsigned)(((u64)H + (u64)range * UW_WAVES - 1) / ((u64)range * UW_WAVES))), bl(64 * UW_WAVES);
 #define UG_LAUNCH(K) hipLaunchKernelGGL(K, g, bl, 0, st, keys, words, bext, nb, words ? *L : L0, H, kl, klr.bs, klr.sh_subj, klr.sh_diag, (int)klr.diag_off, (const uint2*)btab, \
-                                        ft_walk ? 1 : 0, wait_n, q_scls, qoff, r_scls, roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count)
+                                        ft_walk ? 1 : 0, wait_n, range, q_scls, qoff, r_scls, roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count)
     if (words) {   // the buckets' 32-bit words (k_bkt_group), bucketed passes
         if (gallop) {
             if (btab) UG_LAUNCH((k_ungap<3, true, true, true>));
