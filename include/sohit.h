@@ -91,6 +91,7 @@ typedef struct so_counters {
     int64_t hits_bucketed;             /* seed hits binned by the bucketed passes (k_bkt_pass); the rest took the sorted path */
     int64_t align_wide;                /* score-only alignments the packed 16-bit aligner could not take (32-bit kernel)       */
     int64_t cells_wide;                /* their band cells (`cells` counts every task of the early-stop rounds once)            */
+    int64_t seed_passes;               /* seed passes run (one per length class and chunk; sparse neighbouring classes share one) */
 } so_counters;
 
 /* Lifetime.  Replaces: spawning `fsearch-c` with its flags (find_hit.py:119-123). */

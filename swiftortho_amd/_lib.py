@@ -28,7 +28,7 @@ class SoCounters(C.Structure):
                 ("align_launches", C.c_int64), ("align_ms", C.c_double),
                 ("index_ms", C.c_double), ("seed_ms", C.c_double), ("group_ms", C.c_double), ("phase2_ms", C.c_double),
                 ("total_ms", C.c_double), ("count_launches", C.c_int64), ("count_ms", C.c_double),
-                ("hits_bucketed", C.c_int64), ("align_wide", C.c_int64), ("cells_wide", C.c_int64)]
+                ("hits_bucketed", C.c_int64), ("align_wide", C.c_int64), ("cells_wide", C.c_int64), ("seed_passes", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -260,6 +260,9 @@ struct so_ctx {
     std::string ref_path;   // file the reference was read from ("" when it came from memory) and its size / mtime then
     long long ref_fsize = -1, ref_mtime_ns = -1;
     bool ref_loaded = false, qry_loaded = false, index_built = false;
+    // band_plan()'s answers: a function of a chunk's sequence lengths only, so they outlive index rebuilds (cleared with the reference)
+    struct BandPlan { i64 lo, hi; int bp; bool multi_ok; int k; u64 nband; };
+    std::vector<BandPlan> band_plans;
     i64 r_lo = -1, r_hi = -1;
     std::vector<std::unique_ptr<ChunkIndex>> chunks;
     std::vector<std::unique_ptr<ChunkIndex>> spare_chunks;  // dropped chunk objects: their device buffers are reused by the next build
@@ -555,6 +558,7 @@ void load_ref_common(so_ctx* c, i64 r_lo, i64 r_hi) {
     c->r_lo = r_lo, c->r_hi = r_hi;
     upload_set(c, c->ref, c->ref.res.data(), c->ref.off, (u32)c->ref.N);
     c->ref_loaded = true;
+    c->band_plans.clear();
     c->index_built = false;
     c->chunks.clear();
     c->cnt.ref_seqs = c->ref.N;
@@ -983,12 +987,12 @@ struct ProfTimer {
 // picks the diagonal width k, numbers the bands, encodes the entries.  multi_ok = a long subject may own several bands (the
 // kernels resolve bands through a table: one alphabet x one pattern only); otherwise k is wide enough for the longest subject.
 // Returns null when band + diagonal + tag bits exceed 31 (the pass then uses the 8-byte addends).
-ChunkIndex::BandEnc* band_encoding(so_ctx* c, ChunkIndex& ch, int ba, int bp, bool multi_ok) {
-    ++ch.enc_clock;
-    for (auto& e : ch.encs)
-        if (e->k >= 0 && e->ba == ba && e->bp == bp && e->multi_ok == multi_ok) {
-            e->used = ch.enc_clock;
-            return e->k == 0 ? nullptr : e.get();   // k == 0: "does not fit" remembered
+// diagonal bits k and number of bands of the chunk for queries below 2^bp residues (kept in the ctx: see band_plans)
+void band_plan(so_ctx* c, ChunkIndex& ch, int bp, bool multi_ok, int* k_out, u64* nband_out) {
+    for (const auto& pl : c->band_plans)
+        if (pl.lo == ch.seq_lo && pl.hi == ch.seq_hi && pl.bp == bp && pl.multi_ok == multi_ok) {
+            *k_out = pl.k, *nband_out = pl.nband;
+            return;
         }
     const u32 nseq = (u32)(ch.seq_hi - ch.seq_lo);
     const u64 qcap = 1ull << bp;
@@ -1013,6 +1017,22 @@ ChunkIndex::BandEnc* band_encoding(so_ctx* c, ChunkIndex& ch, int ba, int bp, bo
             if (bits < best_bits) best_bits = bits, k = kk, nband = nb;
         }
     }
+    c->band_plans.push_back({ch.seq_lo, ch.seq_hi, bp, multi_ok, k, nband});
+    *k_out = k, *nband_out = nband;
+}
+
+ChunkIndex::BandEnc* band_encoding(so_ctx* c, ChunkIndex& ch, int ba, int bp, bool multi_ok) {
+    ++ch.enc_clock;
+    for (auto& e : ch.encs)
+        if (e->k >= 0 && e->ba == ba && e->bp == bp && e->multi_ok == multi_ok) {
+            e->used = ch.enc_clock;
+            return e->k == 0 ? nullptr : e.get();   // k == 0: "does not fit" remembered
+        }
+    const u32 nseq = (u32)(ch.seq_hi - ch.seq_lo);
+    const u64 qcap = 1ull << bp;
+    int k;
+    u64 nband;
+    band_plan(c, ch, bp, multi_ok, &k, &nband);
     // slot: a stale one, else a new one, else the least recently used
     ChunkIndex::BandEnc* e = nullptr;
     for (auto& x : ch.encs)
@@ -1102,6 +1122,28 @@ void chunk_qhits_deferred(so_ctx* c, Batch& b, int ci) {
     HIP_CHECK(hipStreamSynchronize(c->st));
 }
 
+// Would a pass of `nq` queries no longer than `maxq` with `hits` seed hits in this chunk take the sorted path?  The tests of
+// group_bucketed (seed_pass) on a whole length class: no compact banded addends for that query width, several seed patterns, or fewer
+// hits per (query, widest subject range) than the sparse limit.
+bool class_takes_sorted_path(so_ctx* c, ChunkIndex& ch, u32 maxq, unsigned long long hits, unsigned long long nq) {
+    const int AS = c->cfg.A * c->cfg.S;
+    if ((getenv("SOHIT_BUCKET") && atoi(getenv("SOHIT_BUCKET")) == 0) || AS != 1 || UG_SHARDS != 1 || !nq) return true;
+    if (getenv("SOHIT_LK_WIDE") && atoi(getenv("SOHIT_LK_WIDE")) != 0) return true;
+    const int bp = ceil_log2(std::max<u32>(maxq, 2));
+    const bool bands_ok = !(getenv("SOHIT_BANDS") && atoi(getenv("SOHIT_BANDS")) == 0);
+    int k;
+    u64 nband;
+    band_plan(c, ch, bp, bands_ok, &k, &nband);   // (the layout only: no encoding is built for the question)
+    const int bs = ceil_log2(std::max<u64>(nband, 2));
+    if (bs + k > 31 || bp > 16) return true;
+    const int wb_hi = std::min(std::min(31 - k - bp, bs), bkt_max_wb());
+    int wb_lo = 0;
+    while ((nband + (1ull << wb_lo) - 1) >> wb_lo > BKT_RMAX) ++wb_lo;
+    if (wb_hi < wb_lo) return true;
+    const unsigned long long sparse = getenv("SOHIT_BUCKET_MIN") ? (unsigned long long)std::max(0, atoi(getenv("SOHIT_BUCKET_MIN"))) : 192ull;
+    return hits / (nq * ((nband + (1ull << wb_hi) - 1) >> wb_hi)) < sparse;
+}
+
 void seed_stage(so_ctx* c, Batch& b, int ci) {
     ChunkIndex& ch = *c->chunks[ci];
     const u32 nseq_chunk = (u32)(ch.seq_hi - ch.seq_lo);
@@ -1112,14 +1154,41 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     // scratch and group arrays are sized by it; 32-bit hit ordinals need < 2^32 per pass).
     const unsigned long long* qh = chunk_qhits(c, b, ci);
     const unsigned long long budget = c->max_hits_per_pass;
+    // Pass groups.  A pass holds one length class so that its key fields are as narrow as its queries allow -- what the bucketed
+    // binning needs.  A class whose pass would take the sorted path anyway (class_takes_sorted_path: typically too few hits per query
+    // and subject range, the long seeds) gains nothing from a pass of its own and pays a dozen launches and three host round trips for it:
+    // neighbouring sparse classes are searched as ONE pass (heterogeneous 100 k set, headline seed: ten passes per step -> four).
+    // The class still waiting for its k-mer orders (korder_async) is never merged into an earlier pass.
+    int grp[QCLASSES];
+    {
+        const bool merge_on = !(getenv("SOHIT_PASS_MERGE") && atoi(getenv("SOHIT_PASS_MERGE")) == 0);
+        unsigned long long hits[QCLASSES] = {0}, cnt[QCLASSES] = {0};
+        u32 maxq[QCLASSES] = {0};
+        const u32 known = b.korder_async ? b.q_defer : b.nq;   // (the deferred class's counts arrive later)
+        for (u32 q = 0; q < known; ++q) {
+            const int k = b.qcls[q];
+            hits[k] += qh[q], cnt[k]++, maxq[k] = std::max(maxq[k], b.h_off[q + 1] - b.h_off[q]);
+        }
+        const int held = b.korder_async ? (int)b.qcls[b.q_defer] : -1;
+        bool sp[QCLASSES];
+        for (int k = 0; k < QCLASSES; ++k) sp[k] = merge_on && k != held && cnt[k] && class_takes_sorted_path(c, ch, maxq[k], hits[k], cnt[k]);
+        grp[0] = 0;
+        for (int k = 1; k < QCLASSES; ++k) {
+            // (an empty class between two sparse ones does not separate them)
+            int j = k - 1;
+            while (j > 0 && !cnt[j] && j != held) --j;
+            grp[k] = grp[k - 1] + ((sp[k] && sp[j] && grp[j] == grp[k - 1]) || (!cnt[k] && k != held) ? 0 : 1);
+        }
+    }
     u32 qa = 0;
     while (qa < b.nq) {
         if (b.korder_async && qa >= b.q_defer) chunk_qhits_deferred(c, b, ci);
         unsigned long long acc = 0;
         u32 qb = qa;
-        while (qb < b.nq && (qb == qa || (acc + qh[qb] <= budget && b.qcls[qb] == b.qcls[qa]))) acc += qh[qb++];
+        while (qb < b.nq && (qb == qa || (acc + qh[qb] <= budget && grp[b.qcls[qb]] == grp[b.qcls[qa]]))) acc += qh[qb++];
         if (acc >= 0xFFFFFFF0ull) throw SoError("a single query visits >= 2^32 index entries in one chunk: lower -c");
-        if (acc) seed_pass(c, b, ci, qa, qb, wall(), sc);
+        if (acc) seed_pass(c, b, ci, qa, qb, wall(), sc), ++c->cnt.seed_passes;
+        if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] chunk %d pass queries [%u, %u) classes %d..%d hits %llu\n", ci, qa, qb, (int)b.qcls[qa], (int)b.qcls[qb - 1], acc);
         qa = qb;
     }
 }

@@ -80,6 +80,21 @@ def test_mixed_lengths_vs_oracle(fs, coracle, tmp_path, monkeypatch, env):
         assert 0 < c["align_wide"] < 0.5 * c["alignments"] and 0 < c["cells_wide"] < c["cells"]
 
 
+def test_sparse_seed_searches_neighbouring_length_classes_in_one_pass(fs, coracle, tmp_path, monkeypatch):
+    """With a long seed the queries visit few index entries each: the length classes would all take the sorted path, so seed_stage
+    searches them as ONE pass (the class still waiting for its k-mer orders apart).  Same rows and candidates as the oracle with and
+    without the merge, and fewer seed passes with it."""
+    fa = het_fasta(3000, 11)
+    kw = dict(ssd="11111011111", nr=AA9, ht=120000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    launches = {}
+    for merge in ("1", "0"):
+        monkeypatch.setenv("SOHIT_PASS_MERGE", merge)
+        c, _ = oracle_vs_gpu(fs, coracle, fa, kw, tmp_path)
+        assert c["rows"] > 3000 and c["hits_bucketed"] == 0
+        launches[merge] = c["seed_passes"]
+    assert launches["1"] < launches["0"]
+
+
 def test_mixed_lengths_multi_chunk_two_seeds(fs, oracle, tmp_path, monkeypatch):
     """several chunks (each with its own band numbering) and two seed patterns (no multi-band subjects: first-touch keys walk the hits)"""
     monkeypatch.setenv("SOHIT_BUCKET_MIN", "0")
