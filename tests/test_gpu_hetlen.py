@@ -11,7 +11,11 @@ Run on the GPU box:  python -m pytest tests -m gpu -x -q
 import numpy as np
 import pytest
 
-from test_gpu_parity import fs, oracle_vs_gpu, gpu_rows  # noqa: F401  (fs is a fixture)
+import json
+import os
+
+from conftest import GOLD, het_golden_names
+from test_gpu_parity import flags_to_kwargs, fs, oracle_vs_gpu, gpu_rows  # noqa: F401  (fs is a fixture)
 
 pytestmark = pytest.mark.gpu
 
@@ -50,6 +54,37 @@ def het_fasta(n, seed):
 
 def lengths_of(fa):
     return np.array([len(x) for x in fa.split(b"\n")[1::2]])
+
+
+@pytest.mark.parametrize("name", het_golden_names())
+@pytest.mark.parametrize("whole", [False, True], ids=["by_range", "one_search"])
+def test_heterogeneous_lengths_golden_from_the_real_reference(fs, name, whole):
+    """tests/golden/het_*: 300 proteins of log-normal length, subjects of 4562, 4597 and 30 014 residues, searched by the REAL
+    reference for every query below 4096 residues (-l/-u ranges; longer queries crash it at fsearch.py:1396).  by_range: the HIP
+    path searches the same ranges; one_search: it searches ALL queries in one batch (the giants among them, in their own length
+    class) and the rows of the reference-defined queries are cut out of that result -- a query's rows do not depend on its batch."""
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    ref = open(os.path.join(GOLD, name + ".ref.fsa"), "rb").read()
+    want = open(os.path.join(GOLD, name + ".sc"), "rb").read()
+    kw = flags_to_kwargs(meta["flags"])
+    if whole:
+        s, hits, rows = gpu_rows(fs, ref, ref, kw)
+        skipped = set(meta["skipped_queries"])
+        got = b"".join(l + b"\n" for l in rows.split(b"\n")[:-1] if int(l.split(b"\t")[14]) not in skipped)
+        assert sum(1 for l in rows.split(b"\n")[:-1] if int(l.split(b"\t")[14]) in skipped) > 0   # the giants do report rows of their own
+        hits.close(), s.close()
+    else:
+        got = b""
+        for lo, hi in meta["ranges"]:
+            s, hits, rows = gpu_rows(fs, ref, ref, kw, st=lo, ed=hi)
+            got += rows
+            hits.close(), s.close()
+    if got != want:
+        a, b = got.split(b"\n"), want.split(b"\n")
+        for i in range(max(len(a), len(b))):
+            x = a[i] if i < len(a) else b"<none>"
+            y = b[i] if i < len(b) else b"<none>"
+            assert x == y, "row %d differs\n gpu: %s\n ref: %s" % (i, x.decode("latin-1"), y.decode("latin-1"))
 
 
 def test_generator_shape():

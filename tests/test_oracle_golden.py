@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLD, golden_names, launcher_golden_names
+from conftest import GOLD, golden_names, het_golden_names, launcher_golden_names
 
 
 @pytest.fixture(scope="module")
@@ -81,6 +81,24 @@ def test_end_to_end_golden(oracle, name, tmp_path):
     subprocess.run([oracle.EXE, "-p", "blastp", "-i", qry, "-d", ref, "-o", out, "-T", str(tmp_path)] + meta["flags"], check=True,
                    stderr=subprocess.DEVNULL)
     assert open(out, "rb").read() == open(os.path.join(GOLD, name + ".sc"), "rb").read()
+
+
+@pytest.mark.parametrize("name", het_golden_names())
+def test_heterogeneous_lengths_golden(oracle, name, tmp_path):
+    """300 proteins of log-normal length with subjects of 4562, 4597 and 30 014 residues: the REAL reference's rows for every
+    query below 4096 residues (run in -l/-u ranges; it indexes an empty subject tile for longer queries, fsearch.py:1362/1396/
+    1487-1490) against the oracle's, range by range."""
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    ref = os.path.join(GOLD, name + ".ref.fsa")
+    got = b""
+    for lo, hi in meta["ranges"]:
+        out = str(tmp_path / ("r%d.sc" % lo))
+        subprocess.run([oracle.EXE, "-p", "blastp", "-i", ref, "-d", ref, "-o", out, "-T", str(tmp_path), "-l", str(lo), "-u", str(hi)] + meta["flags"],
+                       check=True, stderr=subprocess.DEVNULL)
+        got += open(out, "rb").read()
+    want = open(os.path.join(GOLD, name + ".sc"), "rb").read()
+    assert want.count(b"\n") > 300 and meta["longest_subject"] >= 30000
+    assert got == want
 
 
 @pytest.mark.parametrize("name", ["stage_default", "stage_multi"])
