@@ -123,6 +123,8 @@ struct SeqSet {
     struct { u8* p = nullptr; } d_scls;   // score classes; 16 readable bytes in front (k_ungap's left-pass windows start up to 8 bytes early)
     struct { u8* p = nullptr; } d_scls4;  // score class * 4 (k_ungap's subject side: column offset in its LDS table), same padding
     DevBuf<u32> d_off, d_words, d_pseq;
+    DevBuf<u8> d_ug_store;       // k_ungap1's subject side (class * 8 with sentinels), made on first use
+    bool ug_valid = false;
     DevBuf<u32> d_bound;         // per sequence: upper bound of any alignment score it can take part in (k_seq_bound)
     u32 P = 0, Ppad = 0;
     HashLut lut;
@@ -237,8 +239,30 @@ struct ChunkIndex {
 
 }  // namespace
 
+// Tuning / diagnostic switches, read from the environment ONCE at so_create (none changes results): tools/diag/README.md
+struct Tune {
+    bool ug1 = true;        // SOHIT_UG1=0: singleton groups stay with k_ungap
+    bool ug1_chain = true;      // SOHIT_UG1_CHAIN=0: the groups of two and more hits stay with k_ungap
+    bool ug1_overlap = false;   // SOHIT_UG1_OVERLAP=1: k_ungap (chains) on a second stream beside k_ungap1
+    int ug1_variant = 2;    // SOHIT_UG1_VARIANT: 0 = 32-bit score-table entries, 1 = 16-bit, 2 = 16-bit and two workgroups per CU where the queries fit
+    u32 ug1_wait = 4;       // SOHIT_UG1_WAIT: idle lanes that trigger a hand-out
+    static int geti(const char* k, int dflt) {
+        const char* e = getenv(k);
+        return e ? atoi(e) : dflt;
+    }
+    void read() {
+        ug1 = geti("SOHIT_UG1", 1) != 0;
+        ug1_variant = geti("SOHIT_UG1_VARIANT", 2);
+        ug1_overlap = geti("SOHIT_UG1_OVERLAP", 0) != 0;
+        ug1_chain = geti("SOHIT_UG1_CHAIN", 1) != 0;
+        ug1_wait = (u32)std::max(1, geti("SOHIT_UG1_WAIT", 4));
+    }
+};
+
 struct so_ctx {
     int device = 0;
+    u32 ncu = 256;          // compute units of the device
+    Tune tune;
     hipStream_t st = nullptr;
     // params
     std::string seeds, alphabet;
@@ -287,6 +311,8 @@ struct so_ctx {
     // batch's other preparation and the seed passes of the shorter length classes
     hipStream_t st_side = nullptr;
     hipEvent_t ev_side_go = nullptr, ev_korder = nullptr;
+    hipStream_t st_ug = nullptr;       // k_ungap beside k_ungap1 (Tune::ug1_overlap)
+    hipEvent_t ev_ug_go = nullptr, ev_ug_done = nullptr;
     bool rows_in_flight = false;
     size_t max_hits_per_pass = (size_t)1 << 30;
     u32 max_batch = 131072;  // queries per device batch.  Round 3, config 3 (100k queries), same box: 25000 64.1 ms, 33334 63.0, 2 x 50000 63.0,
@@ -404,6 +430,7 @@ void layout_set(so_ctx* c, SeqSet& s, const bool present[256], size_t nres, u32 
     s.d_scls4.p = s.d_scls4_store.p + SCLS_PAD_FRONT;
     HIP_CHECK(hipMemcpyAsync(c->d_hmap.p, hmap, 256, hipMemcpyHostToDevice, c->st));
     launch_scls(s.d_res.p, nres, c->d_smap.p, s.d_scls.p, s.d_scls4.p, c->st);
+    s.ug_valid = false;
     s.d_bound.ensure((size_t)nseq + 4);
     launch_seq_bound(s.d_scls.p, s.d_off.p, nseq, c->b62c, s.d_bound.p, c->st);
     if ((u64)nres + nseq + 64 > 0xFFFFFFF0ull) throw SoError("sequence set too large for 32-bit packed positions");
@@ -783,6 +810,7 @@ struct Batch {
     DevBuf<u64> cs_kbase;
     DevBuf<u64> keys, keys2;
     DevBuf<u32> hits32, hits32s, bmat, bpart, bt0, btd, bext, bflag, bcnt, bccnt;  // bucketed binning (k_bucket.hip)
+    DevBuf<u64> mlist;   // heads of the groups of two and more hits of a bucketed pass (k_ungap1 -> k_ungap2)
     DevBuf<u32> flags, gidx, ghead;
     DevBuf<u64> p_qs, p_sd, p_ft, p_qs2, tmp64, q_qs, q_sd, q_ft;
     DevBuf<u32> shard;
@@ -1267,7 +1295,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     }
     // pass-list buffers (k_ungap / k_bkt_ungap append the groups that reach MIN_UNGAP)
     const u32 shard_cap = ungap_shard_cap(H);
-    const size_t pcap = (size_t)shard_cap * UG_SHARDS + 2;
+    const size_t pcap = (size_t)shard_cap * UG_SHARDS + 2 + ungap1_list_slack(c->ncu);   // (+ the unused slots of k_ungap1's reserved pieces)
     b.p_qs.ensure(pcap), b.p_sd.ensure(pcap), b.p_ft.ensure(pcap);
     b.shard.ensure(2 * UG_SHARDS + 8);
     b.stepshard.ensure(UG_SHARDS);
@@ -1349,7 +1377,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         sc.lap("seed.bucket_scatter");
         // the grouped hits leave as the buckets' own 32-bit words (k_ungap's W32 input) unless SOHIT_UG_W32=0 asks for the 64-bit keys
         static const bool w32 = !(getenv("SOHIT_UG_W32") && atoi(getenv("SOHIT_UG_W32")) == 0);
-        if (w32) b.hits32s.ensure((size_t)H + 2);
+        if (w32) b.hits32s.ensure((size_t)H + 8);   // (k_ungap1's chains read four words ahead)
         else b.keys2.ensure((size_t)H + 2);
         b.bext.ensure((size_t)nb + 4);
         launch_bkt_extents(b.bmat.p, b.bt0.p, NT, L.R, nqp, nb, c->d_small.p + 2, b.bext.p, c->st);
@@ -1366,8 +1394,46 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         // ... and a chained ungapped score fits the 20 bits k_bkt_best packs above them (at most 11 per residue of the shorter sequence)
         bbest = !(getenv("SOHIT_BUCKET_BEST") && atoi(getenv("SOHIT_BUCKET_BEST")) == 0) && !ft_walk && (kl.ba + kl.bp + ft_bits_entry <= 44) &&
                 (u64)std::min<u32>(pmaxq, ch.maxslen) * 11ull < (1ull << 20);
-        launch_ungap(w32 ? nullptr : b.keys2.p, Hv, kl, klr, btab, pmaxq >= gallop_min, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo,
-                     c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st, w32 ? b.hits32s.p : nullptr, b.bext.p, nb, &L);
+        // singleton groups (84 % of a dense pass's groups) go to k_ungap1, the chains of two and more seeds stay with k_ungap
+        const bool ug1 = w32 && c->tune.ug1 && pmaxq <= ungap1_qcap() && bbest;   // (its pass list has unused slots: only the bucketed reduction skips them)
+        const bool side = ug1 && c->tune.ug1_overlap;
+        hipStream_t ust = side ? c->st_ug : c->st;
+        const bool ug2 = ug1 && c->tune.ug1_chain;   // ... and the longer groups to k_ungap2, through the list of their heads k_ungap1 writes
+        if (ug1 && !c->ref.ug_valid) {
+            const size_t nres = c->ref.res.size();
+            c->ref.d_ug_store.ensure(nres + 2 * (size_t)U1_UG_PAD);
+            launch_make_ug(c->ref.d_scls.p, c->ref.d_off.p, (u32)c->ref.N, nres, 8u, c->ref.d_ug_store.p + U1_UG_PAD, c->st);
+            c->ref.ug_valid = true;
+        }
+        if (ug2) {
+            if (!b.dev.ug_valid) {
+                const size_t nres = b.h_off[b.nq];
+                b.dev.d_ug_store.ensure(nres + 2 * (size_t)U1_UG_PAD);
+                launch_make_ug(b.dev.d_scls.p, b.dev.d_off.p, b.nq, nres, 1u, b.dev.d_ug_store.p + U1_UG_PAD, c->st);
+                b.dev.ug_valid = true;
+            }
+            b.mlist.ensure(ungap1_mlist_cap(Hv, c->ncu));
+        }
+        if (side) {   // the chains' kernel on a second stream, beside k_ungap1 (both append to the pass list)
+            HIP_CHECK(hipEventRecord(c->ev_ug_go, c->st));
+            HIP_CHECK(hipStreamWaitEvent(c->st_ug, c->ev_ug_go, 0));
+        }
+        if (ug1)
+            launch_ungap1(c->ncu, c->tune.ug1_variant, pmaxq, b.hits32s.p, b.bext.p, nb, L, kl, klr, btab, c->tune.ug1_wait, b.dev.d_scls.p, b.dev.d_off.p,
+                          c->ref.d_ug_store.p + U1_UG_PAD, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.bflag.p + 1, b.shard.p, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p,
+                          ug2 ? b.mlist.p : nullptr, b.bflag.p + 3, c->st);
+        if (ug2)
+            launch_ungap2(c->ncu, b.mlist.p, b.bflag.p + 3, b.hits32s.p, b.bext.p, L, kl, klr, btab, c->tune.ug1_wait, b.dev.d_ug_store.p + U1_UG_PAD, b.dev.d_off.p,
+                          c->ref.d_ug_store.p + U1_UG_PAD, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.bflag.p + 2, b.shard.p, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p,
+                          c->st);
+        else
+            launch_ungap(w32 ? nullptr : b.keys2.p, Hv, kl, klr, btab, pmaxq >= gallop_min, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p,
+                         c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, ust, w32 ? b.hits32s.p : nullptr,
+                         b.bext.p, nb, &L, ug1);
+        if (side) {
+            HIP_CHECK(hipEventRecord(c->ev_ug_done, c->st_ug));
+            HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_ug_done, 0));
+        }
         // the pass records are binned by (query, range of 2^wb chunk SEQUENCES): the same layout unless bands and sequences differ
         bL = L;
         bL.R = (u32)(((u64)nseq_chunk + (1ull << wb) - 1) >> wb);
@@ -2507,6 +2573,12 @@ so_ctx* so_create(int device, const so_params* params) {
         HIP_CHECK(hipSetDevice(device));
         c = new so_ctx();
         c->device = device;
+        c->tune.read();
+        {
+            int ncu = 0;
+            HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+            c->ncu = (u32)std::max(1, ncu);
+        }
         memset(&c->cnt, 0, sizeof c->cnt);
         set_params(c, params);
         HIP_CHECK(hipStreamCreate(&c->st));
@@ -2518,6 +2590,9 @@ so_ctx* so_create(int device, const so_params* params) {
         HIP_CHECK(hipStreamCreateWithFlags(&c->st_side, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_side_go, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_korder, hipEventDisableTiming));
+        HIP_CHECK(hipStreamCreateWithFlags(&c->st_ug, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&c->ev_ug_go, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&c->ev_ug_done, hipEventDisableTiming));
         upload_constants(c);
         if (!(getenv("SOHIT_WARM") && atoi(getenv("SOHIT_WARM")) == 0)) c->warm = std::thread(warm_sort_modules, device);
         g_create_err.clear();

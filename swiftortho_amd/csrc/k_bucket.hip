@@ -585,8 +585,9 @@ __global__ __launch_bounds__(256) void k_rec_count(const u64* __restrict__ p_qs,
     // (a returning atomic per record serialises on those few addresses: 1.4 ms instead of 0.1 ms on config 2)
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool have = i < n;
-    const u32 bk = have ? rec_bucket(p_qs[i], bs, L) : 0xFFFFFFFFu;
+    const u64 qs = i < n ? p_qs[i] : UG_REC_NONE;
+    const bool have = qs != UG_REC_NONE;   // (k_ungap1 leaves the unused slots of its reserved pieces marked)
+    const u32 bk = have ? rec_bucket(qs, bs, L) : 0xFFFFFFFFu;
     const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned long long todo = __ballot(have);
     u32 r = 0;
@@ -610,6 +611,7 @@ __global__ __launch_bounds__(256) void k_rec_scatter(const u64* __restrict__ p_q
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const u64 qs = p_qs[i];
+    if (qs == UG_REC_NONE) return;
     const u32 o = boff[rec_bucket(qs, kl.bs, L)] + rnk[i];
     q_qs[o] = qs, q_sd[o] = p_sd[i], q_ft[o] = ft_key_of_head(p_ft[i], kl, ft_bits_entry, bsp, roff);
 }

@@ -62,7 +62,7 @@ enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN =
 template <int CPI /*chunks per loop iteration*/, bool BANDS, bool GALLOP, bool W32>
 __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restrict__ keys, const u32* __restrict__ words, const u32* __restrict__ bext, u32 nb, BktLayout L,
                                                          u32 H, KeyLayout kl, int rbs, int rsh_subj, int rsh_diag, int rdoff /*klr's fields (BANDS / W32)*/,
-                                                         const uint2* __restrict__ btab, int ft_walk, u32 wait_n, u32 range /*head positions per wave*/,
+                                                         const uint2* __restrict__ btab, int ft_walk /*bit 1 (W32): singleton groups are k_ungap1's, skip them*/, u32 wait_n, u32 range /*head positions per wave*/,
                                                          const u8* __restrict__ q_scls, const u32* __restrict__ qoff,
                                                          const u8* __restrict__ r_scls,
                                                          const u32* __restrict__ roff /*chunk-local offsets (absolute values)*/,
@@ -103,6 +103,8 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
     const u64 qall = (1ull << kl.bq) - 1ull;
     const u64 pmask = (1ull << kl.bp) - 1ull;
     const u32 shard = blockIdx.x & (UG_SHARDS - 1);
+    const bool skip_single = (ft_walk & 2) != 0;
+    ft_walk &= 1;
     const u8* q_m16 = q_scls - 16;  // both class arrays have 16 readable bytes in front (left windows start up to 8 bytes early)
     const u8* r_m16 = r_scls - 16;
 
@@ -166,9 +168,11 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                 u32 wv = pos < H ? words[pos] : 0x80000000u;   // (past the end: reads as the start of another bucket)
                 u32 wp = (u32)__shfl_up((int)wv, 1);
                 if (lane == 0) wp = cur == 0 ? 0u : words[cur - 1];
-                const u32 wn = (u32)__shfl_down((int)wv, 1);
-                const bool head = valid && ((wv >> 31) != 0 || ((wv & WM) >> L.bp) != ((wp & WM) >> L.bp));
-                const bool sing = (lane < 63) && ((wn >> 31) != 0 || ((wn & WM) >> L.bp) != ((wv & WM) >> L.bp));
+                u32 wn = (u32)__shfl_down((int)wv, 1);
+                if (skip_single && lane == 63) wn = pos + 1u < H ? words[pos + 1u] : 0x80000000u;   // (exact: both kernels must agree on what a singleton is)
+                bool head = valid && ((wv >> 31) != 0 || ((wv & WM) >> L.bp) != ((wp & WM) >> L.bp));
+                const bool sing = (lane < 63 || skip_single) && ((wn >> 31) != 0 || ((wn & WM) >> L.bp) != ((wv & WM) >> L.bp));
+                if (skip_single && sing) head = false;
                 // buckets of the 64 positions: the scan's bucket, except behind a bucket start other than its own (rare: a bucket holds
                 // a thousand hits or more) -- those starts are walked one by one, skipping empty buckets
                 u32 lqr = ((L.qa + bqrel) << 10) | brange;
@@ -731,7 +735,7 @@ u32 ungap_shard_cap(u32 H) {
 
 void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& klr, const void* btab, bool gallop, bool ft_walk, const u8* q_scls, const u32* qoff,
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt, u32 shard_cap, u64* p_qs, u64* p_sd,
-                  u64* p_ft, unsigned long long* group_count, hipStream_t st, const u32* words, const u32* bext, u32 nb, const BktLayout* L) {
+                  u64* p_ft, unsigned long long* group_count, hipStream_t st, const u32* words, const u32* bext, u32 nb, const BktLayout* L, bool skip_single) {
     if (!H) return;
     // SOHIT_UG_CPI / SOHIT_UG_WAIT: tuning switches (results do not depend on them)
     const int cpi = getenv("SOHIT_UG_CPI") ? atoi(getenv("SOHIT_UG_CPI")) : UW_CPI;
@@ -748,7 +752,7 @@ void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& 
         while (range > 256u && (u64)H / range < 4096ull) range >>= 1;
     const dim3 g((unsigned)(((u64)H + (u64)range * UW_WAVES - 1) / ((u64)range * UW_WAVES))), bl(64 * UW_WAVES);
 #define UG_LAUNCH(K) hipLaunchKernelGGL(K, g, bl, 0, st, keys, words, bext, nb, words ? *L : L0, H, kl, klr.bs, klr.sh_subj, klr.sh_diag, (int)klr.diag_off, (const uint2*)btab, \
-                                        ft_walk ? 1 : 0, wait_n, range, q_scls, qoff, r_scls, roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count)
+                                        (ft_walk ? 1 : 0) | (skip_single && words ? 2 : 0), wait_n, range, q_scls, qoff, r_scls, roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count)
     if (words) {   // the buckets' 32-bit words (k_bkt_group), bucketed passes
         if (gallop) {
             if (btab) UG_LAUNCH((k_ungap<3, true, true, true>));

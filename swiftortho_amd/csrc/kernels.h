@@ -87,7 +87,27 @@ void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& 
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt, u32 shard_cap, u64* p_qs, u64* p_sd,
                   u64* p_ft, unsigned long long* group_count, hipStream_t st,
                   // bucketed passes: instead of `keys`, the buckets' sorted 32-bit words (launch_bkt_group with words32), their extents and layout
-                  const u32* words = nullptr, const u32* bext = nullptr, u32 nb = 0, const BktLayout* L = nullptr);
+                  const u32* words = nullptr, const u32* bext = nullptr, u32 nb = 0, const BktLayout* L = nullptr,
+                  bool skip_single = false /*bucketed passes: the singleton groups were k_ungap1's*/);
+
+// k_ungap1.hip: the singleton groups of a bucketed pass (queries up to U1_QCAP residues); pass records are appended like k_ungap's
+#define UG_REC_NONE 0xFFFFFFFFFFFFFFFFull   // p_qs of an unused pass-list slot (k_ungap1 reserves the list in pieces)
+#define U1_QCAP 1024          // longest query (its classes sit in an LDS slot per wave)
+#define U1_UG_PAD 4096        // sentinel bytes in front of and behind the subject-side array (a dropped pass keeps reading while the other one runs)
+u32 ungap1_qcap();
+size_t ungap1_list_slack(u32 ncu);   // pass-list slots its waves may leave unused
+// class * mul of every residue, position 0 of every sequence and both pads = the sentinel class (mul = 8: the subject side r_ug; mul = 1:
+// the chain kernel's query side q_ug); `out` points U1_UG_PAD bytes into an allocation of nres + 2 * U1_UG_PAD bytes
+void launch_make_ug(const u8* scls, const u32* off, u32 nseq, size_t nres, u32 mul, u8* out, hipStream_t st);
+size_t ungap1_mlist_cap(u32 H, u32 ncu);   // entries of the chain list of a pass of H hits
+// mlist / mlist_cnt (nullable; counter zeroed): the heads of the groups of two and more hits, for launch_ungap2; without them those
+// groups are launch_ungap's (skip_single)
+void launch_ungap1(u32 ncu, int variant, u32 pmaxq, const u32* words, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, const KeyLayout& klr,
+                   const void* btab, u32 wait_n, const u8* q_scls, const u32* qoff, const u8* r_ug, const u32* roff, const signed char* b62g, u32* work_ctr /*zeroed*/,
+                   u32* shard_cnt, u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, u64* mlist, u32* mlist_cnt, hipStream_t st);
+void launch_ungap2(u32 ncu, const u64* mlist, const u32* mlist_cnt, const u32* words, const u32* bext, const BktLayout& L, const KeyLayout& kl, const KeyLayout& klr,
+                   const void* btab, u32 wait_n, const u8* q_ug, const u32* qoff, const u8* r_ug, const u32* roff, const signed char* b62g, u32* work_ctr /*zeroed*/,
+                   u32* shard_cnt, u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, hipStream_t st);
 void launch_first_touch(bool walk, const u64* keys, u32 H, const KeyLayout& kl, int ft_bits_entry, int bsp, const u32* roff, u64* p_ft, u32 n,
                         hipStream_t st);
 void launch_shard_scan(const u32* shard_cnt, u32* shard_off, hipStream_t st);
