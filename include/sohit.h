@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SOHIT_ABI_VERSION 1
+#define SOHIT_ABI_VERSION 2
 
 typedef struct so_ctx so_ctx;
 
@@ -92,6 +92,10 @@ typedef struct so_counters {
     int64_t align_wide;                /* score-only alignments the packed 16-bit aligner could not take (32-bit kernel)       */
     int64_t cells_wide;                /* their band cells (`cells` counts every task of the early-stop rounds once)            */
     int64_t seed_passes;               /* seed passes run (one per length class and chunk; sparse neighbouring classes share one) */
+    /* round 5 (ABI 2).  With SOHIT_UG_COUNT=1 in the environment of so_create the extension kernels run their counting instances: */
+    int64_t ungap_steps;               /* b62 lookups of the ungapped extension = the reference's `flag` (fsearch.py:2467, 2482)  */
+    int64_t groups_single;             /* groups of one seed hit, extended by k_ungap1                                            */
+    int64_t groups_chain;              /* groups of two and more hits, chained by k_ungap2 (the rest of `groups`: k_ungap)        */
 } so_counters;
 
 /* Lifetime.  Replaces: spawning `fsearch-c` with its flags (find_hit.py:119-123). */

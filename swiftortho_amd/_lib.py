@@ -28,7 +28,8 @@ class SoCounters(C.Structure):
                 ("align_launches", C.c_int64), ("align_ms", C.c_double),
                 ("index_ms", C.c_double), ("seed_ms", C.c_double), ("group_ms", C.c_double), ("phase2_ms", C.c_double),
                 ("total_ms", C.c_double), ("count_launches", C.c_int64), ("count_ms", C.c_double),
-                ("hits_bucketed", C.c_int64), ("align_wide", C.c_int64), ("cells_wide", C.c_int64), ("seed_passes", C.c_int64)]
+                ("hits_bucketed", C.c_int64), ("align_wide", C.c_int64), ("cells_wide", C.c_int64), ("seed_passes", C.c_int64),
+                ("ungap_steps", C.c_int64), ("groups_single", C.c_int64), ("groups_chain", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -141,7 +142,7 @@ def load():
     L.so_mcl.argtypes = [C.c_int, i64, vp, vp, vp, C.c_double, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.POINTER(SoMclResult)]
     L.so_mcl_free.argtypes = [C.POINTER(SoMclResult)]
     L.so_mcl_last_error.restype = cp
-    if L.so_abi_version() != 1:
+    if L.so_abi_version() != 2:
         raise ImportError("libsohit.so ABI version mismatch")
     _lib = L
     return L

@@ -242,6 +242,7 @@ struct ChunkIndex {
 // Tuning / diagnostic switches, read from the environment ONCE at so_create (none changes results): tools/diag/README.md
 struct Tune {
     bool ug1 = true;        // SOHIT_UG1=0: singleton groups stay with k_ungap
+    bool count_steps = false;   // SOHIT_UG_COUNT=1: the extension kernels count their b62 lookups (so_counters.ungap_steps; slower instances)
     bool ug1_chain = true;      // SOHIT_UG1_CHAIN=0: the groups of two and more hits stay with k_ungap
     bool ug1_overlap = false;   // SOHIT_UG1_OVERLAP=1: k_ungap (chains) on a second stream beside k_ungap1
     int ug1_variant = 2;    // SOHIT_UG1_VARIANT: 0 = 32-bit score-table entries, 1 = 16-bit, 2 = 16-bit and two workgroups per CU where the queries fit
@@ -255,6 +256,7 @@ struct Tune {
         ug1_variant = geti("SOHIT_UG1_VARIANT", 2);
         ug1_overlap = geti("SOHIT_UG1_OVERLAP", 0) != 0;
         ug1_chain = geti("SOHIT_UG1_CHAIN", 1) != 0;
+        count_steps = geti("SOHIT_UG_COUNT", 0) != 0;
         ug1_wait = (u32)std::max(1, geti("SOHIT_UG1_WAIT", 4));
     }
 };
@@ -1298,16 +1300,17 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     const size_t pcap = (size_t)shard_cap * UG_SHARDS + 2 + ungap1_list_slack(c->ncu);   // (+ the unused slots of k_ungap1's reserved pieces)
     b.p_qs.ensure(pcap), b.p_sd.ensure(pcap), b.p_ft.ensure(pcap);
     b.shard.ensure(2 * UG_SHARDS + 8);
-    b.stepshard.ensure(UG_SHARDS);
+    b.stepshard.ensure(UG_SHARDS + 4);   // group counts, then (Tune::count_steps) b62 lookups, singleton groups, chained groups
     b.bflag.ensure(4);
     double t1 = wall();
     bool bbest = false;   // set by group_bucketed: pass records were flushed per bucket, k_bkt_best reduces them
     BktLayout bL;
     u32 bnb = 0;
     memset(&bL, 0, sizeof bL);
+    unsigned long long* const ugstat = c->tune.count_steps ? b.stepshard.p + UG_SHARDS : nullptr;   // the counting instances of the extension kernels
     auto reset_pass_lists = [&] {
         HIP_CHECK(hipMemsetAsync(b.shard.p, 0, (2 * UG_SHARDS + 8) * sizeof(u32), c->st));
-        HIP_CHECK(hipMemsetAsync(b.stepshard.p, 0, UG_SHARDS * sizeof(unsigned long long), c->st));
+        HIP_CHECK(hipMemsetAsync(b.stepshard.p, 0, (UG_SHARDS + 4) * sizeof(unsigned long long), c->st));
         HIP_CHECK(hipMemsetAsync(b.bflag.p, 0, 4 * sizeof(u32), c->st));
     };
 
@@ -1421,15 +1424,15 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         if (ug1)
             launch_ungap1(c->ncu, c->tune.ug1_variant, pmaxq, b.hits32s.p, b.bext.p, nb, L, kl, klr, btab, c->tune.ug1_wait, b.dev.d_scls.p, b.dev.d_off.p,
                           c->ref.d_ug_store.p + U1_UG_PAD, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.bflag.p + 1, b.shard.p, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p,
-                          ug2 ? b.mlist.p : nullptr, b.bflag.p + 3, c->st);
+                          ug2 ? b.mlist.p : nullptr, b.bflag.p + 3, ugstat, c->st);
         if (ug2)
             launch_ungap2(c->ncu, b.mlist.p, b.bflag.p + 3, b.hits32s.p, b.bext.p, L, kl, klr, btab, c->tune.ug1_wait, b.dev.d_ug_store.p + U1_UG_PAD, b.dev.d_off.p,
                           c->ref.d_ug_store.p + U1_UG_PAD, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.bflag.p + 2, b.shard.p, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p,
-                          c->st);
+                          ugstat, c->st);
         else
             launch_ungap(w32 ? nullptr : b.keys2.p, Hv, kl, klr, btab, pmaxq >= gallop_min, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p,
                          c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, ust, w32 ? b.hits32s.p : nullptr,
-                         b.bext.p, nb, &L, ug1);
+                         b.bext.p, nb, &L, ug1, ugstat);
         if (side) {
             HIP_CHECK(hipEventRecord(c->ev_ug_done, c->st_ug));
             HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_ug_done, 0));
@@ -1475,7 +1478,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     sc.lap("group.sort_keys");
     // group walk + chained ungapped extension (the kernel finds the group heads itself)
     launch_ungap(b.keys2.p, H, kl, klr, btab, pmaxq >= gallop_min, ft_walk, b.dev.d_scls.p, b.dev.d_off.p, c->ref.d_scls4.p, c->ref.d_off.p + ch.seq_lo,
-                 c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st);
+                 c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st, nullptr, nullptr, 0, nullptr, false, ugstat);
     };
 
     const bool lk_ablation = getenv("SOHIT_LK_VARIANT") && (atoi(getenv("SOHIT_LK_VARIANT")) == 1 || atoi(getenv("SOHIT_LK_VARIANT")) == 2);
@@ -1495,13 +1498,14 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         launch_shard_scan(b.shard.p, shard_off, c->st);
         u32 NP;
         {
-            static_assert(UG_SHARDS * sizeof(unsigned long long) + sizeof(u32) <= 1024, "h_small too small");
+            static_assert((UG_SHARDS + 4) * sizeof(unsigned long long) + sizeof(u32) <= 1024, "h_small too small");
             unsigned long long* gc = (unsigned long long*)small_host(c);
-            u32* np = (u32*)(gc + UG_SHARDS);
-            HIP_CHECK(hipMemcpyAsync(gc, b.stepshard.p, UG_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
+            u32* np = (u32*)(gc + UG_SHARDS + 4);
+            HIP_CHECK(hipMemcpyAsync(gc, b.stepshard.p, (UG_SHARDS + 4) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
             HIP_CHECK(hipMemcpyAsync(np, shard_off + UG_SHARDS, sizeof(u32), hipMemcpyDeviceToHost, c->st));
             HIP_CHECK(hipStreamSynchronize(c->st));
             for (int k = 0; k < UG_SHARDS; ++k) c->cnt.groups += (i64)gc[k];
+            c->cnt.ungap_steps += (i64)gc[UG_SHARDS], c->cnt.groups_single += (i64)gc[UG_SHARDS + 1], c->cnt.groups_chain += (i64)gc[UG_SHARDS + 2];
             NP = *np;
         }
         sc.lap("group.ungap");
@@ -1868,6 +1872,9 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     const size_t var_budget_words = (size_t)1 << 31;
     const u32 TU = align_trace_unit();
     auto trace_offsets = [&](const u32* list, u32 n) -> size_t {   // -> words the list's traces need
+        // the offsets are a 32-bit scan of units: a list whose total could wrap (no task needs more units than the batch-wide stride holds)
+        // takes the slab path -- "does not fit" for both callers
+        if ((u64)n * ((u64)(stride + TU - 1) / TU + 1) >= (1ull << 32)) return ~(size_t)0;
         b.tr_units.ensure((size_t)n + 4), b.tr_ofs.ensure((size_t)n + 4);
         c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)n + 1) + 8);
         launch_trace_units(b.tasks.p, list, n, b.dev.d_off.p, c->ref.d_off.p, b.tr_units.p, c->st);
@@ -2763,23 +2770,27 @@ int so_write_sc(so_ctx* c, const so_hit* hits, int64_t n, const char* path, cons
         if (!f) throw SoError(std::string("cannot open output ") + path);
         // Rows are formatted in slabs of 16384 by a few threads that take slabs in order from a counter; the calling thread writes
         // every slab as soon as it and all slabs before it are done, so formatting and writing overlap and the threads live as long
-        // as the call (round 3 started eight threads per 262144 rows and wrote between the groups).
+        // as the call (round 3 started eight threads per 262144 rows and wrote between the groups).  A formatter waits while it is more
+        // than 4 * nt slabs ahead of the writer: with a slow disk the text of a 300 M-row result would otherwise pile up in memory.
         const int64_t SLAB = 16384;
         const int64_t nslab = (n + SLAB - 1) / SLAB;
         const unsigned nt = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())), nslab));
         std::vector<std::vector<char>> bufs((size_t)nslab);
         std::vector<std::atomic<int>> ready((size_t)nslab);
         for (auto& r : ready) r.store(0);
-        std::atomic<int64_t> next(0);
+        std::atomic<int64_t> next(0), written(0);
         std::atomic<bool> failed(false);
         std::exception_ptr err;
         std::mutex mu;
         std::vector<std::thread> th;
+        const int64_t ahead = 4 * (int64_t)nt;
         for (unsigned t = 0; t < nt; ++t)
             th.emplace_back([&] {
                 for (;;) {
                     const int64_t k = next.fetch_add(1);
                     if (k >= nslab || failed.load()) break;
+                    while (k - written.load(std::memory_order_acquire) >= ahead && !failed.load()) std::this_thread::yield();
+                    if (failed.load()) break;
                     try {
                         std::vector<char>& b = bufs[(size_t)k];
                         const int64_t lo = k * SLAB, hi = std::min<int64_t>(n, lo + SLAB);
@@ -2800,7 +2811,9 @@ int so_write_sc(so_ctx* c, const so_hit* hits, int64_t n, const char* path, cons
             std::vector<char>& b = bufs[(size_t)k];
             if (ok && !b.empty()) ok = fwrite(b.data(), 1, b.size(), f) == b.size();
             std::vector<char>().swap(b);
+            written.store(k + 1, std::memory_order_release);
         }
+        failed.store(failed.load() || !ok);   // (a short write: let waiting formatters go)
         for (auto& x : th) x.join();
         if (fclose(f) != 0) ok = false;
         if (err) std::rethrow_exception(err);

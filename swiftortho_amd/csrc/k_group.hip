@@ -59,7 +59,7 @@ enum { PH_NEED = 0, PH_HIT = 1, PH_RIGHT = 2, PH_LEFT = 3, PH_DONE = 4, PH_FIN =
 // bucket; the bucket (query, band range) of a word follows from its position (bext).  A group = equal word >> bp inside one bucket.
 // Neither the grouping kernel writes nor this one reads the 8-byte keys (8 B per hit each way), and every per-group field is a 32-bit
 // shift instead of a 64-bit one.  Records are always written in the record layout (klr's fields), as with BANDS.
-template <int CPI /*chunks per loop iteration*/, bool BANDS, bool GALLOP, bool W32>
+template <int CPI /*chunks per loop iteration*/, bool BANDS, bool GALLOP, bool W32, bool COUNT /*count the b62 lookups (Fasta.ungap's `flag`) into stat[0]*/>
 __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restrict__ keys, const u32* __restrict__ words, const u32* __restrict__ bext, u32 nb, BktLayout L,
                                                          u32 H, KeyLayout kl, int rbs, int rsh_subj, int rsh_diag, int rdoff /*klr's fields (BANDS / W32)*/,
                                                          const uint2* __restrict__ btab, int ft_walk /*bit 1 (W32): singleton groups are k_ungap1's, skip them*/, u32 wait_n, u32 range /*head positions per wave*/,
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                                                          const u32* __restrict__ roff /*chunk-local offsets (absolute values)*/,
                                                          const signed char* __restrict__ b62g, u32* __restrict__ shard_cnt /*[UG_SHARDS]*/,
                                                          u32 shard_cap, u64* __restrict__ p_qs, u64* __restrict__ p_sd,
-                                                         u64* __restrict__ p_ft, unsigned long long* __restrict__ group_count) {
+                                                         u64* __restrict__ p_ft, unsigned long long* __restrict__ group_count, unsigned long long* __restrict__ stat) {
     // score table addressed by ONE v_perm per element: (query class << 8) | (subject class * 4).  Row stride 256 B; the
     // * 4 spreads the 24 subject classes over 24 LDS banks (a row stride of 64 dwords keeps the bank = column / 4).
     // 16-bit entries T = (score << 4) - 1 at byte offset (query class << 8) | (subject class * 4): adding T to the running
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
     u32 qfront = 0, qback = 0;  // ring counters
     u32 npb = 0;               // buffered pass records
     u32 ngroups = 0;
+    unsigned long long nst = 0;   // COUNT: elements scored by this lane
 
     // lane state
     int phase = PH_NEED;
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
                 const int mp_in = mp;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
+                    if (COUNT) nst += (score8 > (UG_PIN8 >> 1) && k < m) ? 1u : 0u;   // the pass is alive and the element inside its limits
                     score8 += sc[k];
                     const bool drop = mp - score8 >= ((DROPX + 1) << 4) - 7;
                     mp = max(mp, score8);
@@ -470,6 +472,11 @@ __global__ __launch_bounds__(64 * UW_WAVES, 8) void k_ungap(const u64* __restric
         }
     }
     if (lane == 0 && ngroups) atomicAdd(&group_count[shard], (unsigned long long)ngroups);
+    if (COUNT) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nst += __shfl_xor(nst, o);
+        if (lane == 0 && nst) atomicAdd(&stat[0], nst);
+    }
 }
 
 // ---- first-touch keys of the passing groups ----------------------------------------------------------
@@ -735,7 +742,8 @@ u32 ungap_shard_cap(u32 H) {
 
 void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& klr, const void* btab, bool gallop, bool ft_walk, const u8* q_scls, const u32* qoff,
                   const u8* r_scls, const u32* roff, const signed char* b62g, u32* shard_cnt, u32 shard_cap, u64* p_qs, u64* p_sd,
-                  u64* p_ft, unsigned long long* group_count, hipStream_t st, const u32* words, const u32* bext, u32 nb, const BktLayout* L, bool skip_single) {
+                  u64* p_ft, unsigned long long* group_count, hipStream_t st, const u32* words, const u32* bext, u32 nb, const BktLayout* L, bool skip_single,
+                  unsigned long long* stat) {
     if (!H) return;
     // SOHIT_UG_CPI / SOHIT_UG_WAIT: tuning switches (results do not depend on them)
     const int cpi = getenv("SOHIT_UG_CPI") ? atoi(getenv("SOHIT_UG_CPI")) : UW_CPI;
@@ -752,29 +760,37 @@ void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& 
         while (range > 256u && (u64)H / range < 4096ull) range >>= 1;
     const dim3 g((unsigned)(((u64)H + (u64)range * UW_WAVES - 1) / ((u64)range * UW_WAVES))), bl(64 * UW_WAVES);
 #define UG_LAUNCH(K) hipLaunchKernelGGL(K, g, bl, 0, st, keys, words, bext, nb, words ? *L : L0, H, kl, klr.bs, klr.sh_subj, klr.sh_diag, (int)klr.diag_off, (const uint2*)btab, \
-                                        (ft_walk ? 1 : 0) | (skip_single && words ? 2 : 0), wait_n, range, q_scls, qoff, r_scls, roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count)
-    if (words) {   // the buckets' 32-bit words (k_bkt_group), bucketed passes
-        if (gallop) {
-            if (btab) UG_LAUNCH((k_ungap<3, true, true, true>));
-            else UG_LAUNCH((k_ungap<3, false, true, true>));
-        } else {
-            if (btab) UG_LAUNCH((k_ungap<3, true, false, true>));
-            else UG_LAUNCH((k_ungap<3, false, false, true>));
-        }
+                                        (ft_walk ? 1 : 0) | (skip_single && words ? 2 : 0), wait_n, range, q_scls, qoff, r_scls, roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count, stat)
+#define UG_PICK(C, BA, GA, W, CT) UG_LAUNCH((k_ungap<C, BA, GA, W, CT>))
+#define UG_BY_FLAGS(W, CT)                   \
+    do {                                     \
+        if (gallop) {                        \
+            if (btab) UG_PICK(3, true, true, W, CT);   \
+            else UG_PICK(3, false, true, W, CT);       \
+        } else {                             \
+            if (btab) UG_PICK(3, true, false, W, CT);  \
+            else UG_PICK(3, false, false, W, CT);      \
+        }                                    \
+    } while (0)
+    if (stat) {   // counting instances (tests, bench's per-kernel work rates)
+        if (words) UG_BY_FLAGS(true, true);
+        else UG_BY_FLAGS(false, true);
         return;
     }
-    if (gallop) {
-        if (btab) UG_LAUNCH((k_ungap<3, true, true, false>));
-        else UG_LAUNCH((k_ungap<3, false, true, false>));
-    } else if (btab) {
-        if (cpi == 1) UG_LAUNCH((k_ungap<1, true, false, false>));
-        else if (cpi == 2) UG_LAUNCH((k_ungap<2, true, false, false>));
-        else UG_LAUNCH((k_ungap<3, true, false, false>));
-    } else {
-        if (cpi == 1) UG_LAUNCH((k_ungap<1, false, false, false>));
-        else if (cpi == 2) UG_LAUNCH((k_ungap<2, false, false, false>));
-        else UG_LAUNCH((k_ungap<3, false, false, false>));
+    if (words) {   // the buckets' 32-bit words (k_bkt_group), bucketed passes
+        UG_BY_FLAGS(true, false);
+        return;
     }
+    if (gallop || cpi == 3) UG_BY_FLAGS(false, false);
+    else if (btab) {
+        if (cpi == 1) UG_PICK(1, true, false, false, false);
+        else UG_PICK(2, true, false, false, false);
+    } else {
+        if (cpi == 1) UG_PICK(1, false, false, false, false);
+        else UG_PICK(2, false, false, false, false);
+    }
+#undef UG_BY_FLAGS
+#undef UG_PICK
 #undef UG_LAUNCH
 }
 

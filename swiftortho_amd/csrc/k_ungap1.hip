@@ -103,11 +103,22 @@ struct U1Track {
     int gsel;
 };
 
+// COUNT instances: the b62 lookups the reference makes (Fasta.ungap's `flag`, fsearch.py:2467, 2482), recomputed per direction in plain
+// 32-bit arithmetic beside the packed passes: an element counts when its pass is alive and it is no sentinel (the reference's loop
+// condition ends the pass in front of a sentinel position; the element that drops a pass below the X-drop line is still counted)
+struct U1Count {
+    int sR, mR, sL, mL;
+    bool aR, aL;
+    u32 n;
+    __device__ __forceinline__ void start() { sR = mR = sL = mL = 0, aR = aL = true; }
+};
+
 // ---- one step: 16 elements of the right pass (low halves) and 16 of the left pass (high halves) ----
 // qr4 / sr4: the right windows (element k = byte k), ql4 / sl4: the left windows (element k = byte 15 - k).  Returns the drop mask: all
 // ones in the halves whose pass has ended.
-template <int TSH, bool CHAIN>
-__device__ __forceinline__ u32 u1_step(const uint4& qr4, const uint4& ql4, const uint4& sr4, const uint4& sl4, u32 lanebase, pk16& S, pk16& M, U1Track& tr, int eb) {
+template <int TSH, bool CHAIN, bool COUNT>
+__device__ __forceinline__ u32 u1_step(const uint4& qr4, const uint4& ql4, const uint4& sr4, const uint4& sl4, u32 lanebase, pk16& S, pk16& M, U1Track& tr, int eb,
+                                       U1Count& ct) {
     const pk16 c30 = {30, 30}, pinv = {U1_PIN, U1_PIN};
     const u32* qrd = reinterpret_cast<const u32*>(&qr4);
     const u32* qld = reinterpret_cast<const u32*>(&ql4);
@@ -123,6 +134,23 @@ __device__ __forceinline__ u32 u1_step(const uint4& qr4, const uint4& ql4, const
         const u32 ar = (xr << TSH) + lanebase, al = (xl << TSH) + lanebase;
         const u32 cr = *(u1_lds_u16*)(size_t)ar, cl = *(u1_lds_u16*)(size_t)al;
         const pk16 C = __builtin_bit_cast(pk16, __builtin_amdgcn_perm(cl, cr, 0x05040100u));
+        if (COUNT) {
+            const int vr = (short)cr, vl = (short)cl;
+            if (ct.aR) {
+                if (vr == -100) ct.aR = false;
+                else {
+                    ++ct.n, ct.sR += vr, ct.mR = max(ct.mR, ct.sR);
+                    if (ct.mR - ct.sR > DROPX) ct.aR = false;
+                }
+            }
+            if (ct.aL) {
+                if (vl == -100) ct.aL = false;
+                else {
+                    ++ct.n, ct.sL += vl, ct.mL = max(ct.mL, ct.sL);
+                    if (ct.mL - ct.sL > DROPX) ct.aL = false;
+                }
+            }
+        }
         S += C;
         M = __builtin_elementwise_max(M, S);
         // X-drop, tested once per group of <= 3 elements (k = 2, 5, 8, 11, 14, 15) on the group's LOWEST running score against the
@@ -198,12 +226,13 @@ __device__ __forceinline__ u32 u1_reserve(u32 n, int lane, u32& ch_pos, u32& ch_
 // two workgroups = 8 waves per SIMD; 1024-residue slots or 32-bit entries: one).
 // mlist (nullable): the heads of the groups of two and more hits are appended to it as position | bucket << 32, for k_ungap2 (pieces
 // of U1_LCHUNK entries per wave, unused entries = UG_REC_NONE); without it those groups are k_ungap's (skip_single).
-template <bool BANDS, int TSH, int QCAP, int WGS>
+template <bool BANDS, int TSH, int QCAP, int WGS, bool COUNT>
 __global__ __launch_bounds__(64 * U1_WAVES, WGS) __attribute__((amdgpu_num_sgpr(80))) void k_ungap1(   // (8 waves per SIMD need <= 96 SGPRs with VCC and the rest)
     const u32* __restrict__ words, const u32* __restrict__ bext, u32 nb, BktLayout L, int sh_qpos, int diag_off, int rbs, int rsh_subj, int rsh_diag, int rdoff,
     const uint2* __restrict__ btab, u32 wait_n, const u8* __restrict__ q_scls, const u32* __restrict__ qoff, const u8* __restrict__ r_ug, const u32* __restrict__ roff,
     const signed char* __restrict__ b62g, u32* __restrict__ work_ctr, u32* __restrict__ shard_cnt, u64* __restrict__ p_qs, u64* __restrict__ p_sd,
-    u64* __restrict__ p_ft, unsigned long long* __restrict__ group_count, u64* __restrict__ mlist, u32* __restrict__ mlist_cnt) {
+    u64* __restrict__ p_ft, unsigned long long* __restrict__ group_count, u64* __restrict__ mlist, u32* __restrict__ mlist_cnt,
+    unsigned long long* __restrict__ stat /*COUNT: [0] += b62 lookups, [1] += groups*/) {
     constexpr u32 TBYTES = (u32)U1_ROWS << (8 + TSH);
     constexpr int QSLOT = QCAP + 2 * U1_QPAD;
     __shared__ __align__(16) unsigned char u1_smem[TBYTES + U1_WAVES * U1_WAVE_BYTES(QCAP, TSH)];
@@ -226,6 +255,9 @@ __global__ __launch_bounds__(64 * U1_WAVES, WGS) __attribute__((amdgpu_num_sgpr(
     u32 ch_pos = 0, ch_end = 0;   // the wave's reserved piece of the pass list: next free slot, end
     u32 lc_pos = 0, lc_end = 0;   // ... and of the chain list
     U1Track tr_unused;
+    U1Count ct;
+    ct.n = 0;
+    ct.start();
 
     for (;;) {
         // ---- next bucket (range-major: the chip works on one subject range at a time) ----
@@ -335,6 +367,7 @@ __global__ __launch_bounds__(64 * U1_WAVES, WGS) __attribute__((amdgpu_num_sgpr(
                         qR = U1_QPAD + qpos, qL = qR - 16;
                         sR = (i64)sa, sL = (i64)sa - 16;
                         S = pk16{0, 0}, M = pk16{0, 0};
+                        if (COUNT) ct.start();
                         working = true;
                     }
                 }
@@ -351,7 +384,7 @@ __global__ __launch_bounds__(64 * U1_WAVES, WGS) __attribute__((amdgpu_num_sgpr(
             if (working) {
                 const uint4 qr4 = u1_lds16(qslot, qR), ql4 = u1_lds16(qslot, qL);
                 const uint4 sr4 = u1_load16(r_ug + sR), sl4 = u1_load16(r_ug + sL);
-                const u32 msk = u1_step<TSH, false>(qr4, ql4, sr4, sl4, lanebase, S, M, tr_unused, 0);
+                const u32 msk = u1_step<TSH, false, COUNT>(qr4, ql4, sr4, sl4, lanebase, S, M, tr_unused, 0, ct);
                 qR = min(qR + 16, qr_max), qL = max(qL - 16, 0);
                 sR += 16, sL -= 16;
                 fin = msk == 0xFFFFFFFFu;   // both passes have ended
@@ -387,6 +420,12 @@ __global__ __launch_bounds__(64 * U1_WAVES, WGS) __attribute__((amdgpu_num_sgpr(
     if (mlist)
         for (u32 i = lc_pos + (u32)lane; i < lc_end; i += 64) mlist[i] = UG_REC_NONE;
     if (lane == 0 && ngroups) atomicAdd(&group_count[0], (unsigned long long)ngroups);
+    if (COUNT) {
+        unsigned long long nst = ct.n;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nst += __shfl_xor(nst, o);
+        if (lane == 0) atomicAdd(&stat[0], nst), atomicAdd(&stat[1], (unsigned long long)ngroups);
+    }
 }
 
 // ================================================================================================================
@@ -404,13 +443,14 @@ __global__ __launch_bounds__(64 * U1_WAVES, WGS) __attribute__((amdgpu_num_sgpr(
 struct U2Entry {   // 32 bytes
     u32 sa, w, pos, b, qb, e1, pad0, pad1;
 };
-template <bool BANDS, int TSH>
+template <bool BANDS, int TSH, bool COUNT>
 __global__ __launch_bounds__(64 * U1_WAVES, 1) void k_ungap2(const u64* __restrict__ mlist, const u32* __restrict__ mlist_cnt, const u32* __restrict__ words,
                                                             const u32* __restrict__ bext, BktLayout L, int sh_qpos, int diag_off, int rbs, int rsh_subj, int rsh_diag,
                                                             int rdoff, const uint2* __restrict__ btab, u32 wait_n, const u8* __restrict__ q_ug, const u32* __restrict__ qoff,
                                                             const u8* __restrict__ r_ug, const u32* __restrict__ roff, const signed char* __restrict__ b62g,
                                                             u32* __restrict__ work_ctr, u32* __restrict__ shard_cnt, u64* __restrict__ p_qs, u64* __restrict__ p_sd,
-                                                            u64* __restrict__ p_ft, unsigned long long* __restrict__ group_count) {
+                                                            u64* __restrict__ p_ft, unsigned long long* __restrict__ group_count,
+                                                            unsigned long long* __restrict__ stat /*COUNT: [0] += b62 lookups, [2] += groups*/) {
     constexpr u32 TBYTES = (u32)U1_ROWS << (8 + TSH);
     constexpr u32 WBYTES = U2_RING * 32 + U1_PCAP * 16;
     __shared__ __align__(16) unsigned char u2_smem[TBYTES + 17 * 16 + U1_WAVES * WBYTES];
@@ -459,12 +499,16 @@ __global__ __launch_bounds__(64 * U1_WAVES, 1) void k_ungap2(const u64* __restri
     pk16 S = {0, 0}, M = {0, 0};
     U1Track tr;
     tr.Mprev = pk16{0, 0}, tr.sv1 = tr.sv2 = tr.sv3 = pk16{0, 0}, tr.gsel = 0;
+    U1Count ct;
+    ct.n = 0;
+    ct.start();
     auto start_segment = [&](int qpos) {   // both passes of the seed at query position qpos, on the group's diagonal
         Qst = qpos;
         qR = qa0 + qpos, qL = qR - 16;
         sR = sa0 + (qpos - (int)(hw & pmask)), sL = sR - 16;
         S = pk16{0, 0}, M = pk16{0, 0};
         tr.Mprev = pk16{0, 0}, tr.gsel = 0, eb = 0;
+        if (COUNT) ct.start();
         working = true;
     };
     for (;;) {
@@ -543,7 +587,7 @@ __global__ __launch_bounds__(64 * U1_WAVES, 1) void k_ungap2(const u64* __restri
                 ql4.x = (ql4.x & ~mk.x) | (0x18181818u & mk.x), ql4.y = (ql4.y & ~mk.y) | (0x18181818u & mk.y);
                 ql4.z = (ql4.z & ~mk.z) | (0x18181818u & mk.z), ql4.w = (ql4.w & ~mk.w) | (0x18181818u & mk.w);
             }
-            const u32 msk = u1_step<TSH, true>(qr4, ql4, sr4, sl4, lanebase, S, M, tr, eb);
+            const u32 msk = u1_step<TSH, true, COUNT>(qr4, ql4, sr4, sl4, lanebase, S, M, tr, eb, ct);
             qR += 16, qL -= 16, sR += 16, sL -= 16, eb += 16;
             if (msk == 0xFFFFFFFFu) {   // both passes have ended
                 // the segment's maximum joins the chain's score; the next seed is bounded by max_qed: the first position of the right
@@ -607,39 +651,51 @@ __global__ __launch_bounds__(64 * U1_WAVES, 1) void k_ungap2(const u64* __restri
     if (npb) flush();
     for (u32 i = ch_pos + (u32)lane; i < ch_end; i += 64) p_qs[i] = UG_REC_NONE;
     if (lane == 0 && ngroups) atomicAdd(&group_count[0], (unsigned long long)ngroups);
+    if (COUNT) {
+        unsigned long long nst = ct.n;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nst += __shfl_xor(nst, o);
+        if (lane == 0) atomicAdd(&stat[0], nst), atomicAdd(&stat[2], (unsigned long long)ngroups);
+    }
 }
 
 u32 ungap1_qcap() { return U1_QCAP; }
 size_t ungap1_list_slack(u32 ncu) { return (size_t)ncu * 3 * U1_WAVES * U1_CHUNK; }
 size_t ungap1_mlist_cap(u32 H, u32 ncu) { return (size_t)H / 2 + (size_t)ncu * 2 * U1_WAVES * U1_LCHUNK + (size_t)H / 16 + 64; }   // (+ the entries pieces leave unused: < 64 per 1024)
 
-template <bool BANDS, int TSH, int QCAP, int WGS>
+template <bool BANDS, int TSH, int QCAP, int WGS, bool COUNT>
 static void ungap1_launch(u32 ncu, const u32* words, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, const KeyLayout& klr, const void* btab,
                           u32 wait_n, const u8* q_scls, const u32* qoff, const u8* r_ug, const u32* roff, const signed char* b62g, u32* work_ctr, u32* shard_cnt,
-                          u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, u64* mlist, u32* mlist_cnt, hipStream_t st) {
+                          u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, u64* mlist, u32* mlist_cnt, unsigned long long* stat, hipStream_t st) {
     static bool said = false;
     if (!said && getenv("SOHIT_DEBUG")) {
         int nblk = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_ungap1<BANDS, TSH, QCAP, WGS>, 64 * U1_WAVES, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_ungap1<BANDS, TSH, QCAP, WGS, COUNT>, 64 * U1_WAVES, 0);
         hipFuncAttributes fa;
-        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_ungap1<BANDS, TSH, QCAP, WGS>));
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_ungap1<BANDS, TSH, QCAP, WGS, COUNT>));
         fprintf(stderr, "[sohit] k_ungap1<%d,%d,%d,%d>: occupancy query %d blocks per CU (err %d), static LDS %zu, regs %d\n", (int)BANDS, TSH, QCAP, WGS, nblk, (int)e,
                 fa.sharedSizeBytes, fa.numRegs);
         said = true;
     }
     static_assert(WGS * (((size_t)U1_ROWS << (8 + TSH)) + (size_t)U1_WAVES * U1_WAVE_BYTES(QCAP, TSH)) <= 160 * 1024, "LDS of a CU");
-    hipLaunchKernelGGL((k_ungap1<BANDS, TSH, QCAP, WGS>), dim3(ncu * WGS), dim3(64 * U1_WAVES), 0, st, words, bext, nb, L, kl.sh_qpos, (int)kl.diag_off, klr.bs,
+    hipLaunchKernelGGL((k_ungap1<BANDS, TSH, QCAP, WGS, COUNT>), dim3(ncu * WGS), dim3(64 * U1_WAVES), 0, st, words, bext, nb, L, kl.sh_qpos, (int)kl.diag_off, klr.bs,
                        klr.sh_subj, klr.sh_diag, (int)klr.diag_off, (const uint2*)btab, wait_n, q_scls, qoff, r_ug, roff, b62g, work_ctr, shard_cnt, p_qs, p_sd, p_ft,
-                       group_count, mlist, mlist_cnt);
+                       group_count, mlist, mlist_cnt, stat);
 }
 
 // variant: 0 = 32-bit table entries, one workgroup per CU (4 waves per SIMD); 1 = 16-bit entries, one workgroup; 2 = 16-bit entries and
 // 512-residue query slots, two workgroups per CU (8 waves per SIMD; only for passes whose queries fit)
 void launch_ungap1(u32 ncu, int variant, u32 pmaxq, const u32* words, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, const KeyLayout& klr,
                    const void* btab, u32 wait_n, const u8* q_scls, const u32* qoff, const u8* r_ug, const u32* roff, const signed char* b62g, u32* work_ctr, u32* shard_cnt,
-                   u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, u64* mlist, u32* mlist_cnt, hipStream_t st) {
+                   u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, u64* mlist, u32* mlist_cnt, unsigned long long* stat, hipStream_t st) {
     if (!nb) return;
-#define U1_GO(B, T, Q, W) ungap1_launch<B, T, Q, W>(ncu, words, bext, nb, L, kl, klr, btab, wait_n, q_scls, qoff, r_ug, roff, b62g, work_ctr, shard_cnt, p_qs, p_sd, p_ft, group_count, mlist, mlist_cnt, st)
+#define U1_GO(B, T, Q, W) ungap1_launch<B, T, Q, W, false>(ncu, words, bext, nb, L, kl, klr, btab, wait_n, q_scls, qoff, r_ug, roff, b62g, work_ctr, shard_cnt, p_qs, p_sd, p_ft, group_count, mlist, mlist_cnt, nullptr, st)
+#define U1_GOC(B) ungap1_launch<B, 3, U1_QCAP, 1, true>(ncu, words, bext, nb, L, kl, klr, btab, wait_n, q_scls, qoff, r_ug, roff, b62g, work_ctr, shard_cnt, p_qs, p_sd, p_ft, group_count, mlist, mlist_cnt, stat, st)
+    if (stat) {   // counting instance
+        if (btab) U1_GOC(true);
+        else U1_GOC(false);
+        return;
+    }
     if (variant == 2 && pmaxq <= 512) {
         if (btab) U1_GO(true, 3, 512, 2);
         else U1_GO(false, 3, 512, 2);
@@ -651,14 +707,18 @@ void launch_ungap1(u32 ncu, int variant, u32 pmaxq, const u32* words, const u32*
         else U1_GO(false, 3, U1_QCAP, 1);
     }
 #undef U1_GO
+#undef U1_GOC
 }
 
 void launch_ungap2(u32 ncu, const u64* mlist, const u32* mlist_cnt, const u32* words, const u32* bext, const BktLayout& L, const KeyLayout& kl, const KeyLayout& klr,
                    const void* btab, u32 wait_n, const u8* q_ug, const u32* qoff, const u8* r_ug, const u32* roff, const signed char* b62g, u32* work_ctr, u32* shard_cnt,
-                   u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, hipStream_t st) {
-#define U2_GO(B) hipLaunchKernelGGL((k_ungap2<B, 3>), dim3(ncu), dim3(64 * U1_WAVES), 0, st, mlist, mlist_cnt, words, bext, L, kl.sh_qpos, (int)kl.diag_off, klr.bs, klr.sh_subj, \
-                                    klr.sh_diag, (int)klr.diag_off, (const uint2*)btab, wait_n, q_ug, qoff, r_ug, roff, b62g, work_ctr, shard_cnt, p_qs, p_sd, p_ft, group_count)
-    if (btab) U2_GO(true);
-    else U2_GO(false);
+                   u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, unsigned long long* stat, hipStream_t st) {
+#define U2_GO(B, CT) hipLaunchKernelGGL((k_ungap2<B, 3, CT>), dim3(ncu), dim3(64 * U1_WAVES), 0, st, mlist, mlist_cnt, words, bext, L, kl.sh_qpos, (int)kl.diag_off, klr.bs, klr.sh_subj, \
+                                    klr.sh_diag, (int)klr.diag_off, (const uint2*)btab, wait_n, q_ug, qoff, r_ug, roff, b62g, work_ctr, shard_cnt, p_qs, p_sd, p_ft, group_count, stat)
+    if (stat) {
+        if (btab) U2_GO(true, true);
+        else U2_GO(false, true);
+    } else if (btab) U2_GO(true, false);
+    else U2_GO(false, false);
 #undef U2_GO
 }

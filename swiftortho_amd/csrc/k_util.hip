@@ -7,6 +7,14 @@
 #define SCAN_ITERS 8
 #define SCAN_TILE (SCAN_THREADS * 4 * SCAN_ITERS)  // items per block
 
+// four values at a pointer that is only 4-byte aligned (seed_pass scans sub-ranges that start at any slot): still one dwordx4 access
+__device__ __forceinline__ uint4 ld4(const u32* p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ void st4(u32* p, const uint4& v) { __builtin_memcpy(p, &v, 16); }
+
 __device__ __forceinline__ u32 wave_incl_scan_u32(u32 v, int lane) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -42,7 +50,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const u32* __restr
     for (int it = 0; it < SCAN_ITERS; ++it) {
         size_t i = base + (size_t)it * SCAN_THREADS * 4 + (size_t)threadIdx.x * 4;
         if (i + 3 < n) {
-            uint4 v = *reinterpret_cast<const uint4*>(in + i);
+            uint4 v = ld4(in + i);
             s += v.x + v.y + v.z + v.w;
         } else {
             for (int k = 0; k < 4; ++k)
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* __restri
         size_t i = base + (size_t)it * SCAN_THREADS * 4 + (size_t)threadIdx.x * 4;
         u32 a = 0, b = 0, c = 0, d = 0;
         if (i + 3 < n) {
-            uint4 v = *reinterpret_cast<const uint4*>(in + i);
+            uint4 v = ld4(in + i);
             a = v.x, b = v.y, c = v.z, d = v.w;
         } else {
             if (i < n) a = in[i];
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* __restri
         if (inclusive) o0 = ex + a, o1 = o0 + b, o2 = o1 + c, o3 = o2 + d;
         else o0 = ex, o1 = ex + a, o2 = o1 + b, o3 = o2 + c;
         if (i + 3 < n) {
-            *reinterpret_cast<uint4*>(out + i) = make_uint4(o0, o1, o2, o3);
+            st4(out + i, make_uint4(o0, o1, o2, o3));
         } else {
             if (i < n) out[i] = o0;
             if (i + 1 < n) out[i + 1] = o1;
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_scan_small(const u32* __restrict
         if (i + SS_ITEMS <= n) {
 #pragma unroll
             for (int k = 0; k < SS_ITEMS; k += 4) {
-                const uint4 x = *reinterpret_cast<const uint4*>(in + i + k);
+                const uint4 x = ld4(in + i + k);
                 v[k] = x.x, v[k + 1] = x.y, v[k + 2] = x.z, v[k + 3] = x.w;
             }
         } else {
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_scan_small(const u32* __restrict
         }
         if (i + SS_ITEMS <= n) {
 #pragma unroll
-            for (int k = 0; k < SS_ITEMS; k += 4) *reinterpret_cast<uint4*>(out + i + k) = make_uint4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+            for (int k = 0; k < SS_ITEMS; k += 4) st4(out + i + k, make_uint4(v[k], v[k + 1], v[k + 2], v[k + 3]));
         } else {
 #pragma unroll
             for (int k = 0; k < SS_ITEMS; ++k)
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_scan_small(const u32* __restrict
 
 size_t scan_u32_temp_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 2; }
 
-// out[i] = sum(in[0..i)) (exclusive) or sum(in[0..i]) (inclusive); in may alias out (16-byte aligned).
+// out[i] = sum(in[0..i)) (exclusive) or sum(in[0..i]) (inclusive); in may alias out; 4-byte alignment suffices.
 // temp needs scan_u32_temp_elems(n) u32; temp[nblocks] receives the grand total (device side).
 const u32* scan_u32(const u32* in, u32* out, size_t n, bool inclusive, u32* temp, hipStream_t st) {
     size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;

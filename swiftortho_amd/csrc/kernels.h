@@ -88,7 +88,8 @@ void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& 
                   u64* p_ft, unsigned long long* group_count, hipStream_t st,
                   // bucketed passes: instead of `keys`, the buckets' sorted 32-bit words (launch_bkt_group with words32), their extents and layout
                   const u32* words = nullptr, const u32* bext = nullptr, u32 nb = 0, const BktLayout* L = nullptr,
-                  bool skip_single = false /*bucketed passes: the singleton groups were k_ungap1's*/);
+                  bool skip_single = false /*bucketed passes: the singleton groups were k_ungap1's*/,
+                  unsigned long long* stat = nullptr /*non-null: stat[0] += b62 lookups (the reference's `flag`, fsearch.py:2467, 2482)*/);
 
 // k_ungap1.hip: the singleton groups of a bucketed pass (queries up to U1_QCAP residues); pass records are appended like k_ungap's
 #define UG_REC_NONE 0xFFFFFFFFFFFFFFFFull   // p_qs of an unused pass-list slot (k_ungap1 reserves the list in pieces)
@@ -104,10 +105,12 @@ size_t ungap1_mlist_cap(u32 H, u32 ncu);   // entries of the chain list of a pas
 // groups are launch_ungap's (skip_single)
 void launch_ungap1(u32 ncu, int variant, u32 pmaxq, const u32* words, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, const KeyLayout& klr,
                    const void* btab, u32 wait_n, const u8* q_scls, const u32* qoff, const u8* r_ug, const u32* roff, const signed char* b62g, u32* work_ctr /*zeroed*/,
-                   u32* shard_cnt, u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, u64* mlist, u32* mlist_cnt, hipStream_t st);
+                   u32* shard_cnt, u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, u64* mlist, u32* mlist_cnt,
+                   unsigned long long* stat /*nullable: [0] += b62 lookups, [1] += singleton groups*/, hipStream_t st);
 void launch_ungap2(u32 ncu, const u64* mlist, const u32* mlist_cnt, const u32* words, const u32* bext, const BktLayout& L, const KeyLayout& kl, const KeyLayout& klr,
                    const void* btab, u32 wait_n, const u8* q_ug, const u32* qoff, const u8* r_ug, const u32* roff, const signed char* b62g, u32* work_ctr /*zeroed*/,
-                   u32* shard_cnt, u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, hipStream_t st);
+                   u32* shard_cnt, u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, unsigned long long* stat /*nullable: [0], [2] += chained groups*/,
+                   hipStream_t st);
 void launch_first_touch(bool walk, const u64* keys, u32 H, const KeyLayout& kl, int ft_bits_entry, int bsp, const u32* roff, u64* p_ft, u32 n,
                         hipStream_t st);
 void launch_shard_scan(const u32* shard_cnt, u32* shard_off, hipStream_t st);

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_mcl_colkeys(const u32* __restrict__ idx
     if (p < nnz) keys[p] = idx[p], pos[p] = p;
 }
 // y[c] = entries of column c summed in storage order (float32, sequential), flags: [0] some column sums to 0, [1] some sum > 0,
-// [2] some sum < 0, [3] the smallest column index whose sum is not 0 (atomicMin; preset to ~0)
+// [2] some sum < 0 or NaN (then y.min() != 0), [3] the smallest column index whose sum is not 0 (atomicMin; preset to ~0)
 __global__ __launch_bounds__(256) void k_mcl_colsum(const u64* __restrict__ ckeys /*sorted columns*/, const u32* __restrict__ cpos, u32 nnz,
                                                     const float* __restrict__ val, u32 n, float* __restrict__ y, u32* __restrict__ flags) {
     const u32 c = blockIdx.x * 256u + threadIdx.x;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_mcl_colsum(const u64* __restrict__ ckey
     y[c] = s;
     if (s == 0.f) atomicOr(&flags[0], 1u);
     if (s > 0.f) atomicOr(&flags[1], 1u);
-    if (s < 0.f) atomicOr(&flags[2], 1u);
+    if (s < 0.f || s != s) atomicOr(&flags[2], 1u);   // (a NaN sum makes numpy's y.min() NaN: `y.min() == 0` is false, the addend 1e-8)
     if (s != 0.f) atomicMin(&flags[3], c);   // (NaN != 0 too, as numpy's nonzero() sees it)
 }
 // normalize() (find_cluster.py:636-646): `y = np.asarray(cs)[0]` is the 1-D vector of column sums;

@@ -479,12 +479,16 @@ def main(argv=None):
             device_mcl(np.array([0, 1]), np.array([0]), np.array([1.], dtype=np.float32), ifl, rounds=1)
         except Exception:
             pass
-    threading.Thread(target=warm, daemon=True).start()
-    with open(qry, 'r') as f:
-        groups = cnc(f, ifl)
-    w = sys.stdout.write
-    for grp in groups:
-        w('\t'.join(grp) + '\n')
+    wt = threading.Thread(target=warm, daemon=True)
+    wt.start()
+    try:
+        with open(qry, 'r') as f:
+            groups = cnc(f, ifl)
+        w = sys.stdout.write
+        for grp in groups:
+            w('\t'.join(grp) + '\n')
+    finally:
+        wt.join(30.0)   # never leave the interpreter while the thread is inside HIP initialisation (an edge-less input ends before it)
     return 0
 
 

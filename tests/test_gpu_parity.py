@@ -133,11 +133,37 @@ def oracle_vs_gpu(fs, oracle, fasta, kw, tmp_path, sub=None):
         assert np.array_equal(g["identity"], r.dbl[:, 0]) and np.array_equal(g["evalue"], r.dbl[:, 1])
     c = s.counters()
     assert c["seed_hits"] == r.stats["seed_hits"]
+    if os.environ.get("SOHIT_UG_COUNT") == "1":
+        # the extension kernels' counting instances: b62 lookups == the reference's `flag` sum (fsearch.py:2467, 2482) -- the EXTENTS of every
+        # ungapped pass are the reference's, not only the scores that reach a candidate
+        assert c["ungap_steps"] == r.stats["ungap_steps"], (c["ungap_steps"], r.stats["ungap_steps"])
     # the oracle also counts the never-scoring "subject -1" groups (offset 0 of a chunk's first sequence)
     assert 0 <= r.stats["groups"] - c["groups"] <= 64 * c["n_chunks"] * max(1, r.nqueries // 50)
     hits.close()
     s.close()
     return c, r.stats
+
+
+@pytest.mark.parametrize("env", [{}, {"SOHIT_BUCKET_MIN": "0"}, {"SOHIT_BUCKET_MIN": "0", "SOHIT_UG1": "0"}, {"SOHIT_BUCKET_MIN": "0", "SOHIT_UG1_CHAIN": "0"},
+                                 {"SOHIT_BUCKET_MIN": "0", "SOHIT_UG_W32": "0"}],
+                         ids=["default", "bucketed_ungap1_ungap2", "bucketed_classic", "bucketed_ungap1_classic_chains", "bucketed_keys"])
+def test_ungap_steps_equal_the_reference_count(fs, oracle, tmp_path, monkeypatch, env):
+    """so_counters.ungap_steps (SOHIT_UG_COUNT=1: counting instances of k_ungap / k_ungap1 / k_ungap2) == the oracle's sum of Fasta.ungap's
+    `flag` over all groups, on homologous families (chains), a uniform set (singletons) and mixed lengths (banded diagonals), whichever
+    kernels the pass takes; the counters say which ones ran."""
+    from swiftortho_amd import synthprot
+    monkeypatch.setenv("SOHIT_UG_COUNT", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=120000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    for fa in (synthprot.synthprot(1500, 300, 91), synthprot.uniform_proteins(900, 250, 92), synthprot.synthprot(700, seed=93, lengths="lognormal")):
+        c, st = oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+        assert c["ungap_steps"] > 10 * c["groups"]
+        if env.get("SOHIT_BUCKET_MIN") == "0" and "SOHIT_UG1" not in env and "SOHIT_UG_W32" not in env:
+            assert c["groups_single"] > 0.5 * c["groups"]
+            assert (c["groups_chain"] > 0) == ("SOHIT_UG1_CHAIN" not in env)
+        else:
+            assert c["groups_single"] == 0 and c["groups_chain"] == 0
 
 
 def test_synth_2000_vs_oracle(fs, oracle, tmp_path):
