@@ -103,6 +103,9 @@ so_ctx *so_create(int device, const so_params *params);
 void so_destroy(so_ctx *ctx);
 const char *so_last_error(const so_ctx *ctx); /* ctx may be NULL: last so_create() error */
 int so_abi_version(void);
+/* One tuning / diagnostic switch (the SOHIT_* names of swiftortho_amd/csrc/tune.h, with or without the prefix; none changes results) for
+ * this context from now on.  so_create reads the same names from the environment once. */
+int so_set_option(so_ctx *ctx, const char *name, const char *value);
 
 /* Reference side.  Replaces: Fasta(open(ref)) + DB.makedb()/build_msav() per chunk
  * (fsearch.py:2975-2979, 2990, 2208-2295).  r_lo/r_hi are -L/-U (-1 = all).

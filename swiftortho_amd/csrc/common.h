@@ -8,6 +8,8 @@
 #include <string>
 #include <vector>
 
+#include "tune.h"
+
 typedef int64_t i64;
 typedef uint64_t u64;
 typedef uint32_t u32;
@@ -34,6 +36,8 @@ struct DevOom : SoError {
                           std::to_string(__LINE__) + " in " #expr);                                       \
     } while (0)
 
+extern int g_poison;   // Tune::poison of the last so_create (-1: none)
+
 // Grow-only device buffer.
 template <class T>
 struct DevBuf {
@@ -52,8 +56,7 @@ struct DevBuf {
             HIP_CHECK(e);
         }
         // SOHIT_POISON=<byte>: fill every fresh allocation (tests: results must not depend on what device memory held before)
-        static const char* poison = getenv("SOHIT_POISON");
-        if (poison) HIP_CHECK(hipMemset(np_, (int)strtol(poison, nullptr, 0) & 0xFF, nc * sizeof(T)));
+        if (g_poison >= 0) HIP_CHECK(hipMemset(np_, g_poison & 0xFF, nc * sizeof(T)));
         if (keep && p && cap) {
             HIP_CHECK(hipMemcpyAsync(np_, p, cap * sizeof(T), hipMemcpyDeviceToDevice, st));
             HIP_CHECK(hipStreamSynchronize(st));

@@ -239,28 +239,6 @@ struct ChunkIndex {
 
 }  // namespace
 
-// Tuning / diagnostic switches, read from the environment ONCE at so_create (none changes results): tools/diag/README.md
-struct Tune {
-    bool ug1 = true;        // SOHIT_UG1=0: singleton groups stay with k_ungap
-    bool count_steps = false;   // SOHIT_UG_COUNT=1: the extension kernels count their b62 lookups (so_counters.ungap_steps; slower instances)
-    bool ug1_chain = true;      // SOHIT_UG1_CHAIN=0: the groups of two and more hits stay with k_ungap
-    bool ug1_overlap = false;   // SOHIT_UG1_OVERLAP=1: k_ungap (chains) on a second stream beside k_ungap1
-    int ug1_variant = 2;    // SOHIT_UG1_VARIANT: 0 = 32-bit score-table entries, 1 = 16-bit, 2 = 16-bit and two workgroups per CU where the queries fit
-    u32 ug1_wait = 4;       // SOHIT_UG1_WAIT: idle lanes that trigger a hand-out
-    static int geti(const char* k, int dflt) {
-        const char* e = getenv(k);
-        return e ? atoi(e) : dflt;
-    }
-    void read() {
-        ug1 = geti("SOHIT_UG1", 1) != 0;
-        ug1_variant = geti("SOHIT_UG1_VARIANT", 2);
-        ug1_overlap = geti("SOHIT_UG1_OVERLAP", 0) != 0;
-        ug1_chain = geti("SOHIT_UG1_CHAIN", 1) != 0;
-        count_steps = geti("SOHIT_UG_COUNT", 0) != 0;
-        ug1_wait = (u32)std::max(1, geti("SOHIT_UG1_WAIT", 4));
-    }
-};
-
 struct so_ctx {
     int device = 0;
     u32 ncu = 256;          // compute units of the device
@@ -348,6 +326,18 @@ struct so_ctx {
     size_t d_hits_n = 0;
     DevBuf<double> d_p2tab;
 };
+
+// the switches the launch helpers see: those of the context whose API call ran last (one context per process in every use of the
+// library; tests create theirs one after the other)
+static std::atomic<const Tune*> g_tune{nullptr};
+const Tune& tune() {
+    static const Tune dflt;
+    const Tune* t = g_tune.load(std::memory_order_acquire);
+    return t ? *t : dflt;
+}
+void set_tune(const Tune* t) { g_tune.store(t, std::memory_order_release); }
+int g_poison = -1;
+static inline u64 cand_limit() { return tune().cand_limit > 0 ? (u64)tune().cand_limit : 0xFFFFFFF0ull; }
 
 namespace {
 
@@ -606,7 +596,7 @@ i64 chunk_threshold(so_ctx* c, const u32* d_counts /*sizes of the occupied bucke
     long double T = lm + 2.0L * sqrtl(ss / (long double)N);
     long double fl = floorl(T);
     long double margin = ((long double)nn * 8e-16L + 1e-11L) * (T + 1.0L);
-    const bool forced = getenv("SOHIT_EXACT_THRESHOLD") != nullptr;
+    const bool forced = tune().exact_threshold;
     if (!forced && T - fl > margin && (fl + 1.0L) - T > margin) return (i64)fl;
     // exact replay
     std::vector<u32> counts((size_t)nn);  // the reference walks all NC counts and skips the zeros: same sequence
@@ -665,7 +655,7 @@ void build_index(so_ctx* c) {
     i64 End = c->r_hi == -1 ? N : c->r_hi;
     const u32 NC = (u32)c->nc;
     c->cnt.index_entries = 0;
-    const bool dbg = getenv("SOHIT_DEBUG_INDEX") != nullptr;   // wall laps of the build's steps (stderr)
+    const bool dbg = tune().debug_index;   // wall laps of the build's steps (stderr)
     double tl = wall();
     auto dlap = [&](const char* what) {
         if (!dbg) return;
@@ -693,8 +683,8 @@ void build_index(so_ctx* c) {
         ch->maxslen = 0;
         for (i64 j = ch->seq_lo; j < ch->seq_hi; ++j) ch->maxslen = std::max(ch->maxslen, c->ref.len(j));
         {
-            const char* e = getenv("SOHIT_DIR_MAX");  // largest -M served by the bitmap + rank directory (NC / 4 bytes per chunk)
-            ch->use_dir = (u64)NC <= (e ? (u64)atoll(e) : (1ull << 28));
+            // SOHIT_DIR_MAX: largest -M served by the bitmap + rank directory (NC / 4 bytes per chunk)
+            ch->use_dir = (u64)NC <= (tune().dir_max >= 0 ? (u64)tune().dir_max : (1ull << 28));
         }
         // 1. windows per position -> exclusive scan -> (bucket, entry) pairs in position order
         const u32 npos = ch->p_hi - ch->p_lo;
@@ -855,7 +845,7 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
     b.maxqlen = 0;
     b.qid.resize(b.nq), b.qcls.resize(b.nq);
     {
-        const bool classes_on = !(getenv("SOHIT_QCLASS") && atoi(getenv("SOHIT_QCLASS")) == 0);   // SOHIT_QCLASS=0: file order
+        const bool classes_on = tune().qclass;   // SOHIT_QCLASS=0: file order
         u32 cnt[QCLASSES] = {0}, at[QCLASSES] = {0};
         for (u32 i = 0; i < b.nq; ++i) cnt[classes_on ? query_class(Q.len(q_lo + i)) : 0]++;
         for (int k = 1; k < QCLASSES; ++k) at[k] = at[k - 1] + cnt[k - 1];
@@ -921,7 +911,7 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
         if (q_long < b.nq) b.gx.ensure(nres + 4), b.gL.ensure(nres + 4), b.gR.ensure(nres + 4);
         // in a class-ordered batch the long ones are the tail of the last class: their order is computed on the side stream
         // (SOHIT_KSC_ASYNC=0: on the batch's stream)
-        static const bool async_on = !(getenv("SOHIT_KSC_ASYNC") && atoi(getenv("SOHIT_KSC_ASYNC")) == 0);
+        const bool async_on = tune().ksc_async;
         bool ordered = true;
         for (u32 i = 1; i < b.nq && ordered; ++i) ordered = b.qcls[i] >= b.qcls[i - 1];
         b.korder_async = async_on && q_long < b.nq && ordered && b.qcls[q_long] != b.qcls[0];
@@ -1157,10 +1147,10 @@ void chunk_qhits_deferred(so_ctx* c, Batch& b, int ci) {
 // hits per (query, widest subject range) than the sparse limit.
 bool class_takes_sorted_path(so_ctx* c, ChunkIndex& ch, u32 maxq, unsigned long long hits, unsigned long long nq) {
     const int AS = c->cfg.A * c->cfg.S;
-    if ((getenv("SOHIT_BUCKET") && atoi(getenv("SOHIT_BUCKET")) == 0) || AS != 1 || UG_SHARDS != 1 || !nq) return true;
-    if (getenv("SOHIT_LK_WIDE") && atoi(getenv("SOHIT_LK_WIDE")) != 0) return true;
+    if (!tune().bucket || AS != 1 || UG_SHARDS != 1 || !nq) return true;
+    if (tune().lk_wide) return true;
     const int bp = ceil_log2(std::max<u32>(maxq, 2));
-    const bool bands_ok = !(getenv("SOHIT_BANDS") && atoi(getenv("SOHIT_BANDS")) == 0);
+    const bool bands_ok = tune().bands;
     int k;
     u64 nband;
     band_plan(c, ch, bp, bands_ok, &k, &nband);   // (the layout only: no encoding is built for the question)
@@ -1170,7 +1160,7 @@ bool class_takes_sorted_path(so_ctx* c, ChunkIndex& ch, u32 maxq, unsigned long 
     int wb_lo = 0;
     while ((nband + (1ull << wb_lo) - 1) >> wb_lo > BKT_RMAX) ++wb_lo;
     if (wb_hi < wb_lo) return true;
-    const unsigned long long sparse = getenv("SOHIT_BUCKET_MIN") ? (unsigned long long)std::max(0, atoi(getenv("SOHIT_BUCKET_MIN"))) : 192ull;
+    const unsigned long long sparse = (unsigned long long)std::max(0ll, tune().bucket_min);
     return hits / (nq * ((nband + (1ull << wb_hi) - 1) >> wb_hi)) < sparse;
 }
 
@@ -1191,7 +1181,7 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     // The class still waiting for its k-mer orders (korder_async) is never merged into an earlier pass.
     int grp[QCLASSES];
     {
-        const bool merge_on = !(getenv("SOHIT_PASS_MERGE") && atoi(getenv("SOHIT_PASS_MERGE")) == 0);
+        const bool merge_on = tune().pass_merge;
         unsigned long long hits[QCLASSES] = {0}, cnt[QCLASSES] = {0};
         u32 maxq[QCLASSES] = {0};
         const u32 known = b.korder_async ? b.q_defer : b.nq;   // (the deferred class's counts arrive later)
@@ -1218,7 +1208,7 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
         while (qb < b.nq && (qb == qa || (acc + qh[qb] <= budget && grp[b.qcls[qb]] == grp[b.qcls[qa]]))) acc += qh[qb++];
         if (acc >= 0xFFFFFFF0ull) throw SoError("a single query visits >= 2^32 index entries in one chunk: lower -c");
         if (acc) seed_pass(c, b, ci, qa, qb, wall(), sc), ++c->cnt.seed_passes;
-        if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] chunk %d pass queries [%u, %u) classes %d..%d hits %llu\n", ci, qa, qb, (int)b.qcls[qa], (int)b.qcls[qb - 1], acc);
+        if (tune().debug) fprintf(stderr, "[sohit] chunk %d pass queries [%u, %u) classes %d..%d hits %llu\n", ci, qa, qb, (int)b.qcls[qa], (int)b.qcls[qb - 1], acc);
         qa = qb;
     }
 }
@@ -1252,8 +1242,8 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     kl.bq = ceil_log2((u64)b.nq + 1);
     kl.bp = ceil_log2(std::max<u32>(pmaxq, 2));
     kl.ba = AS > 1 ? ceil_log2((u64)AS) : 0;
-    const bool force_wide = getenv("SOHIT_LK_WIDE") && atoi(getenv("SOHIT_LK_WIDE")) != 0;
-    const bool bands_ok = !(getenv("SOHIT_BANDS") && atoi(getenv("SOHIT_BANDS")) == 0);   // SOHIT_BANDS=0: one band per subject whatever its length
+    const bool force_wide = tune().lk_wide;
+    const bool bands_ok = tune().bands;   // SOHIT_BANDS=0: one band per subject whatever its length
     ChunkIndex::BandEnc* enc = force_wide ? nullptr : band_encoding(c, ch, kl.ba, kl.bp, AS == 1 && bands_ok);
     const bool compact = enc != nullptr;
     const u32 nunit = compact ? enc->nband : nseq_chunk;   // what the key's subject field counts
@@ -1278,7 +1268,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         btab = enc->btab.p;
     }
     // k_ungap's GALLOP variant from this query length on (SOHIT_UG_GALLOP: tuning switch)
-    static const u32 gallop_min = getenv("SOHIT_UG_GALLOP") ? (u32)atoi(getenv("SOHIT_UG_GALLOP")) : 1024u;
+    const u32 gallop_min = (u32)tune().ug_gallop;
     const int bsp = ceil_log2((u64)ch.maxslen + 1);
     const int ft_bits_entry = (klr.bs + 1) + klr.ba + bsp;
     const bool ft_walk = AS > 1;  // several (alphabet, pattern) combinations: a group's first-touch key needs all its hits
@@ -1318,7 +1308,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     // One alphabet x one pattern, compact index addends and wb + bd + bp <= 31 (wb counts diagonal bands: one per chunk sequence,
     // several for the few sequences too long for one); returns false when the pass has to take the sorted path below.
     auto group_bucketed = [&]() -> bool {
-        const bool enabled = !(getenv("SOHIT_BUCKET") && atoi(getenv("SOHIT_BUCKET")) == 0);
+        const bool enabled = tune().bucket;
         if (!enabled || AS != 1 || !compact || UG_SHARDS != 1) return false;
         const u32 nqp = qb - qa;
         const int wb_hi = std::min(std::min(31 - kl.bd - kl.bp, kl.bs), bkt_max_wb());   // hit word < 2^31; subjects per range <= the sort's bins
@@ -1326,11 +1316,11 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         while (((u64)nunit + (1ull << wb_lo) - 1) >> wb_lo > BKT_RMAX) ++wb_lo;
         if (wb_hi < wb_lo || kl.bp > 16) return false;
         // widest subject range whose average bucket is a few hits per thread of the workgroup that groups it
-        const u32 target = getenv("SOHIT_BUCKET_AVG") ? (u32)std::max(1, atoi(getenv("SOHIT_BUCKET_AVG"))) : 2560u;
+        const u32 target = (u32)std::max(1ll, tune().bucket_avg);
         int wb = wb_hi;
         // sparse passes (long seeds: a few hundred hits per query) would leave the grouping kernel walking mostly empty
         // buckets: the sorted path handles those well (its segments are short)
-        const u32 sparse = getenv("SOHIT_BUCKET_MIN") ? (u32)std::max(0, atoi(getenv("SOHIT_BUCKET_MIN"))) : 192u;
+        const u32 sparse = (u32)std::max(0ll, tune().bucket_min);
         if ((u64)H / ((u64)nqp * (((u64)nunit + (1ull << wb) - 1) >> wb)) < sparse) return false;
         while (wb > wb_lo && (u64)H / ((u64)nqp * (((u64)nunit + (1ull << wb) - 1) >> wb)) > target) --wb;
         BktLayout L;
@@ -1379,7 +1369,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         t1 = wall();
         sc.lap("seed.bucket_scatter");
         // the grouped hits leave as the buckets' own 32-bit words (k_ungap's W32 input) unless SOHIT_UG_W32=0 asks for the 64-bit keys
-        static const bool w32 = !(getenv("SOHIT_UG_W32") && atoi(getenv("SOHIT_UG_W32")) == 0);
+        const bool w32 = tune().ug_w32;
         if (w32) b.hits32s.ensure((size_t)H + 8);   // (k_ungap1's chains read four words ahead)
         else b.keys2.ensure((size_t)H + 2);
         b.bext.ensure((size_t)nb + 4);
@@ -1389,13 +1379,13 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         const u32 refused = d2h_u32(c, b.bflag.p);
         sc.lap("group.bucket_group");
         if (refused) {
-            if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] bucketed pass refused (flag %u): sorted path\n", refused);
+            if (tune().debug) fprintf(stderr, "[sohit] bucketed pass refused (flag %u): sorted path\n", refused);
             return false;
         }
-        if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] bucketed pass: wb %d ranges %u buckets %u tiles %u hits %u of %u\n", wb, L.R, nb, NT, Hv, H);
+        if (tune().debug) fprintf(stderr, "[sohit] bucketed pass: wb %d ranges %u buckets %u tiles %u hits %u of %u\n", wb, L.R, nb, NT, Hv, H);
         // best diagonal per subject bucket by bucket (k_bkt_best) when first-touch keys fit its 44-bit field; else the sorted path below
         // ... and a chained ungapped score fits the 20 bits k_bkt_best packs above them (at most 11 per residue of the shorter sequence)
-        bbest = !(getenv("SOHIT_BUCKET_BEST") && atoi(getenv("SOHIT_BUCKET_BEST")) == 0) && !ft_walk && (kl.ba + kl.bp + ft_bits_entry <= 44) &&
+        bbest = tune().bucket_best && !ft_walk && (kl.ba + kl.bp + ft_bits_entry <= 44) &&
                 (u64)std::min<u32>(pmaxq, ch.maxslen) * 11ull < (1ull << 20);
         // singleton groups (84 % of a dense pass's groups) go to k_ungap1, the chains of two and more seeds stay with k_ungap
         const bool ug1 = w32 && c->tune.ug1 && pmaxq <= ungap1_qcap() && bbest;   // (its pass list has unused slots: only the bucketed reduction skips them)
@@ -1422,11 +1412,11 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
             HIP_CHECK(hipStreamWaitEvent(c->st_ug, c->ev_ug_go, 0));
         }
         if (ug1)
-            launch_ungap1(c->ncu, c->tune.ug1_variant, pmaxq, b.hits32s.p, b.bext.p, nb, L, kl, klr, btab, c->tune.ug1_wait, b.dev.d_scls.p, b.dev.d_off.p,
+            launch_ungap1(c->ncu, (int)c->tune.ug1_variant, pmaxq, b.hits32s.p, b.bext.p, nb, L, kl, klr, btab, (u32)std::max(1ll, c->tune.ug1_wait), b.dev.d_scls.p, b.dev.d_off.p,
                           c->ref.d_ug_store.p + U1_UG_PAD, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.bflag.p + 1, b.shard.p, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p,
                           ug2 ? b.mlist.p : nullptr, b.bflag.p + 3, ugstat, c->st);
         if (ug2)
-            launch_ungap2(c->ncu, b.mlist.p, b.bflag.p + 3, b.hits32s.p, b.bext.p, L, kl, klr, btab, c->tune.ug1_wait, b.dev.d_ug_store.p + U1_UG_PAD, b.dev.d_off.p,
+            launch_ungap2(c->ncu, b.mlist.p, b.bflag.p + 3, b.hits32s.p, b.bext.p, L, kl, klr, btab, (u32)std::max(1ll, c->tune.ug1_wait), b.dev.d_ug_store.p + U1_UG_PAD, b.dev.d_off.p,
                           c->ref.d_ug_store.p + U1_UG_PAD, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.bflag.p + 2, b.shard.p, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p,
                           ugstat, c->st);
         else
@@ -1464,7 +1454,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     // fewer than a device-wide sort of the (query, subject, diagonal) bits.  One block sorts one segment, so
     // passes with few queries (huge per-query hit lists) use the device-wide sort instead.
     // (Dropped hits carry ~0 and sort last in their segment.)
-    const int seg_mode = getenv("SOHIT_SEGSORT") ? atoi(getenv("SOHIT_SEGSORT")) : 1;
+    const int seg_mode = (int)tune().segsort;
     const u32 nseg = qb - qa;
     if (seg_mode && nseg >= 256) {
         b.qseg.ensure((size_t)b.nq + 4);
@@ -1481,7 +1471,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
                  c->d_b62c.p, b.shard.p, shard_cap, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p, c->st, nullptr, nullptr, 0, nullptr, false, ugstat);
     };
 
-    const bool lk_ablation = getenv("SOHIT_LK_VARIANT") && (atoi(getenv("SOHIT_LK_VARIANT")) == 1 || atoi(getenv("SOHIT_LK_VARIANT")) == 2);
+    const bool lk_ablation = tune().lk_variant == 1 || tune().lk_variant == 2;
     reset_pass_lists();
     if (lk_ablation || !group_bucketed()) {
         bbest = false;
@@ -1530,7 +1520,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
             launch_bkt_best(false, b.q_qs.p, b.q_sd.p, b.q_ft.p, b.bcnt.p, bnb, bL, klr.bs, (u32)ch.seq_lo, b.bccnt.p, nullptr, nullptr, nullptr, bsp, 0,
                             c->st);
             NS = d2h_u32(c, scan_u32(b.bccnt.p, b.bccnt.p, (size_t)bnb + 1, false, c->d_scan_tmp.p, c->st));
-            if (getenv("SOHIT_DEBUG"))
+            if (tune().debug)
                 fprintf(stderr, "[sohit] seed pass: queries %u..%u hits %u seeds %u pass records %u candidates %u (bucketed best)\n", qa, qb, H, K, NP, NS);
             b.c_ft.ensure((size_t)NS + 2), b.c_q.ensure((size_t)NS + 2), b.c_rec.ensure(4 * (size_t)NS + 8);
             c_ftp = b.c_ft.p, c_qp = b.c_q.p, c_recp = b.c_rec.p;
@@ -1538,8 +1528,8 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
                 // candidate order as a keys-only segmented sort: the sort word = first-touch word << idx_bits | position inside the query's
                 // segment (written by k_bkt_best itself) when both fit 63 bits (bit 63 stays free: see sort_cand_keys_seg) -- no index
                 // array, no key-build pass, 8 instead of 12 bytes per candidate and radix pass (SOHIT_CAND_KEYS=0: the pairs sort)
-                static const bool cand_keys = !(getenv("SOHIT_CAND_KEYS") && atoi(getenv("SOHIT_CAND_KEYS")) == 0);
-                static const bool cand_seg0 = !(getenv("SOHIT_CAND_SEGSORT") && atoi(getenv("SOHIT_CAND_SEGSORT")) == 0);
+                const bool cand_keys = tune().cand_keys;
+                const bool cand_seg0 = tune().cand_segsort;
                 const int ftw = kl.ba + kl.bp + ft_bits_entry - bsp + 1;
                 if (cand_keys && cand_seg0 && bL.nqp >= 256 && ftw < 63 && 63 - ftw >= klr.bs + 1) cand_idx_bits = 63 - ftw, cand_ftw = ftw;
             }
@@ -1564,7 +1554,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         launch_qseg(b.p_qs2.p, NP, b.gidx.p, dS, klr.bs, qa, qb, b.qseg.p, c->d_small.p, c->st);
         d2h_pair(c, dS, maxseg, NS);
         b.shead.ensure((size_t)NS + 2);
-        if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] seed pass: queries %u..%u hits %u seeds %u pass records %u candidates %u\n", qa, qb, H, K, NP, NS);
+        if (tune().debug) fprintf(stderr, "[sohit] seed pass: queries %u..%u hits %u seeds %u pass records %u candidates %u\n", qa, qb, H, K, NP, NS);
         launch_group_list(b.flags.p, b.gidx.p, NP, b.shead.p, c->st);
         b.c_ft.ensure((size_t)NS + 2), b.c_q.ensure((size_t)NS + 2), b.c_rec.ensure(4 * (size_t)NS + 8);
         c_ftp = b.c_ft.p, c_qp = b.c_q.p, c_recp = b.c_rec.p;
@@ -1577,12 +1567,11 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         return;
     }
     const int ftbits = kl.ba + kl.bp + ft_bits_entry;
-    static const bool cand_lds = !(getenv("SOHIT_CAND_LDS") && atoi(getenv("SOHIT_CAND_LDS")) == 0);
+    const bool cand_lds = tune().cand_lds;
     if (!bbest && cand_lds && maxseg <= (u32)cand_order_lds_max() && ftbits - bsp + 1 <= cand_order_lds_key_bits()) {
         // sparse path: every query's candidates fit the LDS sort -- ordered and written to the candidate store by one kernel
         const u32 base = b.chunk_base.back();
-        const char* lim = getenv("SOHIT_CAND_LIMIT");  // (tests lower the limit to exercise the split)
-        if ((u64)base + NS >= (lim ? (u64)atoll(lim) : 0xFFFFFFF0ull)) throw CandOverflow();
+        if ((u64)base + NS >= cand_limit()) throw CandOverflow();   // (SOHIT_CAND_LIMIT: tests lower the limit to exercise the split)
         b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
         b.cand_rec.ensure(4 * ((size_t)base + NS) + 16, true, c->st);
         launch_cand_order_lds(c_ftp, c_recp, b.qseg.p, qa, qb, maxseg, bsp, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, c->st);
@@ -1595,8 +1584,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     }
     if (cand_idx_bits) {
         const u32 base = b.chunk_base.back();
-        const char* lim = getenv("SOHIT_CAND_LIMIT");  // (tests lower the limit to exercise the split)
-        if ((u64)base + NS >= (lim ? (u64)atoll(lim) : 0xFFFFFFF0ull)) throw CandOverflow();
+        if ((u64)base + NS >= cand_limit()) throw CandOverflow();   // (SOHIT_CAND_LIMIT: tests lower the limit to exercise the split)
         b.qseg.ensure((size_t)b.nq + 4), b.tmp64.ensure((size_t)NS + 2);
         launch_stride_gather(b.bccnt.p, bL.R, bL.nqp + 1, b.qseg.p, c->st);
         ensure_sort_tmp(c, sort_cand_keys_seg_temp_bytes(NS, bL.nqp, cand_idx_bits, cand_idx_bits + cand_ftw));
@@ -1618,7 +1606,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     int qshift = 0;  // where the query sits in the final sort's key stream (b.c_ft2)
     if (ftbits + kl.bq <= 64) {
         launch_combine_q_ft(c_qp, c_ftp, NS, ftbits, bsp, b.tmp64.p, c->st);
-        static const bool cand_seg = !(getenv("SOHIT_CAND_SEGSORT") && atoi(getenv("SOHIT_CAND_SEGSORT")) == 0);
+        const bool cand_seg = tune().cand_segsort;
         if (bbest && cand_seg && bL.nqp >= 256) {
             // k_bkt_best wrote the candidates query-major: a query's segment = [ccnt[q * R], ccnt[(q + 1) * R]); only the first-touch bits
             // are sorted, inside the segments (the query bits stay on top of the sort word for k_emit_cands)
@@ -1642,8 +1630,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     }
     // append to the candidate store
     const u32 base = b.chunk_base.back();
-    const char* lim = getenv("SOHIT_CAND_LIMIT");  // (tests lower the limit to exercise the split)
-    if ((u64)base + NS >= (lim ? (u64)atoll(lim) : 0xFFFFFFF0ull)) throw CandOverflow();  // search_loaded() splits the batch and runs the halves
+    if ((u64)base + NS >= cand_limit()) throw CandOverflow();  // search_loaded() splits the batch and runs the halves (SOHIT_CAND_LIMIT: tests)
     b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
     b.cand_rec.ensure(4 * ((size_t)base + NS) + 16, true, c->st);
     b.segfirst.ensure((size_t)b.nq + 4);
@@ -1663,8 +1650,7 @@ struct HitCache {
     so_hit* p = nullptr;
     size_t bytes = 0;
     static bool enabled() {
-        const char* e = getenv("SOHIT_HIT_CACHE");
-        return !(e && atoi(e) == 0);
+        return tune().hit_cache;
     }
     so_hit* take(size_t& cap_rows) {
         std::lock_guard<std::mutex> g(mu);
@@ -1781,7 +1767,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     }
     sc.lap("phase2.gather");
     // candidate dump for so_query_candidates (tests only)
-    if (getenv("SOHIT_KEEP_CANDS")) {
+    if (tune().keep_cands) {
         std::vector<u32> qcoff((size_t)nq + 1), rec(4 * (size_t)Ntot + 4);
         HIP_CHECK(hipMemcpyAsync(qcoff.data(), b.qcoff.p, ((size_t)nq + 1) * sizeof(u32), hipMemcpyDeviceToHost, c->st));
         if (Ntot) HIP_CHECK(hipMemcpyAsync(rec.data(), b.fin_rec.p, 4 * (size_t)Ntot * sizeof(u32), hipMemcpyDeviceToHost, c->st));
@@ -1837,13 +1823,13 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                    b.rk_slot.p, c->st);
     // k_align runs four alignments per wave and a wave lasts as long as its longest one: every launch list is ordered by band rows,
     // longest first (one 13-bit radix sort; config 3: align rounds 33.6 -> 28.4 ms, sort included).  SOHIT_ALIGN_SORT=0: as listed.
-    const bool align_sort = !(getenv("SOHIT_ALIGN_SORT") && atoi(getenv("SOHIT_ALIGN_SORT")) == 0);
+    const bool align_sort = tune().align_sort;
     // The packed 16-bit aligner takes a task whose scores fit its cells: 11 * min(rows, columns), or the smaller of the two sequences'
     // score bounds (k_seq_bound), within range.  That is a property of the TASK: a launch list is split into the tasks it cannot take
     // (k_task_rows clears bit 13 of their sort key, so they lead the sorted list, and counts them) and the rest.  Only batches that hold
     // a query AND a reference sequence above the length limit can contain such tasks at all.
     const u32 maxwin_q = std::min<u32>(b.maxqlen, LONG_SEQ), maxwin_s = std::min<u32>(c->ref.maxlen, LONG_SEQ);
-    const bool pk_on = !(getenv("SOHIT_ALIGN_PK") && atoi(getenv("SOHIT_ALIGN_PK")) == 0) && align_pk_supported(c->st);
+    const bool pk_on = tune().align_pk && align_pk_supported(c->st);
     const bool pk_mixed = pk_on && (int)std::min(maxwin_q, maxwin_s) > align_pk_max_len();
     auto sort_by_rows = [&](const u32* list, u32 n, u32* n_wide) -> const u32* {
         const bool split = n_wide && pk_mixed;
@@ -1892,11 +1878,10 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     // config 2, 0.55 M tasks, 16.7 -> 17.1 ms).  SOHIT_SPEC_SLACK: the guess tests the ungapped score against expect x this (default 1e3:
     // config 3 keeps 1.44 M traces, all of them of reported rows, 175 k rows are left for the second pass; 1: 1.30 M / 315 k; 1e6: 1.56 M /
     // 57 k with 1.3 k traces unused -- a wrong guess costs about as much as a right one saves).
-    const char* spec_env = getenv("SOHIT_SPEC");
-    const bool spec_on = spec_env ? atoi(spec_env) != 0 : NT >= (1u << 21);
-    const double spec_slack = getenv("SOHIT_SPEC_SLACK") ? atof(getenv("SOHIT_SPEC_SLACK")) : 1e3;
+    const bool spec_on = tune().spec >= 0 ? tune().spec != 0 : NT >= (1u << 21);
+    const double spec_slack = tune().spec_slack;
     u32 spec_cap = NT;   // (8 GiB of kept traces at most: checked on the list's actual trace sizes below)
-    if (getenv("SOHIT_SPEC_CAP")) spec_cap = (u32)std::max(0, atoi(getenv("SOHIT_SPEC_CAP")));   // (tests: the round that does not fit)
+    if (tune().spec_cap >= 0) spec_cap = (u32)tune().spec_cap;   // (tests: the round that does not fit)
     u32 nspec = 0;
     if (spec_on) {
         b.tpos.ensure((size_t)NT + 4);
@@ -1989,9 +1974,8 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     enum { EMIT_PARTS_MAX = 8 };
     // SOHIT_EMIT_PARTS (1-8, default 4) / SOHIT_EMIT_MIN_ROWS (default 2^18: smaller results leave in one piece): tuning and test switches
     // (with kept traces -- nspec -- the last stage is short: fewer ranges, SOHIT_SPEC_PARTS, default 2)
-    const int EMIT_PARTS = std::min<int>(EMIT_PARTS_MAX, std::max(1, nspec ? (getenv("SOHIT_SPEC_PARTS") ? atoi(getenv("SOHIT_SPEC_PARTS")) : 2)
-                                                                            : (getenv("SOHIT_EMIT_PARTS") ? atoi(getenv("SOHIT_EMIT_PARTS")) : 4)));
-    const u32 emit_min_rows = getenv("SOHIT_EMIT_MIN_ROWS") ? (u32)std::max(1, atoi(getenv("SOHIT_EMIT_MIN_ROWS"))) : (1u << 18);
+    const int EMIT_PARTS = std::min<int>(EMIT_PARTS_MAX, std::max(1, nspec ? (int)tune().spec_parts : (int)tune().emit_parts));
+    const u32 emit_min_rows = (u32)std::max(1ll, tune().emit_min_rows);
     // (config 3, one batch: 1 part 57.0 ms per step, 4 parts 56.0)
     const u32 qstep = (nq + EMIT_PARTS - 1) / EMIT_PARTS;
     c->d_small.ensure(16);
@@ -2049,7 +2033,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             HIP_CHECK(hipStreamSynchronize(c->st));
             pb[parts] = v[parts];
             for (int p = 1; p < parts; ++p) pb[p] = part_row[p] < NO ? v[p] : pb[parts];
-            if (getenv("SOHIT_DEBUG")) fprintf(stderr, "[sohit] kept traces %u, reported rows %u, of them without a trace %u\n", nspec, NO, pb[parts]);
+            if (tune().debug) fprintf(stderr, "[sohit] kept traces %u, reported rows %u, of them without a trace %u\n", nspec, NO, pb[parts]);
         }
         // the list aligned with traces now: the rows without a kept trace (nspec), or all rows; its traces take their own sizes
         // (b.tr_ofs) when the whole list fits the budget, else slabs of the batch-wide stride
@@ -2060,7 +2044,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         // wave and k_traceback sixty-four walks, and either lasts as long as its longest (on uniform lengths the sort costs more than
         // it saves -- config 3: 9.1 -> 9.9 ms -- hence the test).  The traces' offsets follow the ordered list.
         const bool order_rows = (b.permuted || (u64)b.maxqlen * b.nq > 3ull * b.h_off[b.nq] / 2) &&
-                                !(getenv("SOHIT_TRACE_SORT") && atoi(getenv("SOHIT_TRACE_SORT")) == 0);
+                                tune().trace_sort;
         if (order_rows) {
             auto order_list = [&](const u32* in, u32 t0, u32 t1, u32* out) {   // [t0, t1) of `in`, longest band first, to the same range of `out`
                 const u32 n = t1 - t0;
@@ -2128,7 +2112,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         {   // SOHIT_TEST_OOM_PHASE2=1 (tests): the first multi-query batch of the process fails here, as a device allocation of the
             // emission stage would -- search_loaded() reruns it as two halves
             static bool fired = false;
-            if (!fired && nq > 1 && getenv("SOHIT_TEST_OOM_PHASE2")) {
+            if (!fired && nq > 1 && tune().test_oom_phase2) {
                 fired = true;
                 throw DevOom(0);
             }
@@ -2259,8 +2243,8 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
     c->last_cands.assign((size_t)(ed - st), std::vector<u32>());
     c->masked.clear();
     const int nchunks = (int)c->chunks.size();
-    if (const char* e = getenv("SOHIT_BATCH")) c->max_batch = (u32)std::max(1, atoi(e));
-    if (const char* e = getenv("SOHIT_MAX_HITS")) c->max_hits_per_pass = (size_t)std::max(1ll, atoll(e));
+    if (tune().batch > 0) c->max_batch = (u32)tune().batch;
+    if (tune().max_hits > 0) c->max_hits_per_pass = (size_t)tune().max_hits;
     // A batch's candidate store is indexed with 32 bits (and costs 20 bytes of HBM per candidate).  A query has at most one candidate per
     // reference sequence and at most one per seed hit; the hits a query expects follow from the index itself (a window drawn like the
     // reference's own hits sum(c^2) / sum(c) entries per chunk).  Batches are sized so that the estimate stays below 2^32 -- the sparse
@@ -2277,7 +2261,7 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
     }
     const double est_cands = std::max(1., std::min((double)std::max<i64>(D, 1), est_hits));
     i64 batch_q = std::max<i64>(1, c->max_batch);
-    if (!getenv("SOHIT_BATCH")) batch_q = std::min<i64>(batch_q, std::max<i64>(1024, (i64)((double)0xE0000000ull / est_cands)));
+    if (tune().batch <= 0) batch_q = std::min<i64>(batch_q, std::max<i64>(1024, (i64)((double)0xE0000000ull / est_cands)));
     std::function<void(i64, i64)> run_batch = [&](i64 b0, i64 b1) {
         const so_counters keep = c->cnt;
         const size_t keep_rows = out.n, keep_dev_rows = c->d_hits_n;   // what the batch may have appended before it failed
@@ -2299,7 +2283,7 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
             c->cnt.cells_wide += (i64)uc[2];
             c->cnt.n_queries += b.nq;
             c->cnt.query_aa += b.h_off[b.nq];
-            if (getenv("SOHIT_KEEP_MASKED")) {
+            if (tune().keep_masked) {
                 if (c->masked.empty()) c->masked_lo = st;
                 if (b.h_res.empty() && b.h_off[b.nq]) {
                     b.h_res.resize(b.h_off[b.nq] + 16);
@@ -2519,7 +2503,7 @@ void query_work(so_ctx* c, i64 q_lo, i64 q_hi, u64* out) {
     build_index(c);
     const i64 N = c->qry.N;
     i64 st = std::min<i64>(std::max<i64>(0, q_lo), N), ed = std::min<i64>(q_hi < 0 ? N : q_hi, N);
-    if (const char* e = getenv("SOHIT_BATCH")) c->max_batch = (u32)std::max(1, atoi(e));
+    if (tune().batch > 0) c->max_batch = (u32)tune().batch;
     const bool prof = c->profile;
     c->profile = false;  // a pre-pass, not part of any timed stage
     try {
@@ -2550,6 +2534,8 @@ template <class F>
 int guarded(so_ctx* c, F f) {
     try {
         if (!c) return 1;
+        set_tune(&c->tune);
+        g_poison = (int)c->tune.poison;
         HIP_CHECK(hipSetDevice(c->device));
         f();
         c->err.clear();
@@ -2581,6 +2567,8 @@ so_ctx* so_create(int device, const so_params* params) {
         c = new so_ctx();
         c->device = device;
         c->tune.read();
+        set_tune(&c->tune);
+        g_poison = (int)c->tune.poison;
         {
             int ncu = 0;
             HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
@@ -2601,7 +2589,7 @@ so_ctx* so_create(int device, const so_params* params) {
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_ug_go, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_ug_done, hipEventDisableTiming));
         upload_constants(c);
-        if (!(getenv("SOHIT_WARM") && atoi(getenv("SOHIT_WARM")) == 0)) c->warm = std::thread(warm_sort_modules, device);
+        if (c->tune.warm) c->warm = std::thread(warm_sort_modules, device);
         g_create_err.clear();
         return c;
     } catch (const std::exception& e) {
@@ -2627,7 +2615,11 @@ void so_destroy(so_ctx* c) {
     if (c->ev_side_go) (void)hipEventDestroy(c->ev_side_go);
     if (c->ev_korder) (void)hipEventDestroy(c->ev_korder);
     if (c->st_side) (void)hipStreamDestroy(c->st_side);
+    if (c->ev_ug_go) (void)hipEventDestroy(c->ev_ug_go);
+    if (c->ev_ug_done) (void)hipEventDestroy(c->ev_ug_done);
+    if (c->st_ug) (void)hipStreamDestroy(c->st_ug);
     if (c->st) (void)hipStreamDestroy(c->st);
+    if (&c->tune == &tune()) set_tune(nullptr);
     delete c;
     g_hit_cache.clear();
 }
@@ -2833,6 +2825,32 @@ int64_t so_fmt_rows(const double* v, int64_t n, char* out, int64_t cap) {
         out[w++] = '\n';
     }
     return w;
+}
+
+// One switch of tune.h's table by its environment name (with or without the SOHIT_ prefix), for this context from now on.
+int so_set_option(so_ctx* c, const char* name, const char* value) {
+    return guarded(c, [&] {
+        if (!name || !value) throw SoError("so_set_option: name or value is NULL");
+        std::string n = name;
+        if (n.rfind("SOHIT_", 0) != 0) n = "SOHIT_" + n;
+        bool found = false;
+#define X_B(f) c->tune.f = atoi(value) != 0;
+#define X_I(f) c->tune.f = strtoll(value, nullptr, 0);
+#define X_D(f) c->tune.f = atof(value);
+#define X_P(f) c->tune.f = atoi(value) != 0;
+#define X(kind, field, env, dflt, text) \
+    if (!found && n == env) {           \
+        X_##kind(field) found = true;   \
+    }
+        SOHIT_TUNE_TABLE(X)
+#undef X
+#undef X_B
+#undef X_I
+#undef X_D
+#undef X_P
+        if (!found) throw SoError("so_set_option: unknown switch " + n);
+        g_poison = (int)c->tune.poison;
+    });
 }
 
 int so_set_profile(so_ctx* c, int on) {

@@ -746,8 +746,8 @@ void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& 
                   unsigned long long* stat) {
     if (!H) return;
     // SOHIT_UG_CPI / SOHIT_UG_WAIT: tuning switches (results do not depend on them)
-    const int cpi = getenv("SOHIT_UG_CPI") ? atoi(getenv("SOHIT_UG_CPI")) : UW_CPI;
-    const u32 wait_n = getenv("SOHIT_UG_WAIT") ? (u32)atoi(getenv("SOHIT_UG_WAIT")) : UW_WAIT;
+    const int cpi = (int)tune().ug_cpi;
+    const u32 wait_n = (u32)tune().ug_wait;
     BktLayout L0 = BktLayout();
     L0.nqp = 1;
     // A wave walks its range's groups one after the other on each lane: with 4096 positions per wave a pass of a few million hits (the
@@ -755,7 +755,7 @@ void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& 
     // half a fill get shorter ranges, down to 256 positions (heterogeneous 100 k set: 14.4 -> 13.0 ms of extension per step; config 3's
     // passes keep 4096 -- shorter ranges there only add table set-ups).  SOHIT_UG_RANGE: a fixed range.
     u32 range = UW_RANGE;
-    if (const char* e = getenv("SOHIT_UG_RANGE")) range = (u32)std::max(64, atoi(e));
+    if (tune().ug_range > 0) range = (u32)std::max(64ll, tune().ug_range);
     else
         while (range > 256u && (u64)H / range < 4096ull) range >>= 1;
     const dim3 g((unsigned)(((u64)H + (u64)range * UW_WAVES - 1) / ((u64)range * UW_WAVES))), bl(64 * UW_WAVES);

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_compact_seeds(const u32* __restrict__ e
 #define LW_SEEDS 256
 #define LW_WAVES 4
 static int lw_iters() {  // 64-hit steps per wave tile (tuning knob; config 2: 4 -> 0.54 ms, 8 -> 0.48 ms, 16 -> 0.46 ms)
-    static const int v = getenv("SOHIT_LK_ITERS") ? atoi(getenv("SOHIT_LK_ITERS")) : 16;
+    const int v = (int)tune().lk_iters;
     return v == 4 || v == 8 ? v : 16;
 }
 
@@ -465,7 +465,7 @@ void launch_lookup(const u32* cs_hoff, const u32* cs_base, const u64* cs_kbase, 
                    const void* dkeys, bool compact, const u32* roff, const KeyLayout& kl, u32 maxslen, u64* keys, hipStream_t st) {
     if (!H) return;
     const u32 nw = lookup_num_blocks(H);
-    static const int var = getenv("SOHIT_LK_VARIANT") ? atoi(getenv("SOHIT_LK_VARIANT")) : 0;
+    const int var = (int)tune().lk_variant;
     const dim3 g((nw + LW_WAVES - 1) / LW_WAVES), bl(64 * LW_WAVES);
 #define LK_LAUNCH(I, V)                                                                                                              \
     do {                                                                                                                             \

@@ -23,7 +23,7 @@ using SegCfg = rocprim::segmented_radix_sort_config<BITS, rocprim::kernel_config
 // keys cost the same per pass as 8-bit / 256 x 16 (3.96 vs 3.97 ms on config 2) and keep widths up to 27 at three passes.
 // (10-bit digits with 1024 x 4 keys: 5.3 ms per three passes -- no better than four 8-bit ones.)
 static int seg_variant(size_t n, u32 nseg, int width) {
-    static const int v = getenv("SOHIT_SEG_CFG") ? atoi(getenv("SOHIT_SEG_CFG")) : -1;
+    const int v = (int)tune().seg_cfg;
     if (v >= 0) return v;
     if (!(nseg && n / nseg >= 4096)) return 0;
     if (width > 24 && width <= 27) return 6;
@@ -70,7 +70,7 @@ static hipError_t seg_sort_pairs(void* temp, size_t& bytes, const u64* kin, u64*
 }
 static hipError_t seg_sort_pairs_dispatch(void* temp, size_t& bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, u32 nseg,
                                           const u32* sb, const u32* se, int b0, int b1, hipStream_t st) {
-    static const int v = getenv("SOHIT_CSEG_CFG") ? atoi(getenv("SOHIT_CSEG_CFG")) : -1;   // tuning switch: 0 default, 1 = 256 x 16, 2 = 512 x 16
+    const int v = (int)tune().cseg_cfg;   // tuning switch: 0 default, 1 = 256 x 16, 2 = 512 x 16
     const size_t avg = nseg ? n / nseg : 0;
     // 100k weight-6 set (7.5 k candidates per query and pass), best / candidate-order stage per step: device-wide sort 166.7 ms, 256 x 16
     // 166.7, 512 x 16 145.4, 1024 x 16 148.9
@@ -94,7 +94,7 @@ void sort_pairs_u64_u32_seg(void* temp, size_t temp_bytes, const u64* kin, u64* 
 // begin + bits == 64 shifts by the word size and ends up comparing the bits BELOW begin_bit (ROCm 7.2) -- the caller keeps bit 63 free.
 static hipError_t cand_keys_dispatch(void* temp, size_t& bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* sb, const u32* se, int b0,
                                      int b1, hipStream_t st) {
-    static const int v = getenv("SOHIT_CSEG_CFG") ? atoi(getenv("SOHIT_CSEG_CFG")) : -1;
+    const int v = (int)tune().cseg_cfg;
     const size_t avg = nseg ? n / nseg : 0;
     const int cfg = v >= 0 ? v : avg >= 3072 ? 2 : avg >= 1024 ? 1 : 0;
     if (cfg == 2) return seg_sort<SegCfg<16, 512>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);

@@ -668,7 +668,7 @@ static void ungap1_launch(u32 ncu, const u32* words, const u32* bext, u32 nb, co
                           u32 wait_n, const u8* q_scls, const u32* qoff, const u8* r_ug, const u32* roff, const signed char* b62g, u32* work_ctr, u32* shard_cnt,
                           u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, u64* mlist, u32* mlist_cnt, unsigned long long* stat, hipStream_t st) {
     static bool said = false;
-    if (!said && getenv("SOHIT_DEBUG")) {
+    if (!said && tune().debug) {
         int nblk = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_ungap1<BANDS, TSH, QCAP, WGS, COUNT>, 64 * U1_WAVES, 0);
         hipFuncAttributes fa;

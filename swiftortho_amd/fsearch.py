@@ -120,6 +120,11 @@ class Searcher:
     def set_profile(self, on):
         self.L.so_set_profile(self.h, 1 if on else 0)
 
+    def set_option(self, name, value):
+        """one switch of csrc/tune.h by its SOHIT_* name, for this searcher from now on (so_create read the environment once)"""
+        if self.L.so_set_option(self.h, str(name).encode(), str(value).encode()) != 0:
+            raise ValueError(self.L.so_last_error(self.h).decode())
+
     def reset_counters(self):
         self.L.so_reset_counters(self.h)
 

@@ -159,11 +159,11 @@ def test_ungap_steps_equal_the_reference_count(fs, oracle, tmp_path, monkeypatch
     for fa in (synthprot.synthprot(1500, 300, 91), synthprot.uniform_proteins(900, 250, 92), synthprot.synthprot(700, seed=93, lengths="lognormal")):
         c, st = oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
         assert c["ungap_steps"] > 10 * c["groups"]
-        if env.get("SOHIT_BUCKET_MIN") == "0" and "SOHIT_UG1" not in env and "SOHIT_UG_W32" not in env:
+        if "SOHIT_UG1" in env or "SOHIT_UG_W32" in env:
+            assert c["groups_single"] == 0 and c["groups_chain"] == 0
+        elif env.get("SOHIT_BUCKET_MIN") == "0":
             assert c["groups_single"] > 0.5 * c["groups"]
             assert (c["groups_chain"] > 0) == ("SOHIT_UG1_CHAIN" not in env)
-        else:
-            assert c["groups_single"] == 0 and c["groups_chain"] == 0
 
 
 def test_synth_2000_vs_oracle(fs, oracle, tmp_path):
