@@ -143,16 +143,55 @@ def run_rank(p):
         if ed > st:
             weights[st:ed] += sdist.sharded_query_work(s, lens, st, ed)   # the pre-pass itself is split over the ranks
         lo, hi = sdist.shard_queries(weights, world, st, ed)[rank]
-        dev = s.search_device(lo, hi)   # hi == lo: an empty result, still takes part in the exchange
-        g = sdist.gather_device_records(dev.tensor())
-        if rank == 0:
-            # ranks hold contiguous ascending query ranges: their records back to back are the file order
-            arr, n = fsearch.hits_from_bytes(s, g.to_host())
-            s._chk(s.L.so_write_sc(s.h, arr, n, os.fsencode(p['outfile']), b'w'))
-        dev.close()
+        # Every rank formats and writes ITS OWN rows (round 5; before: the records of all ranks were gathered to rank 0, which formatted
+        # ~300 M rows alone at 1 M proteins).  Ranks hold contiguous ascending query ranges, so the file is the ranks' texts back to back:
+        # each rank writes a part file, the byte counts are exchanged (one all_gather of 8 bytes), rank 0 sizes the output file and
+        # every rank copies its part to its offset -- find_hit.py's own scheme (block files + cat, find_hit.py:133-146) with the
+        # copy done by all ranks at once.  The RCCL record gather stays the exchange of so_search_device / bench.py.
+        hits = s.search(lo, hi)   # hi == lo: no rows, still takes part in the exchange
+        part = '%s.part%d' % (p['outfile'], rank)
+        hits.write(part, 'w')
+        hits.close()
+        place_parts(p['outfile'], part, rank, world, dist)
     finally:
         s.close()
         dist.destroy_process_group()
+
+
+def place_parts(outfile, part, rank, world, dist):
+    """The ranks' part files -> `outfile`, each copied to the offset its predecessors' sizes give (os.copy_file_range: no user-space
+    copy; plain reads / pwrites where the kernel or the file system lacks it); parts are removed."""
+    import torch
+    n = os.path.getsize(part)
+    sizes = torch.zeros(world, dtype=torch.int64)
+    mine = torch.tensor([n], dtype=torch.int64)
+    if dist.get_backend() == 'nccl':
+        sizes, mine = sizes.cuda(), mine.cuda()
+    dist.all_gather_into_tensor(sizes, mine)
+    sizes = [int(x) for x in sizes.cpu().tolist()]
+    off = sum(sizes[:rank])
+    if rank == 0:
+        with open(outfile, 'wb') as f:
+            f.truncate(sum(sizes))
+    dist.barrier()
+    if n:
+        with open(part, 'rb') as src, open(outfile, 'r+b') as dst:
+            done = 0
+            try:
+                while done < n:
+                    k = os.copy_file_range(src.fileno(), dst.fileno(), min(n - done, 1 << 30), done, off + done)
+                    if k <= 0:
+                        raise OSError('short copy')
+                    done += k
+            except (OSError, AttributeError):
+                while done < n:
+                    buf = os.pread(src.fileno(), min(n - done, 1 << 24), done)
+                    if not buf:
+                        raise IOError('part file %s shorter than expected' % part)
+                    os.pwrite(dst.fileno(), buf, off + done)
+                    done += len(buf)
+    os.remove(part)
+    dist.barrier()
 
 
 def fasta_parse(f):

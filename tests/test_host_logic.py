@@ -150,6 +150,44 @@ def test_two_rank_gloo_gather(tmp_path, empty1):
         assert line[1:] == ["100", str(sum(range(100))), "True"]
 
 
+PLACE_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from swiftortho_amd import find_hit
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+out = os.environ["OUT"]
+part = "%%s.part%%d" %% (out, rank)
+# rank r's "rows": r * 1000 + 17 lines (rank 1 none when EMPTY1), each naming its rank and line number
+n = 0 if (rank == 1 and os.environ.get("EMPTY1")) else rank * 1000 + 17
+open(part, "wb").write(b"".join(b"rank%%d line %%07d\n" %% (rank, i) for i in range(n)))
+find_hit.place_parts(out, part, rank, world, dist)
+assert not os.path.exists(part)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,empty1", [(2, False), (3, True)])
+def test_every_rank_places_its_own_rows_in_the_output_file(tmp_path, world, empty1):
+    """find_hit.py -a N (round 5): every rank writes a part file and copies it to ITS offset of the output file (one all_gather of the
+    byte counts; no rank formats or writes another's rows).  world_size 2 and 3 over gloo, one rank without rows: the file is the
+    ranks' texts back to back, the parts are gone."""
+    script = tmp_path / "pw.py"
+    script.write_text(PLACE_WORKER % ROOT)
+    out = tmp_path / "out.sc"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29950 + os.getpid() % 40 + world), WORLD_SIZE=str(world), OUT=str(out))
+    if empty1:
+        env["EMPTY1"] = "1"
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    want = b"".join(b"rank%d line %07d\n" % (r, i) for r in range(world) for i in range(0 if (r == 1 and empty1) else r * 1000 + 17))
+    assert out.read_bytes() == want
+    assert sorted(os.listdir(tmp_path)) == ["out.sc", "pw.py"]
+
+
 def test_bench_gpus_n_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no torch.distributed environment starts the two ranks itself (child torchrun, before
     anything touches the GPU) and relays the exit code.  Here there is no GPU, so both ranks must fail loudly -- "needs a GPU:
