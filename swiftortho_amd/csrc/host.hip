@@ -280,8 +280,8 @@ struct so_ctx {
     DevBuf<u32> d_scan_tmp, d_tmp32a, d_tmp32b;
     DevBuf<u64> d_stats;
     DevBuf<u32> d_small;  // parked scan totals (stash_u32)
-    DevBuf<u32> ix_pcount, ix_bkt, ix_bkt2, ix_flags, ix_ridx;  // index build scratch
-    DevBuf<u64> ix_ent;
+    DevBuf<u32> ix_pcount, ix_bkt, ix_bkt2, ix_flags, ix_ridx, ix_plan, ix_tk;  // index build scratch
+    DevBuf<u64> ix_ent, ix_tv;
     DevBuf<u8> d_pcls;
     DevBuf<u8> d_sort_tmp;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -633,8 +633,8 @@ void warm_sort_modules(int device) {
             HIP_CHECK(hipMemsetAsync(v.p, 0, 8 * sizeof(u64), st));
             const u32 sg[2] = {0, 2};
             HIP_CHECK(hipMemcpyAsync(seg.p, sg, sizeof sg, hipMemcpyHostToDevice, st));
-            tmp.ensure(std::max(sort_pairs_u32_u64_temp_bytes(2, 8), sort_keys_u64_seg_temp_bytes(2, 1, 0, 8)) + 256);
-            sort_pairs_u32_u64(tmp.p, tmp.cap, k.p, k2.p, v.p, v2.p, 2, 8, st);
+            tmp.ensure(std::max(sort_pairs_u64_u32_temp_bytes(2, 8), sort_keys_u64_seg_temp_bytes(2, 1, 0, 8)) + 256);
+            sort_pairs_u64_u32(tmp.p, tmp.cap, v.p, v2.p, k.p, k2.p, 2, 8, st);   // (the index build no longer sorts: the sorted path's units)
             sort_keys_u64_seg(tmp.p, tmp.cap, v.p, v2.p, 2, 1, seg.p, 0, 8, st);
             HIP_CHECK(hipStreamSynchronize(st));
         }
@@ -709,10 +709,13 @@ void build_index(so_ctx* c) {
             // 2. group by bucket id (ascending): the slot layout of the reference's CSR
             const int bbits = ceil_log2((u64)NC);
             dlap("windows (emit)");
-            ensure_sort_tmp(c, sort_pairs_u32_u64_temp_bytes(E, bbits));
-            dlap("alloc sort tmp");
-            sort_pairs_u32_u64(c->d_sort_tmp.p, c->d_sort_tmp.cap, c->ix_bkt.p, c->ix_bkt2.p, c->ix_ent.p, ch->entries.p, E, bbits, c->st);
-            dlap("pair sort");
+            // (hand-written: two counting passes, k_ixsort.hip; members of a bucket land in no particular order)
+            (void)bbits;
+            c->ix_plan.ensure(ixsort_plan_elems((u32)NC) + 8), c->ix_tk.ensure((size_t)E + 4), c->ix_tv.ensure((size_t)E + 4);
+            c->d_scan_tmp.ensure(scan_u32_temp_elems(ixsort_plan_elems((u32)NC)) + 8);
+            dlap("alloc grouping scratch");
+            ixsort_pairs(c->ix_bkt.p, c->ix_ent.p, E, (u32)NC, c->ix_plan.p, c->d_scan_tmp.p, c->ix_tk.p, c->ix_tv.p, c->ix_bkt2.p, ch->entries.p, c->st);
+            dlap("pair grouping");
             // 3. runs -> occupied bucket list, first slots, sizes
             c->ix_flags.ensure((size_t)E + 4), c->ix_ridx.ensure((size_t)E + 4);
             c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)E + 1) + 8);

@@ -38,16 +38,3 @@ __global__ __launch_bounds__(256) void k_stride_gather(const u32* __restrict__ s
 void launch_stride_gather(const u32* src, u32 stride, u32 n, u32* dst, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_stride_gather, dim3((n + 255) / 256), dim3(256), 0, st, src, stride, n, dst);
 }
-
-// (bucket id, index entry) pairs of the index build
-size_t sort_pairs_u32_u64_temp_bytes(size_t n, int bits) {
-    size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs((void*)nullptr, bytes, (const u32*)nullptr, (u32*)nullptr, (const u64*)nullptr, (u64*)nullptr,
-                                             (int)n, 0, bits, (hipStream_t)0);
-    return bytes;
-}
-
-void sort_pairs_u32_u64(void* temp, size_t temp_bytes, const u32* kin, u32* kout, const u64* vin, u64* vout, size_t n, int bits, hipStream_t st) {
-    if (n == 0) return;
-    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, kin, kout, vin, vout, (int)n, 0, bits, st));
-}

@@ -25,6 +25,11 @@ size_t sort_pairs_u64_u32_temp_bytes(size_t n, int bits);
 void sort_pairs_u64_u32(void* temp, size_t temp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, int bits,
                         hipStream_t st);
 
+// k_ixsort.hip: (bucket id, entry) pairs grouped by ascending bucket id, members of a bucket in no particular order.  plan:
+// ixsort_plan_elems(NC) u32, scan_tmp: scan_u32_temp_elems of that, (tk, tv): E pairs of scratch; (kin, vin) are scratch too when NC > 2^27
+size_t ixsort_plan_elems(u32 NC);
+void ixsort_pairs(u32* kin, u64* vin, u32 E, u32 NC, u32* plan, u32* scan_tmp, u32* tk, u64* tv, u32* kout, u64* vout, hipStream_t st);
+
 // k_prep.hip
 void launch_layout(const u8* res, const u32* off, u32 nseq, u32 P, u32 Ppad, const u8* hmap, u32* pseq, u8* pcls, u32* words,
                    hipStream_t st);
@@ -49,8 +54,6 @@ void launch_run_heads(const u32* bkt, u32 E, u32* flags, hipStream_t st);
 void launch_run_list(const u32* bkt, const u32* flags, const u32* ridx, u32 E, u32 U, u32* ub, u32* ubeg, u32* cnt, hipStream_t st);
 void launch_dir_build(const u32* ub, u32 U, u64* dir /*zeroed, NC / 32 + 1 words*/, hipStream_t st);
 void launch_htab_insert(const u32* ub, const u32* ubeg, u32 U, u32* hkey, u64* hval, int hshift, u32 hmask, hipStream_t st);
-void sort_pairs_u32_u64(void* temp, size_t temp_bytes, const u32* kin, u32* kout, const u64* vin, u64* vout, size_t n, int bits, hipStream_t st);
-size_t sort_pairs_u32_u64_temp_bytes(size_t n, int bits);
 #define INDEX_STATS_BLOCKS 2048
 void launch_index_stats(const u32* counts, u32 NC, u64* stats_buf /*4 + 4 * INDEX_STATS_BLOCKS*/, hipStream_t st);
 void launch_encode_band32(const u64* entries, u32 E, int ba, const u32* gbase /*per chunk sequence*/, const u32* roff /*chunk-local*/, u32* dk32, hipStream_t st);

@@ -341,6 +341,22 @@ def test_hit_budget_splits_passes(fs, oracle, tmp_path, monkeypatch):
     oracle_vs_gpu(fs, oracle, synthprot.synthprot(400, 150, 84), kw, tmp_path)
 
 
+@pytest.mark.parametrize("NC", [9, 16384, 16385, 134217728, 134217729, 300000007])
+def test_index_grouping_at_every_bucket_count(fs, oracle, NC):
+    """The index build groups its (bucket, entry) pairs with two hand-written counting passes (k_ixsort.hip): bins of 2^wsh ids, then
+    16384 ids per LDS pass -- one bin (NC <= 16384), the first two-bin split, the widest single-pass bins (NC = 2^27) and bins that
+    need the extra split by the upper digit (NC above 2^27; 3e8 also takes the hashed directory).  Index arrays == the oracle's CSR."""
+    from swiftortho_amd import synthprot
+    fa = synthprot.synthprot(300, 120, 17)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=NC, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    s, hits, _ = gpu_rows(fs, fa, fa, kw)
+    ix = oracle.Index(fa, kw["ssd"], kw["nr"], 1, NC)
+    assert s.chunk_threshold(0) == ix.threshold
+    check_index(s, ix, NC, A=1, S=1)
+    hits.close()
+    s.close()
+
+
 def test_huge_family_over_4096_candidates_per_query(fs, oracle, tmp_path):
     """one 6000-member family: every query collects > 4096 candidates, which takes the global-memory
     variant of the exact wave quicksort (phase 2 ordering) instead of the LDS one."""
