@@ -1590,11 +1590,20 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         if ((u64)base + NS >= cand_limit()) throw CandOverflow();   // (SOHIT_CAND_LIMIT: tests lower the limit to exercise the split)
         b.qseg.ensure((size_t)b.nq + 4), b.tmp64.ensure((size_t)NS + 2);
         launch_stride_gather(b.bccnt.p, bL.R, bL.nqp + 1, b.qseg.p, c->st);
-        ensure_sort_tmp(c, sort_cand_keys_seg_temp_bytes(NS, bL.nqp, cand_idx_bits, cand_idx_bits + cand_ftw));
-        sort_cand_keys_seg(c->d_sort_tmp.p, c->d_sort_tmp.cap, c_ftp, b.tmp64.p, NS, bL.nqp, b.qseg.p, cand_idx_bits, cand_idx_bits + cand_ftw, c->st);
         b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
         b.cand_rec.ensure(4 * ((size_t)base + NS) + 16, true, c->st);
-        launch_emit_cands_seg(b.tmp64.p, b.qseg.p, bL.nqp, bL.qa, cand_idx_bits, c_recp, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, c->st);
+        bool lib_sort = !tune().cand_order_lds;
+        if (!lib_sort) {   // sort + row gather per query in one hand-written kernel (k_cand_order_seg)
+            HIP_CHECK(hipMemsetAsync(b.bflag.p, 0, sizeof(u32), c->st));
+            launch_cand_order_seg(c_ftp, b.qseg.p, bL.nqp, bL.qa, cand_idx_bits, cand_idx_bits + cand_ftw, c_recp, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base,
+                                  qcnt, b.bflag.p, c->st);
+            lib_sort = d2h_u32(c, b.bflag.p) != 0;   // (a digit group above the LDS sort: never seen; the library path then redoes the pass's order)
+        }
+        if (lib_sort) {   // (SOHIT_CAND_ORDER_LDS=0: the library's segmented radix sort, then the gather)
+            ensure_sort_tmp(c, sort_cand_keys_seg_temp_bytes(NS, bL.nqp, cand_idx_bits, cand_idx_bits + cand_ftw));
+            sort_cand_keys_seg(c->d_sort_tmp.p, c->d_sort_tmp.cap, c_ftp, b.tmp64.p, NS, bL.nqp, b.qseg.p, cand_idx_bits, cand_idx_bits + cand_ftw, c->st);
+            launch_emit_cands_seg(b.tmp64.p, b.qseg.p, bL.nqp, bL.qa, cand_idx_bits, c_recp, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, qcnt, c->st);
+        }
         b.chunk_base.back() = base + NS;
         c->cnt.candidates += NS;
         sc.lap("group.best_order");

@@ -198,6 +198,10 @@ void launch_rec_scatter(const u64* p_qs, const u64* p_sd, const u64* p_ft, const
                         int ft_bits_entry, int bsp, const u32* roff, const u32* boff, u64* q_qs, u64* q_sd, u64* q_ft, hipStream_t st);
 void launch_bkt_best(bool write, const u64* q_qs, const u64* q_sd, const u64* q_ft, const u32* boff, u32 nb, const BktLayout& L, int bs,
                      u32 seq_lo, u32* ccnt, u64* c_ft, u32* c_q, u32* c_rec, int bsp, int idx_bits /*> 0: c_ft receives sort words*/, hipStream_t st);
+// sort words (first-touch word << idx_bits | position in the query's segment) -> the query's records in first-touch order, its count
+// (word_bits = idx_bits + width of the first-touch word; *fallback |= 2 when a query's digit group exceeds the LDS sort: order the pass otherwise)
+void launch_cand_order_seg(const u64* words, const u32* seg, u32 nqp, u32 qa, int idx_bits, int word_bits, const u32* c_rec, u32* out_q, u32* out_rec, u32* qcnt,
+                           u32* fallback, hipStream_t st);
 void launch_emit_cands_seg(const u64* sorted, const u32* seg, u32 nqp, u32 qa, int idx_bits, const u32* c_rec, u32* out_q, u32* out_rec, u32* qcnt,
                            hipStream_t st);
 size_t sort_cand_keys_seg_temp_bytes(size_t n, u32 nseg, int begin_bit, int end_bit);
