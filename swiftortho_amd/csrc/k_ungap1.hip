@@ -699,9 +699,12 @@ void launch_ungap1(u32 ncu, int variant, u32 pmaxq, const u32* words, const u32*
     if (variant == 2 && pmaxq <= 512) {
         if (btab) U1_GO(true, 3, 512, 2);
         else U1_GO(false, 3, 512, 2);
-    } else if (variant == 0) {
-        if (btab) U1_GO(true, 4, U1_QCAP, 1);
-        else U1_GO(false, 4, U1_QCAP, 1);
+    } else if (variant == 0 && pmaxq <= 1024) {
+        if (btab) U1_GO(true, 4, 1024, 1);
+        else U1_GO(false, 4, 1024, 1);
+    } else if (pmaxq <= 1024) {
+        if (btab) U1_GO(true, 3, 1024, 1);
+        else U1_GO(false, 3, 1024, 1);
     } else {
         if (btab) U1_GO(true, 3, U1_QCAP, 1);
         else U1_GO(false, 3, U1_QCAP, 1);

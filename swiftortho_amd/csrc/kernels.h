@@ -96,7 +96,7 @@ void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& 
 
 // k_ungap1.hip: the singleton groups of a bucketed pass (queries up to U1_QCAP residues); pass records are appended like k_ungap's
 #define UG_REC_NONE 0xFFFFFFFFFFFFFFFFull   // p_qs of an unused pass-list slot (k_ungap1 reserves the list in pieces)
-#define U1_QCAP 1024          // longest query (its classes sit in an LDS slot per wave)
+#define U1_QCAP 2048          // longest query (its classes sit in an LDS slot per wave; packed 16-bit scores: 11 * 2048 + the pin's 8192 < 2^15)
 #define U1_UG_PAD 4096        // sentinel bytes in front of and behind the subject-side array (a dropped pass keeps reading while the other one runs)
 u32 ungap1_qcap();
 size_t ungap1_list_slack(u32 ncu);   // pass-list slots its waves may leave unused
