@@ -56,7 +56,11 @@ struct DevBuf {
             HIP_CHECK(e);
         }
         // SOHIT_POISON=<byte>: fill every fresh allocation (tests: results must not depend on what device memory held before)
-        if (g_poison >= 0) HIP_CHECK(hipMemset(np_, g_poison & 0xFF, nc * sizeof(T)));
+        // (the fill is queued on the null stream, which the non-blocking streams -- index build, side streams -- are not ordered with: wait for it)
+        if (g_poison >= 0) {
+            HIP_CHECK(hipMemset(np_, g_poison & 0xFF, nc * sizeof(T)));
+            HIP_CHECK(hipStreamSynchronize(0));
+        }
         if (keep && p && cap) {
             HIP_CHECK(hipMemcpyAsync(np_, p, cap * sizeof(T), hipMemcpyDeviceToDevice, st));
             HIP_CHECK(hipStreamSynchronize(st));

@@ -1958,12 +1958,23 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
             // score-only: the packed 16-bit kernel (two alignments per register) for every task whose scores fit it, the 32-bit one for the
             // n_wide tasks at the head of the list that do not
+            // (the few wide tasks of a mixed batch are its longest: a launch of their own lasts as long as one 4096-row band, ~0.5 ms per
+            // round with the GPU nearly idle -- so they run beside the packed kernel, on st_side, which is idle in phase 2; st_ug would
+            // not do: it shares its hardware queue with the batch's stream on this runtime -- four queues, dealt round-robin)
+            const bool wide_aside = n_wide && NR > n_wide && tune().wide_aside;
+            hipStream_t wst = wide_aside ? c->st_side : c->st;
+            if (wide_aside) {
+                HIP_CHECK(hipEventRecord(c->ev_ug_go, c->st));
+                HIP_CHECK(hipStreamWaitEvent(c->st_side, c->ev_ug_go, 0));
+            }
             if (n_wide)
                 launch_align(b.tasks.p, rlist, n_wide, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
-                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, nullptr, b.ares.p, false, c->st);
+                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, nullptr, b.ares.p, false, wst);
+            if (wide_aside) HIP_CHECK(hipEventRecord(c->ev_ug_done, c->st_side));
             if (NR > n_wide)
                 launch_align_pk(b.tasks.p, rlist + n_wide, NR - n_wide, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_scls4.p,
                                 c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->st);
+            if (wide_aside) HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_ug_done, 0));
             pt.stop();
             c->cnt.align_wide += n_wide;
         }

@@ -16,6 +16,7 @@
 // score table.  2-bit traces go to a per-task scratch slab; the traceback caches its trace word.
 #include "common.h"
 #include "kernels.h"
+#include <algorithm>
 #include <type_traits>
 
 #define KB 16  // kbound
@@ -252,26 +253,108 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
 // ('|') and the left boundary cell (i, i-17) ('|'), plus the alignment statistics (1454-1471).
 // One thread per alignment; the 2-bit traces come from the slab k_align wrote in the same launch
 // sequence (kernel boundary = visibility), with the current trace word cached in a register.
+//
+// LONG walks (wave mode, round 5).  A thread's walk is a chain of dependent steps -- ~0.4 us each once the wave is alone on its SIMD --
+// so a launch lasted as long as its longest walk: 1.6 ms for the 4096 columns of a giant's self-alignment, whatever else it held
+// (log-normal set: 4 launches, 7.2 ms per step).  The first `nw` blocks of the launch therefore take the first nw list positions
+// (the lists are ordered longest band first) ONE WALK PER WAVE when the band has at least `wrows` rows: the 64 lanes look at the next
+// 64 cells up the current diagonal together (their trace codes and residues: one memory round trip), the leading run of plain
+// diagonal columns -- code 1, no '-' residue -- is added in one go (columns, matches by popcount; behind a non-gap column the gap
+// machine's three counters are all f(-1)), and the column that ends the run takes the single step of the thread walk, served from the
+// lane that looked at it.  The other blocks walk 64 alignments each as before and skip what a wave took.
+template <bool WAVE>
+__device__ __forceinline__ void traceback_one(const u32 tid, const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx,
+                                              const u8* __restrict__ q_res, const u32* __restrict__ qoff, const u8* __restrict__ r_res,
+                                              const u32* __restrict__ roff, const u32* __restrict__ trace, u32 trace_stride,
+                                              const u32* __restrict__ tpos, const u32* __restrict__ tofs, AlnRes* __restrict__ out, u32 nw, int wrows);
+
 __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 ntasks,
                                                   const u8* __restrict__ q_res, const u32* __restrict__ qoff,
                                                   const u8* __restrict__ r_res, const u32* __restrict__ roff,
                                                   const u32* __restrict__ trace, u32 trace_stride, const u32* __restrict__ tpos,
-                                                  const u32* __restrict__ tofs, AlnRes* __restrict__ out) {
-    const u32 tid = blockIdx.x * 64u + threadIdx.x;
+                                                  const u32* __restrict__ tofs, AlnRes* __restrict__ out, u32 nw, int wrows) {
+    if (blockIdx.x < nw) {
+        traceback_one<true>(blockIdx.x, tasks, ridx, q_res, qoff, r_res, roff, trace, trace_stride, tpos, tofs, out, nw, wrows);
+        return;
+    }
+    const u32 tid = (blockIdx.x - nw) * 64u + threadIdx.x;
     if (tid >= ntasks) return;
+    traceback_one<false>(tid, tasks, ridx, q_res, qoff, r_res, roff, trace, trace_stride, tpos, tofs, out, nw, wrows);
+}
+
+template <bool WAVE>
+__device__ __forceinline__ void traceback_one(const u32 tid, const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx,
+                                              const u8* __restrict__ q_res, const u32* __restrict__ qoff, const u8* __restrict__ r_res,
+                                              const u32* __restrict__ roff, const u32* __restrict__ trace, u32 trace_stride,
+                                              const u32* __restrict__ tpos, const u32* __restrict__ tofs, AlnRes* __restrict__ out, u32 nw, int wrows) {
     const u32 slot = ridx ? ridx[tid] : tid;
     const AlnTask tk = tasks[slot];
-    AlnRes r = out[slot];
     const u32 qb = qoff[tk.q], sb = roff[tk.subj];
     const int lq = min((int)(qoff[tk.q + 1] - qb), (int)tk.qe), ls = min((int)(roff[tk.subj + 1] - sb), (int)tk.se);
     const int qi = min((int)tk.qi, lq), qj = min((int)tk.qj, ls);
     const int la = lq - qi, lb = ls - qj;
+    {   // who walks this alignment: a wave, if the band is long and the list position is among the first nw
+        const bool by_wave = tid < nw && min(max(la, lb), min(la, lb) + KB) >= wrows;
+        if (by_wave != WAVE) return;
+    }
+    AlnRes r = out[slot];
     const bool swp = !(la < lb);
     const u8* craw = swp ? (r_res + sb + qj) : (q_res + qb + qi);
     const u8* rraw = swp ? (q_res + qb + qi) : (r_res + sb + qj);
     // tpos: traces kept per task (speculative); tofs: per launch position, variable size; else one stride per launch position
     const u32* tr = trace + (size_t)(tpos ? tpos[slot] : tofs ? tofs[tid] : tid) * trace_stride;
     const int bi = r.qst, bj = r.qed;
+    if (WAVE) {
+        const int t = threadIdx.x;
+        int i = bi, j = bj, AL = 0, matches = 0, fm1 = 0, f0 = 0, f1 = 0;
+        while (i > 0 || j > 0) {
+            const int d = j - i + KB;
+            const bool inband = i > 0 && j > 0 && d >= 0;   // (wave-uniform)
+            // lane t looks at cell (i - t, j - t) of the diagonal; outside the band interior every lane looks at (i, j)
+            const int it = inband ? i - t : i, jt = inband ? j - t : j;
+            int tcl = 0;
+            if (inband && it > 0 && jt > 0) {
+                const int m = it + (d >> 1);
+                tcl = (int)((tr[((m >> 3) - 1) * 16 + (d >> 1)] >> (((7 - (m & 7)) << 2) + ((d & 1) << 1))) & 3u);
+            }
+            const int a0l = jt > 0 ? (int)craw[jt - 1] : (int)'-', a1l = it > 0 ? (int)rraw[it - 1] : (int)'-';
+            int run = 0;
+            if (inband) {
+                const u64 okm = __ballot(it > 0 && jt > 0 && tcl == 1 && a0l != '-' && a1l != '-');
+                run = ~okm ? __builtin_ctzll(~okm) : 64;
+                if (run) {
+                    const u64 eqm = __ballot(a0l == a1l);
+                    AL += run, matches += __builtin_popcountll(run < 64 ? eqm & ((1ull << run) - 1ull) : eqm);
+                    f0 = fm1, f1 = fm1;
+                    i -= run, j -= run;
+                }
+                if (run == 64) continue;
+                if (!(i > 0 || j > 0)) break;
+            }
+            // the column at (i, j), looked at by lane `run`: the thread walk's step
+            int tc;
+            if (i == 0) tc = 2;
+            else if (j == 0) tc = 3;
+            else if (d < 0) tc = 3;  // left boundary cell (i, i-17): '|'
+            else tc = __builtin_amdgcn_readlane(tcl, run);
+            if (tc == 0) break;
+            ++AL;
+            const int a0 = tc != 3 ? __builtin_amdgcn_readlane(a0l, run) : (int)'-', a1 = tc != 2 ? __builtin_amdgcn_readlane(a1l, run) : (int)'-';
+            matches += (a0 == a1) ? 1 : 0;
+            const bool g0 = a0 == '-', g1 = a1 == '-';
+            const int nm1 = g0 ? 1 + f0 : (g1 ? 1 + f1 : fm1), n0 = g1 ? 1 + f1 : fm1, n1 = g0 ? 1 + f0 : fm1;
+            fm1 = nm1, f0 = n0, f1 = n1;
+            if (tc != 3) --j;
+            if (tc != 2) --i;
+        }
+        if (t == 0) {
+            r.aln = AL, r.matches = matches, r.gap = fm1;
+            if (swp) r.qst = i + qi, r.qed = bi + qi, r.sst = j + qj, r.sed = bj + qj;
+            else r.qst = j + qi, r.qed = bj + qi, r.sst = i + qj, r.sed = bi + qj;
+            out[slot] = r;
+        }
+        return;
+    }
     // The reference derives its statistics from the two aligned STRINGS, gap columns spelled '-' (1454-1471): identity
     // compares characters, and the gap counter is a three-state machine over them (op = -1 / 0 / 1; a '-' in string 0 opens
     // when op != 0, else one in string 1 opens when op != 1, else op resets) -- so a run of L gap columns counts ceil(L / 2)
@@ -399,6 +482,11 @@ void launch_trace_units(const AlnTask* tasks, const u32* ridx, u32 n, const u32*
     hipLaunchKernelGGL(k_trace_units, dim3((n + 1 + 255) / 256), dim3(256), 0, st, tasks, ridx, n, qoff, roff, units);
 }
 
+// list positions offered to the wave walks (SOHIT_TRACE_WAVE_ROWS = 0: none)
+static inline u32 traceback_waves(u32 ntasks) {
+    return tune().trace_wave_rows > 0 ? (u32)std::min<long long>(ntasks, std::max<long long>(0, tune().trace_wave_max)) : 0u;
+}
+
 // with_traceback = false: scores only (trace may be null); true: traces + traceback statistics
 void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u8* q_scls4, const u32* qoff,
                   const u8* r_res, const u8* r_scls, const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride,
@@ -411,8 +499,9 @@ void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q
     }
     hipLaunchKernelGGL((k_align<true>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff,
                        b62g, trace, trace_stride, tofs, out, (u32*)nullptr, 0u);
-    hipLaunchKernelGGL(k_traceback, dim3((ntasks + 63) / 64), dim3(64), 0, st, tasks, ridx, ntasks, q_res, qoff, r_res, roff, trace,
-                       trace_stride, (const u32*)nullptr, tofs, out);
+    const u32 nw = traceback_waves(ntasks);
+    hipLaunchKernelGGL(k_traceback, dim3(nw + (ntasks + 63) / 64), dim3(64), 0, st, tasks, ridx, ntasks, q_res, qoff, r_res, roff, trace,
+                       trace_stride, (const u32*)nullptr, tofs, out, nw, (int)tune().trace_wave_rows);
 }
 
 void launch_align_traced(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
@@ -426,6 +515,7 @@ void launch_align_traced(const AlnTask* tasks, const u32* ridx, u32 ntasks, cons
 void launch_traceback(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u32* qoff, const u8* r_res, const u32* roff,
                       const u32* trace, u32 trace_stride, const u32* tpos, AlnRes* out, hipStream_t st) {
     if (!ntasks) return;
-    hipLaunchKernelGGL(k_traceback, dim3((ntasks + 63) / 64), dim3(64), 0, st, tasks, ridx, ntasks, q_res, qoff, r_res, roff, trace, trace_stride, tpos,
-                       (const u32*)nullptr, out);
+    const u32 nw = traceback_waves(ntasks);
+    hipLaunchKernelGGL(k_traceback, dim3(nw + (ntasks + 63) / 64), dim3(64), 0, st, tasks, ridx, ntasks, q_res, qoff, r_res, roff, trace, trace_stride, tpos,
+                       (const u32*)nullptr, out, nw, (int)tune().trace_wave_rows);
 }

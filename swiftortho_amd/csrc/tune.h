@@ -45,8 +45,11 @@
     X(I, cand_limit, "SOHIT_CAND_LIMIT", 0, "tests: candidate-store size at which a batch is split (0: 2^32 - 16)")                                            \
     /* ---- phase 2 ---- */                                                                                                                                     \
     X(B, align_pk, "SOHIT_ALIGN_PK", 1, "packed 16-bit score-only aligner where the scores fit")                                                               \
+    X(B, wide_aside, "SOHIT_WIDE_ASIDE", 1, "the 32-bit score-only aligner of a round's wide tasks on a second stream beside the packed one")                 \
     X(B, align_sort, "SOHIT_ALIGN_SORT", 1, "launch lists ordered by band rows")                                                                               \
     X(B, trace_sort, "SOHIT_TRACE_SORT", 1, "trace pass lists ordered by band rows on mixed-length batches")                                                   \
+    X(I, trace_wave_rows, "SOHIT_TRACE_WAVE_ROWS", 1024, "traceback: bands of this many rows and more are walked by a wave of their own (0: never)")         \
+    X(I, trace_wave_max, "SOHIT_TRACE_WAVE_MAX", 32768, "... among the first this many positions of a launch list")                                            \
     X(I, spec, "SOHIT_SPEC", -1, "speculative traces in the first round: 0 off, 1 on, -1 from 2^21 tasks on")                                                  \
     X(D, spec_slack, "SOHIT_SPEC_SLACK", 1e3, "... the guess tests the ungapped score against expect x this")                                                  \
     X(I, spec_cap, "SOHIT_SPEC_CAP", -1, "tests: most speculative traces kept (-1: all)")                                                                      \
