@@ -880,8 +880,27 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
         HIP_CHECK(hipMemcpyAsync(b.dev.d_off.p, b.h_off.data(), ((size_t)b.nq + 1) * sizeof(u32), hipMemcpyHostToDevice, c->st));
         if (c->filter) {
             c->d_segmask.ensure(nres_b + 64);
+            // a class-ordered batch keeps its long queries at the end: the instances for them start there, and the one for the queries
+            // above 4096 residues (one wave per query: 0.4 ms for a 30 000-residue giant) runs on the side stream beside the others
+            u32 q_mid = 0, q_long = 0;
+            bool ordered = true;
+            for (u32 i = 1; i < b.nq && ordered; ++i) ordered = b.qcls[i] >= b.qcls[i - 1];
+            if (ordered && tune().qclass) {
+                while (q_mid < b.nq && b.qcls[q_mid] < 2) ++q_mid;      // classes 0, 1: below 1024 residues
+                q_long = q_mid;
+                while (q_long < b.nq && b.qcls[q_long] < 4) ++q_long;   // class 4: 4096 and more
+            }
+            const bool seg_aside = b.maxqlen > 4096 && tune().seg_aside;
+            if (seg_aside) {
+                HIP_CHECK(hipEventRecord(c->ev_side_go, c->st));   // (the batch's offsets are on their way)
+                HIP_CHECK(hipStreamWaitEvent(c->st_side, c->ev_side_go, 0));
+            }
             launch_seg(c->qry.d_res.p, c->qry.d_off.p, (u32)q_lo, d_qid, b.nq, b.dev.d_off.p, c->d_symmap.p, c->d_upmap.p, c->d_segtab.p,
-                       c->d_segmask.p, b.dev.d_res.p, b.maxqlen, c->st);
+                       c->d_segmask.p, b.dev.d_res.p, b.maxqlen, q_mid, q_long, c->st, seg_aside ? c->st_side : c->st);
+            if (seg_aside) {
+                HIP_CHECK(hipEventRecord(c->ev_ug_done, c->st_side));
+                HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_ug_done, 0));
+            }
         } else if (b.permuted) {
             launch_gather_seqs(c->qry.d_res.p, c->qry.d_off.p, (u32)q_lo, d_qid, b.nq, b.dev.d_off.p, b.dev.d_res.p, c->st);
         } else {
@@ -1819,7 +1838,18 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             b.gx.ensure((size_t)Ntot + 4), b.gL.ensure((size_t)Ntot + 4), b.gR.ensure((size_t)Ntot + 4);
             gx = b.gx.p, gL = b.gL.p, gR = b.gR.p;
         }
-        launch_csort(b.fin_rec.p, b.qcoff.p, nq, vmax, b.dev.d_off.p, c->ref.d_off.p, b.perm.p, b.ntask.p, b.ntile.p, gx, gL, gR, c->st);
+        // (the lists too long for the LDS instances are sorted in global scratch, a wave each: beside the LDS instances, on the side stream)
+        const bool cs_aside = gx && tune().csort_aside;
+        if (cs_aside) {
+            HIP_CHECK(hipEventRecord(c->ev_ug_go, c->st));
+            HIP_CHECK(hipStreamWaitEvent(c->st_side, c->ev_ug_go, 0));
+        }
+        launch_csort(b.fin_rec.p, b.qcoff.p, nq, vmax, b.dev.d_off.p, c->ref.d_off.p, b.perm.p, b.ntask.p, b.ntile.p, gx, gL, gR, c->st,
+                     cs_aside ? c->st_side : c->st);
+        if (cs_aside) {
+            HIP_CHECK(hipEventRecord(c->ev_ug_done, c->st_side));
+            HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_ug_done, 0));
+        }
     }
     const u32* dNRk = scan_u32(b.ntask.p, b.roffc.p, (size_t)nq + 1, false, c->d_scan_tmp.p, c->st);
     stash_u32(c, dNRk, 0);

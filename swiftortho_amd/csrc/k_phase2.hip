@@ -546,13 +546,13 @@ void launch_add_u32(u32* acc, const u32* x, u32 n, hipStream_t st) {
 }
 
 void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, const u32* qoff, const u32* roff, u32* perm, u32* ntask,
-                  u32* ntile, u64* gx, u32* gL, u32* gR, hipStream_t st) {
+                  u32* ntile, u64* gx, u32* gL, u32* gR, hipStream_t st, hipStream_t st_g /*k_csort's (may equal st)*/) {
     if (!nq) return;
+    if (gx) hipLaunchKernelGGL(k_csort, dim3(nq), dim3(64), 0, st_g, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile, gx, gL, gR);
     hipLaunchKernelGGL((k_csort_lds<512, 0>), dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile);
     hipLaunchKernelGGL((k_csort_lds<1024, 512>), dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile);
     hipLaunchKernelGGL((k_csort_lds<2048, 1024>), dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile);
     hipLaunchKernelGGL((k_csort_lds<LDS_SORT_MAX, 2048>), dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile);
-    if (gx) hipLaunchKernelGGL(k_csort, dim3(nq), dim3(64), 0, st, rec, qcoff, nq, vmax, qoff, roff, perm, ntask, ntile, gx, gL, gR);
 }
 
 int csort_lds_max() { return LDS_SORT_MAX; }

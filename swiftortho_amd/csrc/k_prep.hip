@@ -143,7 +143,7 @@ template <int CAP, int TILE>
 __global__ __launch_bounds__(64) void k_seg(const u8* __restrict__ raw, const u32* __restrict__ src_off, u32 q_lo, const u32* __restrict__ qid, u32 nq,
                                             const u32* __restrict__ dst_off, const u8* __restrict__ symmap /*256: upper-cased byte*/,
                                             const u8* __restrict__ upmap /*256*/, const SegTab* __restrict__ tab, u8* __restrict__ mk,
-                                            u8* __restrict__ out, int min_len /*this instance serves lengths > min_len*/) {
+                                            u8* __restrict__ out, int min_len /*this instance serves lengths > min_len*/, u32 q_first /*first slot of the grid*/) {
     constexpr bool STAGE = CAP > 0;
     constexpr int SEG_TILE = TILE;
     __shared__ u8 s_sym[256], s_up[256];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void k_seg(const u8* __restrict__ raw, const u3
     __shared__ double s_t1[SEG_TILE], s_t2[SEG_TILE];
     __shared__ u8 s_S[STAGE ? CAP : 4], s_m[STAGE ? CAP : 4];
     const int lane = threadIdx.x;
-    const u32 q = blockIdx.x;
+    const u32 q = q_first + blockIdx.x;
     if (q >= nq) return;
     const u32 sq = q_lo + (qid ? qid[q] : q);   // the batch may hold its queries in another order than the file
     const int n = (int)(src_off[sq + 1] - src_off[sq]);
@@ -286,18 +286,28 @@ __global__ __launch_bounds__(256) void k_copy_range(const u8* __restrict__ src, 
     if (i < n) dst[i] = src[i];
 }
 
+#define SEG_STAGE_GIANT 32768  // ... and up to this length in an instance of one wave per CU (72 KB of LDS): a 30 000-residue query's replay and walk
+                               // out of global memory took 1.3 ms (0.3 of it the additions themselves)
+
+// q_mid / q_long: the slots in front of them hold no query above SEG_STAGE_SMALL / SEG_STAGE_MAX residues (a class-ordered batch keeps
+// its long queries at the end: the two long instances are launched over the tail only; 0: anywhere).  st_long (may equal st): the
+// stream of the instance for the queries above SEG_STAGE_MAX -- one wave per query, milliseconds for a giant, beside the other two.
 void launch_seg(const u8* raw, const u32* src_off, u32 q_lo, const u32* qid, u32 nq, const u32* dst_off, const u8* symmap, const u8* upmap,
-                const void* tab, u8* mk, u8* out, u32 max_len, hipStream_t st) {
+                const void* tab, u8* mk, u8* out, u32 max_len, u32 q_mid, u32 q_long, hipStream_t st, hipStream_t st_long) {
     if (!nq) return;
-    // three instances over the same grid, each serving its length range: (0, 1024], (1024, 4096] staged in LDS, longer ones unstaged
+    // instances over the same slots, each serving its length range: (0, 1024], (1024, 4096], (4096, 32768] staged in LDS, longer ones unstaged
+    if (max_len > SEG_STAGE_MAX && q_long < nq) {
+        hipLaunchKernelGGL((k_seg<SEG_STAGE_GIANT, 512>), dim3(nq - q_long), dim3(64), 0, st_long, raw, src_off, q_lo, qid, nq, dst_off, symmap, upmap,
+                           (const SegTab*)tab, mk, out, SEG_STAGE_MAX, q_long);
+        if (max_len > SEG_STAGE_GIANT)
+            hipLaunchKernelGGL((k_seg<0, 512>), dim3(nq - q_long), dim3(64), 0, st_long, raw, src_off, q_lo, qid, nq, dst_off, symmap, upmap,
+                               (const SegTab*)tab, mk, out, SEG_STAGE_GIANT, q_long);
+    }
     hipLaunchKernelGGL((k_seg<SEG_STAGE_SMALL, 128>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, qid, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk,
-                       out, 0);
-    if (max_len > SEG_STAGE_SMALL)
-        hipLaunchKernelGGL((k_seg<SEG_STAGE_MAX, 512>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, qid, nq, dst_off, symmap, upmap, (const SegTab*)tab,
-                           mk, out, SEG_STAGE_SMALL);
-    if (max_len > SEG_STAGE_MAX)
-        hipLaunchKernelGGL((k_seg<0, 512>), dim3(nq), dim3(64), 0, st, raw, src_off, q_lo, qid, nq, dst_off, symmap, upmap, (const SegTab*)tab, mk, out,
-                           SEG_STAGE_MAX);
+                       out, 0, 0u);
+    if (max_len > SEG_STAGE_SMALL && q_mid < nq)
+        hipLaunchKernelGGL((k_seg<SEG_STAGE_MAX, 512>), dim3(nq - q_mid), dim3(64), 0, st, raw, src_off, q_lo, qid, nq, dst_off, symmap, upmap,
+                           (const SegTab*)tab, mk, out, SEG_STAGE_SMALL, q_mid);
 }
 
 // unmasked queries of a batch that holds them in another order than the file: a wave per sequence

@@ -42,7 +42,7 @@ void launch_scls(const u8* res, size_t n, const u8* smap, u8* scls, u8* scls4 /*
 void launch_seq_bound(const u8* scls, const u32* off, u32 nseq, const signed char* b62c_host, u32* bound, hipStream_t st);
 // batch slot q holds sequence q_lo + (qid ? qid[q] : q) of the source set
 void launch_seg(const u8* raw, const u32* src_off, u32 q_lo, const u32* qid, u32 nq, const u32* dst_off, const u8* symmap, const u8* upmap,
-                const void* tab /*SegTab on the device*/, u8* mk, u8* out, u32 max_len, hipStream_t st);
+                const void* tab, u8* mk, u8* out, u32 max_len, u32 q_mid, u32 q_long, hipStream_t st, hipStream_t st_long);
 void launch_gather_seqs(const u8* raw, const u32* src_off, u32 q_lo, const u32* qid, u32 nq, const u32* dst_off, u8* out, hipStream_t st);
 void launch_copy_range(const u8* src, u8* dst, size_t n, hipStream_t st);
 
@@ -157,7 +157,7 @@ void launch_gather_cands(const u32* src_q, const u32* src_rec, u32 n, const u32*
 void launch_add_u32(u32* acc, const u32* x, u32 n, hipStream_t st);
 void launch_csort(const u32* rec, const u32* qcoff, u32 nq, u32 vmax, const u32* qoff, const u32* roff, u32* perm, u32* ntask,
                   u32* ntile, u64* gx /*scratch, only for queries with > csort_lds_max() candidates; may be null*/, u32* gL, u32* gR,
-                  hipStream_t st);
+                  hipStream_t st, hipStream_t st_g);
 int csort_lds_max();
 void launch_mktasks(const u32* rec, const u32* qcoff, const u32* perm, const u32* ntask, const u32* roffc, const u32* toff, u32 nq,
                     const u32* qoff, const u32* roff, AlnTask* tasks, u32* rk_slot, hipStream_t st);

@@ -28,6 +28,7 @@
     X(B, lk_wide, "SOHIT_LK_WIDE", 0, "8-byte index addends whatever the field widths")                                                                        \
     X(B, qclass, "SOHIT_QCLASS", 1, "queries of a batch in length-class order (0: file order)")                                                                \
     X(B, pass_merge, "SOHIT_PASS_MERGE", 1, "neighbouring length classes that take the sorted path anyway share one pass")                                     \
+    X(B, seg_aside, "SOHIT_SEG_ASIDE", 1, "SEG masking of queries above 4096 residues on the side stream beside the shorter ones")                              \
     X(B, ksc_async, "SOHIT_KSC_ASYNC", 1, "k-mer order of queries above 4096 windows on a side stream")                                                        \
     X(I, segsort, "SOHIT_SEGSORT", 1, "sorted path: segmented sort of the keys inside each query (0: device-wide sort)")                                        \
     X(I, lk_variant, "SOHIT_LK_VARIANT", 0, "ABLATION (1, 2: lookup timing only, results invalid): variants of k_lookup")                                      \
@@ -45,6 +46,7 @@
     X(I, cand_limit, "SOHIT_CAND_LIMIT", 0, "tests: candidate-store size at which a batch is split (0: 2^32 - 16)")                                            \
     /* ---- phase 2 ---- */                                                                                                                                     \
     X(B, align_pk, "SOHIT_ALIGN_PK", 1, "packed 16-bit score-only aligner where the scores fit")                                                               \
+    X(B, csort_aside, "SOHIT_CSORT_ASIDE", 1, "candidate lists above 4096 entries sorted (k_csort) on the side stream beside the LDS instances")               \
     X(B, wide_aside, "SOHIT_WIDE_ASIDE", 1, "the 32-bit score-only aligner of a round's wide tasks on a second stream beside the packed one")                 \
     X(B, align_sort, "SOHIT_ALIGN_SORT", 1, "launch lists ordered by band rows")                                                                               \
     X(B, trace_sort, "SOHIT_TRACE_SORT", 1, "trace pass lists ordered by band rows on mixed-length batches")                                                   \
