@@ -1873,6 +1873,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     const u32 maxwin_q = std::min<u32>(b.maxqlen, LONG_SEQ), maxwin_s = std::min<u32>(c->ref.maxlen, LONG_SEQ);
     const bool pk_on = tune().align_pk && align_pk_supported(c->st);
     const bool pk_mixed = pk_on && (int)std::min(maxwin_q, maxwin_s) > align_pk_max_len();
+    const bool traced_pk = pk_on && tune().align_pk_trace;   // traced alignments by the packed kernel too (SOHIT_ALIGN_PK_TRACE=0: k_align<true>)
     auto sort_by_rows = [&](const u32* list, u32 n, u32* n_wide) -> const u32* {
         const bool split = n_wide && pk_mixed;
         if (n_wide) *n_wide = pk_on ? 0u : n;
@@ -1964,17 +1965,19 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             launch_round_idx_spec(b.tcnt.p, b.spcnt.p, b.roff.p, b.spoff.p, b.toff.p, b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.st_state.p, nq,
                                   b.ridx.p, b.sidx.p, c->st);
             if (NS) {
-                const u32* slist = sort_by_rows(b.sidx.p, NS, nullptr);
+                u32 nw_s = 0;   // (leading tasks of the ordered list whose scores need 32-bit cells)
+                const u32* slist = sort_by_rows(b.sidx.p, NS, traced_pk ? &nw_s : nullptr);
+                if (!traced_pk) nw_s = NS;
                 const size_t tw = trace_offsets(slist, NS);
                 ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
                 if (tw <= var_budget_words) {
                     b.spec_trace.ensure(tw + 64);
                     launch_align_traced(b.tasks.p, slist, NS, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_scls4.p,
-                                        c->ref.d_off.p, c->d_b62c.p, b.spec_trace.p, TU, b.tr_ofs.p, b.ares.p, b.tpos.p, 0u, c->st);
+                                        c->ref.d_off.p, c->d_b62c.p, b.spec_trace.p, TU, b.tr_ofs.p, b.ares.p, b.tpos.p, 0u, c->st, nw_s);
                     nspec = NS;
                 } else {   // the traces would not fit after all: these tasks score-only, like the rest of the round
                     launch_align(b.tasks.p, slist, NS, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
-                                 c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, nullptr, b.ares.p, false, c->st);
+                                 c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, nullptr, b.ares.p, false, c->st, 0u);
                 }
                 pt.stop();
             }
@@ -1999,7 +2002,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             }
             if (n_wide)
                 launch_align(b.tasks.p, rlist, n_wide, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
-                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, nullptr, b.ares.p, false, wst);
+                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, nullptr, b.ares.p, false, wst, 0u);
             if (wide_aside) HIP_CHECK(hipEventRecord(c->ev_ug_done, c->st_side));
             if (NR > n_wide)
                 launch_align_pk(b.tasks.p, rlist + n_wide, NR - n_wide, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_scls4.p,
@@ -2098,24 +2101,33 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         // it saves -- config 3: 9.1 -> 9.9 ms -- hence the test).  The traces' offsets follow the ordered list.
         const bool order_rows = (b.permuted || (u64)b.maxqlen * b.nq > 3ull * b.h_off[b.nq] / 2) &&
                                 tune().trace_sort;
+        // tasks of emission range p's traced list that need the 32-bit cells (they lead the ordered range); a mixed batch whose lists are
+        // not ordered keeps the 32-bit kernel for all of them
+        u32 nwide_part[EMIT_PARTS_MAX] = {0};
         if (order_rows) {
-            auto order_list = [&](const u32* in, u32 t0, u32 t1, u32* out) {   // [t0, t1) of `in`, longest band first, to the same range of `out`
+            // [t0, t1) of `in`, longest band first, to the same range of `out`; split: the wide tasks first, returns their number
+            auto order_list = [&](const u32* in, u32 t0, u32 t1, u32* out, bool split) -> u32 {
                 const u32 n = t1 - t0;
-                if (!n) return;
+                if (!n) return 0u;
                 b.tmp64.ensure((size_t)n + 2), b.c_ft2.ensure((size_t)n + 2);
                 ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(n, 64));
-                launch_task_rows(b.tasks.p, in + t0, n, b.dev.d_off.p, c->ref.d_off.p, b.dev.d_bound.p, c->ref.d_bound.p, 0, 0u, nullptr, nullptr, b.tmp64.p, c->st);
-                sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, in + t0, out + t0, n, 13, c->st);
+                c->d_small.ensure(16);
+                if (split) HIP_CHECK(hipMemsetAsync(c->d_small.p + 12, 0, sizeof(u32), c->st));
+                launch_task_rows(b.tasks.p, in + t0, n, b.dev.d_off.p, c->ref.d_off.p, b.dev.d_bound.p, c->ref.d_bound.p, split ? align_pk_max_len() : 0,
+                                 split ? align_pk_max_score() : 0u, split ? c->d_small.p + 12 : nullptr, nullptr, b.tmp64.p, c->st);
+                sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, in + t0, out + t0, n, split ? 14 : 13, c->st);
+                return split ? d2h_u32(c, c->d_small.p + 12) : 0u;
             };
             b.tl_sorted.ensure((size_t)tn + 4);
             if (nspec) b.al_sorted.ensure((size_t)(NO - tn) + 4);
             for (int p = 0; p < parts; ++p) {
                 const u32 r0 = parts > 1 ? part_row[p] : 0u, r1 = parts > 1 ? part_row[p + 1] : NO;
+                const bool split = traced_pk && pk_mixed;
                 if (nspec) {
-                    order_list(tlist, pb[p], pb[p + 1], b.tl_sorted.p);
-                    order_list(alist, r0 - pb[p], r1 - pb[p + 1], b.al_sorted.p);
+                    nwide_part[p] = order_list(tlist, pb[p], pb[p + 1], b.tl_sorted.p, split);
+                    (void)order_list(alist, r0 - pb[p], r1 - pb[p + 1], b.al_sorted.p, false);
                 } else {
-                    order_list(tlist, r0, r1, b.tl_sorted.p);
+                    nwide_part[p] = order_list(tlist, r0, r1, b.tl_sorted.p, split);
                 }
             }
             tlist = b.tl_sorted.p;
@@ -2124,17 +2136,20 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         const size_t tw = tn ? trace_offsets(tlist, tn) : 0;
         const bool tvar = tw <= var_budget_words;
         b.trace.ensure(tvar ? tw + 64 : (size_t)std::min(slab, std::max<u32>(maxpart, 1)) * stride + 64);
-        auto align_traced = [&](u32 t0, u32 t1) {   // tasks [t0, t1) of tlist
+        auto align_traced = [&](u32 t0, u32 t1, int p) {   // tasks [t0, t1) of tlist = emission range p's
             if (t1 <= t0) return;
+            // the range's leading tasks that take the 32-bit kernel
+            const u32 nw = !traced_pk ? t1 - t0 : (order_rows ? std::min(nwide_part[p], t1 - t0) : (pk_mixed ? t1 - t0 : 0u));
             if (tvar) {
                 launch_align(b.tasks.p, tlist + t0, t1 - t0, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
-                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, TU, b.tr_ofs.p + t0, b.ares.p, true, c->st);
+                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, TU, b.tr_ofs.p + t0, b.ares.p, true, c->st, nw);
                 return;
             }
             for (u32 t = t0; t < t1; t += slab) {
                 const u32 n = std::min(slab, t1 - t);
                 launch_align(b.tasks.p, tlist + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
-                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, nullptr, b.ares.p, true, c->st);
+                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, nullptr, b.ares.p, true, c->st,
+                             std::min(n, nw > t - t0 ? nw - (t - t0) : 0u));
             }
         };
         for (int p = 0; p < parts; ++p) {
@@ -2143,13 +2158,13 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             if (r1 > r0 && nspec) {
                 const u32 b0 = pb[p], b1 = pb[p + 1], a0 = r0 - b0, a1 = r1 - b1;
                 ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
-                align_traced(b0, b1);
+                align_traced(b0, b1, p);
                 launch_traceback(b.tasks.p, alist + a0, a1 - a0, b.dev.d_res.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_off.p, b.spec_trace.p, TU,
                                  b.tpos.p, b.ares.p, c->st);
                 pt.stop();
             } else if (r1 > r0) {
                 ProfTimer pt(c, &c->cnt.align_ms, &c->cnt.align_launches);
-                align_traced(r0, r1);
+                align_traced(r0, r1, p);
                 pt.stop();
             }
             launch_emit_hits(b.tasks.p, b.ares.p, b.toff.p, b.sel.p, b.nout.p, b.ooff.p, b.bits.p, qa, qb, b.outrec.p, c->st);

@@ -304,6 +304,7 @@ __device__ __forceinline__ void traceback_one(const u32 tid, const AlnTask* __re
     // tpos: traces kept per task (speculative); tofs: per launch position, variable size; else one stride per launch position
     const u32* tr = trace + (size_t)(tpos ? tpos[slot] : tofs ? tofs[tid] : tid) * trace_stride;
     const int bi = r.qst, bj = r.qed;
+    const int tagged = r.pad & 1;   // traces written by k_align_pk<true>: 3 diagonal, 1 up (here: 1 diagonal, 3 up) -- swapped on reading
     if (WAVE) {
         const int t = threadIdx.x;
         int i = bi, j = bj, AL = 0, matches = 0, fm1 = 0, f0 = 0, f1 = 0;
@@ -316,6 +317,7 @@ __device__ __forceinline__ void traceback_one(const u32 tid, const AlnTask* __re
             if (inband && it > 0 && jt > 0) {
                 const int m = it + (d >> 1);
                 tcl = (int)((tr[((m >> 3) - 1) * 16 + (d >> 1)] >> (((7 - (m & 7)) << 2) + ((d & 1) << 1))) & 3u);
+                tcl ^= (tcl & tagged) << 1;
             }
             const int a0l = jt > 0 ? (int)craw[jt - 1] : (int)'-', a1l = it > 0 ? (int)rraw[it - 1] : (int)'-';
             int run = 0;
@@ -413,6 +415,7 @@ __device__ __forceinline__ void traceback_one(const u32 tid, const AlnTask* __re
                 const int key = ((m >> 3) - 1) * 16 + (d >> 1);
                 if (key != wkey) wv = key == nkey ? nv : tr[key], wkey = key;
                 tc = (int)((wv >> (((7 - (m & 7)) << 2) + ((d & 1) << 1))) & 3u);
+                tc ^= (tc & tagged) << 1;
             }
         }
         if (tc == 0) break;
@@ -487,18 +490,18 @@ static inline u32 traceback_waves(u32 ntasks) {
     return tune().trace_wave_rows > 0 ? (u32)std::min<long long>(ntasks, std::max<long long>(0, tune().trace_wave_max)) : 0u;
 }
 
-// with_traceback = false: scores only (trace may be null); true: traces + traceback statistics
+// with_traceback = false: scores only (trace may be null); true: traces + traceback statistics.  n_wide (with_traceback): the leading
+// list positions that need the 32-bit cells; the rest is aligned by the packed kernel (ntasks: all of them by the 32-bit one)
 void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u8* q_scls4, const u32* qoff,
                   const u8* r_res, const u8* r_scls, const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride,
-                  const u32* tofs, AlnRes* out, bool with_traceback, hipStream_t st) {
+                  const u32* tofs, AlnRes* out, bool with_traceback, hipStream_t st, u32 n_wide) {
     if (!ntasks) return;
     if (!with_traceback) {
         hipLaunchKernelGGL((k_align<false>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4,
                            roff, b62g, trace, trace_stride, (const u32*)nullptr, out, (u32*)nullptr, 0u);
         return;
     }
-    hipLaunchKernelGGL((k_align<true>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff,
-                       b62g, trace, trace_stride, tofs, out, (u32*)nullptr, 0u);
+    launch_align_traced(tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff, b62g, trace, trace_stride, tofs, out, nullptr, 0u, st, n_wide);
     const u32 nw = traceback_waves(ntasks);
     hipLaunchKernelGGL(k_traceback, dim3(nw + (ntasks + 63) / 64), dim3(64), 0, st, tasks, ridx, ntasks, q_res, qoff, r_res, roff, trace,
                        trace_stride, (const u32*)nullptr, tofs, out, nw, (int)tune().trace_wave_rows);
@@ -506,10 +509,14 @@ void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q
 
 void launch_align_traced(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
                          const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out,
-                         u32* tpos_out, u32 tpos_base, hipStream_t st) {
+                         u32* tpos_out, u32 tpos_base, hipStream_t st, u32 n_wide) {
     if (!ntasks) return;
-    hipLaunchKernelGGL((k_align<true>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff,
-                       b62g, trace, trace_stride, tofs, out, tpos_out, tpos_base);
+    n_wide = std::min(n_wide, ntasks);
+    if (n_wide)
+        hipLaunchKernelGGL((k_align<true>), dim3((n_wide + 15) / 16), dim3(256), 0, st, tasks, ridx, n_wide, q_scls, q_scls4, qoff, r_scls, r_scls4, roff,
+                           b62g, trace, trace_stride, tofs, out, tpos_out, tpos_base);
+    launch_align_pk_traced(tasks, ridx, n_wide, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff, b62g, trace, trace_stride, tofs, out, tpos_out,
+                           tpos_base, st);
 }
 
 void launch_traceback(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u32* qoff, const u8* r_res, const u32* roff,

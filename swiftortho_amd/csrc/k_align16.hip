@@ -117,10 +117,20 @@ __device__ __forceinline__ void pk_setup(PkSide& s, const AlnTask& tk, u32 slot,
 }
 
 #define PK_THREADS 1024   // two workgroups (2 x 51 KB of table) per CU = 8 waves per SIMD
-__global__ __launch_bounds__(PK_THREADS) void k_align_pk(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 ntasks,
+// TRACE = true (round 5): the same cells with their traces written and the position of the maximum kept, for the alignments that are
+// reported -- k_align<true>'s job at 10.5 instead of 15 vector instructions per cell.  A cell's trace IS its tag: the four iterations of a
+// group shift their (odd tag << 2 | even tag) nibbles into a register, both alignments at once, and every second group ends with one
+// store per alignment into the 32-bit kernel's own trace layout (word [(m >> 3) - 1][lane], iteration m in nibble 7 - (m & 7): a group is
+// the upper or the lower half of such a word).  The codes differ -- tag 3 diagonal, 1 up against trace 1 diagonal, 3 up -- so the
+// result says which it is (AlnRes.pad = 1) and k_traceback swaps the two when it reads them.  The maximum's position: four 32-bit keys
+// (alignment A / B x even / odd cell) of (value | 3) << 16 | (0xFFFF - iteration), two instructions per cell and alignment.
+template <bool TRACE>
+__global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_align_pk(const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx, u32 ntasks,
                                                   const u8* __restrict__ q_scls, const u8* __restrict__ q_scls4, const u32* __restrict__ qoff,
                                                   const u8* __restrict__ r_scls, const u8* __restrict__ r_scls4, const u32* __restrict__ roff,
-                                                  const signed char* __restrict__ b62g, AlnRes* __restrict__ out) {
+                                                  const signed char* __restrict__ b62g, AlnRes* __restrict__ out, u32* __restrict__ trace,
+                                                  u32 trace_stride, const u32* __restrict__ tofs, u32* __restrict__ tpos_out, u32 tpos_base,
+                                                  u32 t0 /*first list position of this launch: ridx, tofs and the traces are the whole list's*/) {
     __shared__ __attribute__((aligned(16))) unsigned char s_tab[PK_TAB];
     for (int i = threadIdx.x; i < 25 * 32 * 32; i += PK_THREADS) {
         const int a = i >> 10, b = (i >> 5) & 31;   // row class, column class; i & 31 = the lane's copy
@@ -131,8 +141,8 @@ __global__ __launch_bounds__(PK_THREADS) void k_align_pk(const AlnTask* __restri
     const u32 lane2 = (threadIdx.x & 31u) << 1;
     const u32 g = blockIdx.x * (PK_THREADS / 16) + (threadIdx.x >> 4);   // 16-lane row = task pair
     const int l = threadIdx.x & 15;
-    if (2u * g >= ntasks) return;
-    const u32 tA = 2u * g, tB = min(2u * g + 1u, ntasks - 1u);  // odd tail: the pair is (last, last), written once
+    if (t0 + 2u * g >= ntasks) return;
+    const u32 tA = t0 + 2u * g, tB = min(tA + 1u, ntasks - 1u);  // odd tail: the pair is (last, last), written once
     PkSide A, B;
     {
         const u32 sa = ridx ? ridx[tA] : tA, sb = ridx ? ridx[tB] : tB;
@@ -141,6 +151,17 @@ __global__ __launch_bounds__(PK_THREADS) void k_align_pk(const AlnTask* __restri
     }
     u32 W3e = PK_STOP | PK_TAG3, W3o = PK_STOP | PK_TAG3, Io_out = 0, Do_out = 0;  // results of iteration m - 1
     u32 key = PK_STOP;
+    // TRACE: (value | 3) << 16 | (0xFFFF - m) of the best even / odd cell of A and of B (first strict maximum in row-major order = the largest
+    // such key inside a lane: i = m - l); the group's trace nibbles; where the two alignments' traces live
+    u32 keyEA = 47u << 16, keyOA = keyEA, keyEB = keyEA, keyOB = keyEA, tw = 0, twh = 0;
+    u32 tuA = 0, tuB = 0;
+    u32 *trA = nullptr, *trB = nullptr;
+    if (TRACE) {
+        tuA = tofs ? tofs[tA] : tA, tuB = tofs ? tofs[tB] : tB;
+        trA = trace + (size_t)tuA * trace_stride + l;
+        trB = trace + (size_t)tuB * trace_stride + l;
+    }
+    const int mendA = A.R + 15, mendB = tB != tA ? B.R + 15 : -1;
     const int m_end = max(A.R, B.R) + 15;
     const int int_hi = min(min(A.R, A.ncols), min(B.R, B.ncols)) - 3;  // groups m0 in [17, int_hi]: every window byte of both sides is inside its sequence
 
@@ -193,7 +214,29 @@ __global__ __launch_bounds__(PK_THREADS) void k_align_pk(const AlnTask* __restri
             u32 we, Ie_out, De_out, wo;
             pk_cell(pk_dpp_shr1(Io_out), Do_out, W3e, S0[k], we, Ie_out, De_out, W3e);
             pk_cell(Ie_out, pk_dpp_shl1(De_out), W3o, S1[k], wo, Io_out, Do_out, W3o);
-            key = pk_max(key, pk_max(we, wo));
+            if (TRACE) {
+                const u32 rk = 0xFFFFu - (u32)(m0 + k);   // (wave-uniform)
+                keyEA = max(keyEA, __builtin_amdgcn_alignbit(W3e, rk << 16, 16)), keyOA = max(keyOA, __builtin_amdgcn_alignbit(W3o, rk << 16, 16));
+                keyEB = max(keyEB, (W3e & 0xFFFF0000u) | rk), keyOB = max(keyOB, (W3o & 0xFFFF0000u) | rk);
+                // (plain 32-bit shifts: a half holds exactly the four nibbles of a group and is cleared behind its store; the bits the
+                // shift by 2 carries across the halves fall outside the mask)
+                tw = (((wo << 2) & 0x000C000Cu) | (we & 0x00030003u)) | (tw << 4);
+            } else {
+                key = pk_max(key, pk_max(we, wo));
+            }
+        }
+        if (TRACE) {
+            // the group is the upper (m0 & 4 == 0) or the lower half of word [(m0 >> 3) - 1][l]: whole words are stored, by the lower half's
+            // group (an alignment that ends inside the upper half's group still gets its word: the lower half then holds cells nobody
+            // reads; the longer partner's last upper half is stored behind the loop)
+            if (!(m0 & 4)) {
+                twh = tw;
+            } else {
+                const u32 at = (u32)((m0 >> 3) - 1) * 16u;
+                if (m0 - 4 <= mendA) trA[at] = (twh << 16) | (tw & 0xFFFFu);
+                if (m0 - 4 <= mendB) trB[at] = (twh & 0xFFFF0000u) | (tw >> 16);
+            }
+            tw = 0;
         }
         A.rp += 4, A.cp += 4, B.rp += 4, B.cp += 4;
     };
@@ -210,8 +253,50 @@ __global__ __launch_bounds__(PK_THREADS) void k_align_pk(const AlnTask* __restri
         }
         four(m0, std::true_type{});
     }
+    if (TRACE) {   // a last group that is an upper half: left-aligned, as k_align<true> stores it
+        const int ml = 8 + ((m_end - 8) & ~3);
+        if (!(ml & 4)) {
+            const u32 at = (u32)((ml >> 3) - 1) * 16u;
+            if (ml <= mendA) trA[at] = twh << 16;
+            if (ml <= mendB) trB[at] = twh & 0xFFFF0000u;
+        }
+    }
     // reduce over the 16 lanes: maximum per half; cells per side
     int ncA = A.ncell, ncB = B.ncell;
+    if (TRACE) {
+        // lane best: max score, then smallest i, then the even cell (smaller j); over the lanes: max score, smallest i, smallest j
+        auto lane_best = [&](u32 kE, u32 kO, int& best, int& bi, int& bj) {
+            const int sE = ((int)(kE >> 16) - 47) >> 2, sO = ((int)(kO >> 16) - 47) >> 2;
+            const int iE = 0xFFFF - (int)(kE & 0xFFFFu) - l, iO = 0xFFFF - (int)(kO & 0xFFFFu) - l;
+            const bool takeO = (sO > sE) || (sO == sE && iO < iE);
+            best = takeO ? sO : sE, bi = takeO ? iO : iE;
+            bj = bi + 2 * l - KB + (takeO ? 1 : 0);
+            if (best == 0) bi = 0, bj = 0;  // nothing scored: (i_max, j_max) stay (0, 0) (1391)
+        };
+        int bA, iA, jA, bB, iB, jB;
+        lane_best(keyEA, keyOA, bA, iA, jA);
+        lane_best(keyEB, keyOB, bB, iB, jB);
+        for (int msk = 8; msk > 0; msk >>= 1) {
+            const int ob = __shfl_xor(bA, msk, 16), oi = __shfl_xor(iA, msk, 16), oj = __shfl_xor(jA, msk, 16);
+            if (ob > bA || (ob == bA && (oi < iA || (oi == iA && oj < jA)))) bA = ob, iA = oi, jA = oj;
+            const int pb = __shfl_xor(bB, msk, 16), pi = __shfl_xor(iB, msk, 16), pj = __shfl_xor(jB, msk, 16);
+            if (pb > bB || (pb == bB && (pi < iB || (pi == iB && pj < jB)))) bB = pb, iB = pi, jB = pj;
+            ncA += __shfl_xor(ncA, msk, 16);
+            ncB += __shfl_xor(ncB, msk, 16);
+        }
+        if (l != 0) return;
+        AlnRes r;
+        r.aln = 0, r.matches = 0, r.gap = 0, r.pad = 1 /*traces = tags*/, r.sst = 0, r.sed = 0;
+        r.maxscore = bA, r.qst = iA, r.qed = jA, r.cells = ncA;   // (i_max, j_max) parked for k_traceback
+        out[A.slot] = r;
+        if (tpos_out) tpos_out[A.slot] = tpos_base + tuA;
+        if (tB != tA) {
+            r.maxscore = bB, r.qst = iB, r.qed = jB, r.cells = ncB;
+            out[B.slot] = r;
+            if (tpos_out) tpos_out[B.slot] = tpos_base + tuB;
+        }
+        return;
+    }
     for (int msk = 8; msk > 0; msk >>= 1) {
         key = pk_max(key, (u32)__shfl_xor((int)key, msk, 16));
         ncA += __shfl_xor(ncA, msk, 16);
@@ -263,6 +348,17 @@ void launch_align_pk(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8
                      const u8* r_scls4, const u32* roff, const signed char* b62g, AlnRes* out, hipStream_t st) {
     if (!ntasks) return;
     const u32 pairs = (ntasks + 1) / 2;
-    hipLaunchKernelGGL(k_align_pk, dim3((pairs + PK_THREADS / 16 - 1) / (PK_THREADS / 16)), dim3(PK_THREADS), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff, b62g,
-                       out);
+    hipLaunchKernelGGL((k_align_pk<false>), dim3((pairs + PK_THREADS / 16 - 1) / (PK_THREADS / 16)), dim3(PK_THREADS), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff,
+                       r_scls, r_scls4, roff, b62g, out, (u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, 0u, 0u);
+}
+
+// with traces (the walk is k_traceback's), list positions [t0, t1) of a launch list: ridx, tofs (or the position itself) and the trace room
+// are the whole list's, as k_align<true> and k_traceback see them; tofs / tpos_out / tpos_base as for k_align<true>
+void launch_align_pk_traced(const AlnTask* tasks, const u32* ridx, u32 t0, u32 t1, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
+                            const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out,
+                            u32* tpos_out, u32 tpos_base, hipStream_t st) {
+    if (t1 <= t0) return;
+    const u32 pairs = (t1 - t0 + 1) / 2;
+    hipLaunchKernelGGL((k_align_pk<true>), dim3((pairs + PK_THREADS / 16 - 1) / (PK_THREADS / 16)), dim3(PK_THREADS), 0, st, tasks, ridx, t1, q_scls, q_scls4, qoff,
+                       r_scls, r_scls4, roff, b62g, out, trace, trace_stride, tofs, tpos_out, tpos_base, t0);
 }

@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void k_task_rows(const AlnTask* __restrict__ t
             for (int o = 32; o > 0; o >>= 1) wcells += (u32)__shfl_xor((int)wcells, o);
             if ((threadIdx.x & 63) == 0) {
                 atomicAdd(n_wide, (u32)__popcll(wb));
-                atomicAdd(cells_wide, (unsigned long long)wcells);
+                if (cells_wide) atomicAdd(cells_wide, (unsigned long long)wcells);
             }
         }
     }

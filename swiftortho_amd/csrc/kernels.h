@@ -139,7 +139,7 @@ u32 align_trace_stride(int max_rows);
 void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u8* q_scls4, const u32* qoff,
                   const u8* r_res, const u8* r_scls, const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride,
                   const u32* tofs /*traces: start of launch position t's trace in units of trace_stride words, or null = t*/, AlnRes* out,
-                  bool with_traceback, hipStream_t st);
+                  bool with_traceback, hipStream_t st, u32 n_wide /*with_traceback: leading positions for the 32-bit kernel, the rest packed*/);
 // trace room each task of a launch list needs, in units of align_trace_unit() words (+ a 0 behind the last): scanned, they are `tofs`
 u32 align_trace_unit();
 void launch_trace_units(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, u32* units /*n + 1*/, hipStream_t st);
@@ -218,7 +218,11 @@ void launch_trace_split(const u32* sel_idx, u32 n, const u32* flags, const u32* 
 // k_align.hip: the two halves of launch_align(..., true) on their own (speculative traces: the walk runs long after the alignment)
 void launch_align_traced(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
                          const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out,
-                         u32* tpos_out /*tofs: receives tpos_base + tofs[t]*/, u32 tpos_base, hipStream_t st);
+                         u32* tpos_out /*tofs: receives tpos_base + tofs[t]*/, u32 tpos_base, hipStream_t st, u32 n_wide);
+// k_align16.hip: list positions [t0, t1) by the packed kernel, traces in the same layout (codes = tags: AlnRes.pad = 1)
+void launch_align_pk_traced(const AlnTask* tasks, const u32* ridx, u32 t0, u32 t1, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
+                            const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out,
+                            u32* tpos_out, u32 tpos_base, hipStream_t st);
 void launch_traceback(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u32* qoff, const u8* r_res, const u32* roff,
                       const u32* trace, u32 trace_stride, const u32* tpos, AlnRes* out, hipStream_t st);
 void launch_stop_round_w(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* ntile, const u32* roffc,
