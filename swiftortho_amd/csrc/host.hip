@@ -119,7 +119,8 @@ struct SeqSet {
     std::vector<u8> res;         // concatenated residues (raw bytes)
     u32 maxlen = 0;
     // device
-    DevBuf<u8> d_res, d_scls_store, d_scls4_store;
+    DevBuf<u8> d_res, d_scls_store, d_scls4_store, d_pcls_store, d_pcls4_store;
+    struct { u8* p = nullptr; } d_pcls, d_pcls4;   // classes / classes * 4 with PCLS_PAD sentinels behind every sequence (k_align_pk)
     struct { u8* p = nullptr; } d_scls;   // score classes; 16 readable bytes in front (k_ungap's left-pass windows start up to 8 bytes early)
     struct { u8* p = nullptr; } d_scls4;  // score class * 4 (k_ungap's subject side: column offset in its LDS table), same padding
     DevBuf<u32> d_off, d_words, d_pseq;
@@ -422,6 +423,9 @@ void layout_set(so_ctx* c, SeqSet& s, const bool present[256], size_t nres, u32 
     s.d_scls4.p = s.d_scls4_store.p + SCLS_PAD_FRONT;
     HIP_CHECK(hipMemcpyAsync(c->d_hmap.p, hmap, 256, hipMemcpyHostToDevice, c->st));
     launch_scls(s.d_res.p, nres, c->d_smap.p, s.d_scls.p, s.d_scls4.p, c->st);
+    s.d_pcls_store.ensure(nres + (size_t)PCLS_PAD * (nseq + 2) + 64), s.d_pcls4_store.ensure(nres + (size_t)PCLS_PAD * (nseq + 2) + 64);
+    s.d_pcls.p = s.d_pcls_store.p + PCLS_PAD, s.d_pcls4.p = s.d_pcls4_store.p + PCLS_PAD;
+    launch_pad_cls(s.d_scls.p, s.d_off.p, nseq, s.d_pcls.p, s.d_pcls4.p, c->st);
     s.ug_valid = false;
     s.d_bound.ensure((size_t)nseq + 4);
     launch_seq_bound(s.d_scls.p, s.d_off.p, nseq, c->b62c, s.d_bound.p, c->st);
@@ -1873,6 +1877,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     const u32 maxwin_q = std::min<u32>(b.maxqlen, LONG_SEQ), maxwin_s = std::min<u32>(c->ref.maxlen, LONG_SEQ);
     const bool pk_on = tune().align_pk && align_pk_supported(c->st);
     const bool pk_mixed = pk_on && (int)std::min(maxwin_q, maxwin_s) > align_pk_max_len();
+    const PkCls pkc{b.dev.d_pcls.p, b.dev.d_pcls4.p, c->ref.d_pcls.p, c->ref.d_pcls4.p};
     const bool traced_pk = pk_on && tune().align_pk_trace;   // traced alignments by the packed kernel too (SOHIT_ALIGN_PK_TRACE=0: k_align<true>)
     auto sort_by_rows = [&](const u32* list, u32 n, u32* n_wide) -> const u32* {
         const bool split = n_wide && pk_mixed;
@@ -1973,7 +1978,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                 if (tw <= var_budget_words) {
                     b.spec_trace.ensure(tw + 64);
                     launch_align_traced(b.tasks.p, slist, NS, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_scls4.p,
-                                        c->ref.d_off.p, c->d_b62c.p, b.spec_trace.p, TU, b.tr_ofs.p, b.ares.p, b.tpos.p, 0u, c->st, nw_s);
+                                        c->ref.d_off.p, c->d_b62c.p, b.spec_trace.p, TU, b.tr_ofs.p, b.ares.p, b.tpos.p, 0u, c->st, nw_s, pkc);
                     nspec = NS;
                 } else {   // the traces would not fit after all: these tasks score-only, like the rest of the round
                     launch_align(b.tasks.p, slist, NS, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
@@ -2005,8 +2010,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                              c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, nullptr, b.ares.p, false, wst, 0u);
             if (wide_aside) HIP_CHECK(hipEventRecord(c->ev_ug_done, c->st_side));
             if (NR > n_wide)
-                launch_align_pk(b.tasks.p, rlist + n_wide, NR - n_wide, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_scls.p, c->ref.d_scls4.p,
-                                c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->st);
+                launch_align_pk(b.tasks.p, rlist + n_wide, NR - n_wide, pkc, b.dev.d_off.p, c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->st);
             if (wide_aside) HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_ug_done, 0));
             pt.stop();
             c->cnt.align_wide += n_wide;
@@ -2142,14 +2146,14 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
             const u32 nw = !traced_pk ? t1 - t0 : (order_rows ? std::min(nwide_part[p], t1 - t0) : (pk_mixed ? t1 - t0 : 0u));
             if (tvar) {
                 launch_align(b.tasks.p, tlist + t0, t1 - t0, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
-                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, TU, b.tr_ofs.p + t0, b.ares.p, true, c->st, nw);
+                             c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, TU, b.tr_ofs.p + t0, b.ares.p, true, c->st, nw, pkc);
                 return;
             }
             for (u32 t = t0; t < t1; t += slab) {
                 const u32 n = std::min(slab, t1 - t);
                 launch_align(b.tasks.p, tlist + t, n, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
                              c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, b.trace.p, stride, nullptr, b.ares.p, true, c->st,
-                             std::min(n, nw > t - t0 ? nw - (t - t0) : 0u));
+                             std::min(n, nw > t - t0 ? nw - (t - t0) : 0u), pkc);
             }
         };
         for (int p = 0; p < parts; ++p) {

@@ -494,14 +494,14 @@ static inline u32 traceback_waves(u32 ntasks) {
 // list positions that need the 32-bit cells; the rest is aligned by the packed kernel (ntasks: all of them by the 32-bit one)
 void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u8* q_scls4, const u32* qoff,
                   const u8* r_res, const u8* r_scls, const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride,
-                  const u32* tofs, AlnRes* out, bool with_traceback, hipStream_t st, u32 n_wide) {
+                  const u32* tofs, AlnRes* out, bool with_traceback, hipStream_t st, u32 n_wide, PkCls pk) {
     if (!ntasks) return;
     if (!with_traceback) {
         hipLaunchKernelGGL((k_align<false>), dim3((ntasks + 15) / 16), dim3(256), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4,
                            roff, b62g, trace, trace_stride, (const u32*)nullptr, out, (u32*)nullptr, 0u);
         return;
     }
-    launch_align_traced(tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff, b62g, trace, trace_stride, tofs, out, nullptr, 0u, st, n_wide);
+    launch_align_traced(tasks, ridx, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff, b62g, trace, trace_stride, tofs, out, nullptr, 0u, st, n_wide, pk);
     const u32 nw = traceback_waves(ntasks);
     hipLaunchKernelGGL(k_traceback, dim3(nw + (ntasks + 63) / 64), dim3(64), 0, st, tasks, ridx, ntasks, q_res, qoff, r_res, roff, trace,
                        trace_stride, (const u32*)nullptr, tofs, out, nw, (int)tune().trace_wave_rows);
@@ -509,14 +509,13 @@ void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q
 
 void launch_align_traced(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
                          const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out,
-                         u32* tpos_out, u32 tpos_base, hipStream_t st, u32 n_wide) {
+                         u32* tpos_out, u32 tpos_base, hipStream_t st, u32 n_wide, PkCls pk) {
     if (!ntasks) return;
-    n_wide = std::min(n_wide, ntasks);
+    n_wide = pk.q ? std::min(n_wide, ntasks) : ntasks;   // (no padded arrays given: everything by the 32-bit kernel)
     if (n_wide)
         hipLaunchKernelGGL((k_align<true>), dim3((n_wide + 15) / 16), dim3(256), 0, st, tasks, ridx, n_wide, q_scls, q_scls4, qoff, r_scls, r_scls4, roff,
                            b62g, trace, trace_stride, tofs, out, tpos_out, tpos_base);
-    launch_align_pk_traced(tasks, ridx, n_wide, ntasks, q_scls, q_scls4, qoff, r_scls, r_scls4, roff, b62g, trace, trace_stride, tofs, out, tpos_out,
-                           tpos_base, st);
+    launch_align_pk_traced(tasks, ridx, n_wide, ntasks, pk, qoff, roff, b62g, trace, trace_stride, tofs, out, tpos_out, tpos_base, st);
 }
 
 void launch_traceback(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u32* qoff, const u8* r_res, const u32* roff,

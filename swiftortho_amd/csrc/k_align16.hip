@@ -91,16 +91,20 @@ struct PkSide {                 // one of the two alignments of a 16-lane row
     const u8* rp;               // row classes of the current group's four iterations (this lane)
     const u8* cp;               // column classes * 4, one column early
     int nrows, ncols, R;
+    int int_hi;                 // last group start m0 that needs no window masks
     int ridx0, cidx0;           // index (into the sequence) of byte 0 of the two windows at m0 = 8
     u32 slot;
     int ncell;
 };
 
+// the class arrays are the PADDED ones (k_pad_cls): sequence s at off[s] + PCLS_PAD * s, PCLS_PAD sentinel bytes behind it
 __device__ __forceinline__ void pk_setup(PkSide& s, const AlnTask& tk, u32 slot, int l, const u8* __restrict__ q_scls,
                                          const u8* __restrict__ q_scls4, const u32* __restrict__ qoff, const u8* __restrict__ r_scls,
                                          const u8* __restrict__ r_scls4, const u32* __restrict__ roff) {
     const u32 qb = qoff[tk.q], sb = roff[tk.subj];
-    const int lq = min((int)(qoff[tk.q + 1] - qb), (int)tk.qe), ls = min((int)(roff[tk.subj + 1] - sb), (int)tk.se);
+    const int lenq = (int)(qoff[tk.q + 1] - qb), lens = (int)(roff[tk.subj + 1] - sb);
+    const int lq = min(lenq, (int)tk.qe), ls = min(lens, (int)tk.se);
+    q_scls += (size_t)PCLS_PAD * tk.q, q_scls4 += (size_t)PCLS_PAD * tk.q, r_scls += (size_t)PCLS_PAD * tk.subj, r_scls4 += (size_t)PCLS_PAD * tk.subj;
     const int qi = min((int)tk.qi, lq), qj = min((int)tk.qj, ls);
     const int la = lq - qi, lb = ls - qj;
     const bool swp = !(la < lb);  // abs(qed - qst) < abs(sed - sst) -> no swap (1364-1369)
@@ -108,6 +112,10 @@ __device__ __forceinline__ void pk_setup(PkSide& s, const AlnTask& tk, u32 slot,
     const u8* ccls = swp ? (r_scls4 + sb + qj) : (q_scls4 + qb + qi);
     const u8* rcls = swp ? (q_scls + qb + qi) : (r_scls + sb + qj);
     s.R = min(s.nrows, s.ncols + KB);
+    // Both windows end where their sequences end (no tile of a long sequence): what lies behind them are the arrays' sentinels, PCLS_PAD
+    // bytes of them -- rows are read up to R + 18, columns up to ncols + 37 -- so the groups up to the alignment's last need no masks.
+    // Else (and for every group in front of m0 = 17): the masked path.
+    s.int_hi = ((int)tk.qe >= lenq && (int)tk.se >= lens) ? s.R + 15 : min(s.R, s.ncols) - 3;
     s.ridx0 = 8 - l - 1, s.cidx0 = 8 + l - KB - 1;
     s.rp = rcls + s.ridx0, s.cp = ccls + s.cidx0;
     s.slot = slot;
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     }
     const int mendA = A.R + 15, mendB = tB != tA ? B.R + 15 : -1;
     const int m_end = max(A.R, B.R) + 15;
-    const int int_hi = min(min(A.R, A.ncols), min(B.R, B.ncols)) - 3;  // groups m0 in [17, int_hi]: every window byte of both sides is inside its sequence
+    const int int_hi = min(A.int_hi, B.int_hi);  // groups m0 in [17, int_hi]: every window byte of both sides is inside its sequence or a sentinel behind it
 
     auto four = [&](int m0, auto edge) {
         constexpr bool EDGE = decltype(edge)::value;
@@ -344,21 +352,20 @@ int align_pk_max_len() { return 740; }
 // ... or whose score bound does: (score << 2) + 47 + 44 <= 32767
 u32 align_pk_max_score() { return 8169; }
 
-void launch_align_pk(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
-                     const u8* r_scls4, const u32* roff, const signed char* b62g, AlnRes* out, hipStream_t st) {
+void launch_align_pk(const AlnTask* tasks, const u32* ridx, u32 ntasks, PkCls pk, const u32* qoff, const u32* roff, const signed char* b62g, AlnRes* out,
+                     hipStream_t st) {
     if (!ntasks) return;
     const u32 pairs = (ntasks + 1) / 2;
-    hipLaunchKernelGGL((k_align_pk<false>), dim3((pairs + PK_THREADS / 16 - 1) / (PK_THREADS / 16)), dim3(PK_THREADS), 0, st, tasks, ridx, ntasks, q_scls, q_scls4, qoff,
-                       r_scls, r_scls4, roff, b62g, out, (u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, 0u, 0u);
+    hipLaunchKernelGGL((k_align_pk<false>), dim3((pairs + PK_THREADS / 16 - 1) / (PK_THREADS / 16)), dim3(PK_THREADS), 0, st, tasks, ridx, ntasks, pk.q, pk.q4, qoff,
+                       pk.r, pk.r4, roff, b62g, out, (u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, 0u, 0u);
 }
 
 // with traces (the walk is k_traceback's), list positions [t0, t1) of a launch list: ridx, tofs (or the position itself) and the trace room
 // are the whole list's, as k_align<true> and k_traceback see them; tofs / tpos_out / tpos_base as for k_align<true>
-void launch_align_pk_traced(const AlnTask* tasks, const u32* ridx, u32 t0, u32 t1, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
-                            const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out,
-                            u32* tpos_out, u32 tpos_base, hipStream_t st) {
+void launch_align_pk_traced(const AlnTask* tasks, const u32* ridx, u32 t0, u32 t1, PkCls pk, const u32* qoff, const u32* roff, const signed char* b62g,
+                            u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out, u32* tpos_out, u32 tpos_base, hipStream_t st) {
     if (t1 <= t0) return;
     const u32 pairs = (t1 - t0 + 1) / 2;
-    hipLaunchKernelGGL((k_align_pk<true>), dim3((pairs + PK_THREADS / 16 - 1) / (PK_THREADS / 16)), dim3(PK_THREADS), 0, st, tasks, ridx, t1, q_scls, q_scls4, qoff,
-                       r_scls, r_scls4, roff, b62g, out, trace, trace_stride, tofs, tpos_out, tpos_base, t0);
+    hipLaunchKernelGGL((k_align_pk<true>), dim3((pairs + PK_THREADS / 16 - 1) / (PK_THREADS / 16)), dim3(PK_THREADS), 0, st, tasks, ridx, t1, pk.q, pk.q4, qoff,
+                       pk.r, pk.r4, roff, b62g, out, trace, trace_stride, tofs, tpos_out, tpos_base, t0);
 }

@@ -84,6 +84,28 @@ __global__ __launch_bounds__(256) void k_scls(const u8* __restrict__ res, size_t
     }
 }
 
+// ---- class arrays with SENTINELS behind every sequence (the packed aligner's, k_align16.hip) ------------------------------------
+// Sequence s's classes at off[s] + PCLS_PAD * s, followed by PCLS_PAD bytes of the sentinel class (24; * 4 in the column array); the
+// two arrays point PCLS_PAD bytes into their allocations (sentinels in front of sequence 0 too).  A band that runs off the END of a
+// sequence then reads sentinels where the plain arrays hold the next sequence: the aligner's last groups need no window masks.
+__global__ __launch_bounds__(256) void k_pad_cls(const u8* __restrict__ scls, const u32* __restrict__ off, u32 nseq, u8* __restrict__ out,
+                                                 u8* __restrict__ out4) {
+    const u32 s = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (s == 0 && lane < PCLS_PAD) out[(ptrdiff_t)lane - PCLS_PAD] = 24, out4[(ptrdiff_t)lane - PCLS_PAD] = 96;
+    if (s >= nseq) return;
+    const u32 a = off[s], e = off[s + 1];
+    u8* o = out + a + (size_t)PCLS_PAD * s;
+    u8* o4 = out4 + a + (size_t)PCLS_PAD * s;
+    for (u32 i = lane; i < e - a; i += 64) {
+        const u8 c = scls[a + i];
+        o[i] = c, o4[i] = (u8)(c << 2);
+    }
+    if (lane < PCLS_PAD) o[e - a + lane] = 24, o4[e - a + lane] = 96;
+}
+void launch_pad_cls(const u8* scls, const u32* off, u32 nseq, u8* out, u8* out4, hipStream_t st) {
+    hipLaunchKernelGGL(k_pad_cls, dim3(std::max(1u, (nseq + 3) / 4)), dim3(256), 0, st, scls, off, nseq, out, out4);
+}
+
 // ---- upper bound of any local alignment score a sequence can take part in -------------------------------------
 // Every column of an alignment scores at most the row maximum of its residue's class (gaps and mismatches only lower the sum),
 // so  sum over the sequence of max(0, max_b b62[class][b])  bounds the score of every alignment the sequence is one side of.

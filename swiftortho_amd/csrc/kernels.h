@@ -35,6 +35,12 @@ void launch_layout(const u8* res, const u32* off, u32 nseq, u32 P, u32 Ppad, con
                    hipStream_t st);
 // score classes of n residues; scls / scls4 point SCLS_PAD_FRONT bytes into allocations of n + SCLS_PAD_FRONT + SCLS_PAD_BACK
 // bytes, and the pads are zeroed here
+#define PCLS_PAD 48   // sentinel bytes behind every sequence of the packed aligner's class arrays (k_pad_cls)
+struct PkCls {   // the four padded class arrays of a (query batch, reference) pair
+    const u8 *q, *q4, *r, *r4;
+};
+void launch_pad_cls(const u8* scls, const u32* off, u32 nseq, u8* out /*PCLS_PAD bytes into an allocation of nres + PCLS_PAD * (nseq + 2) + 64*/, u8* out4,
+                    hipStream_t st);
 #define SCLS_PAD_FRONT 16
 #define SCLS_PAD_BACK 64
 void launch_scls(const u8* res, size_t n, const u8* smap, u8* scls, u8* scls4 /*nullable: class * 4*/, hipStream_t st);
@@ -139,7 +145,8 @@ u32 align_trace_stride(int max_rows);
 void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u8* q_scls4, const u32* qoff,
                   const u8* r_res, const u8* r_scls, const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride,
                   const u32* tofs /*traces: start of launch position t's trace in units of trace_stride words, or null = t*/, AlnRes* out,
-                  bool with_traceback, hipStream_t st, u32 n_wide /*with_traceback: leading positions for the 32-bit kernel, the rest packed*/);
+                  bool with_traceback, hipStream_t st, u32 n_wide /*with_traceback: leading positions for the 32-bit kernel, the rest packed*/,
+                  PkCls pk = PkCls{nullptr, nullptr, nullptr, nullptr});
 // trace room each task of a launch list needs, in units of align_trace_unit() words (+ a 0 behind the last): scanned, they are `tofs`
 u32 align_trace_unit();
 void launch_trace_units(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, u32* units /*n + 1*/, hipStream_t st);
@@ -148,8 +155,8 @@ void launch_trace_units(const AlnTask* tasks, const u32* ridx, u32 n, const u32*
 bool align_pk_supported(hipStream_t st);   // the d16 load behaviour k_align_pk relies on (probed once per process)
 int align_pk_max_len();   // largest min(rows, columns) it can score whatever the residues
 u32 align_pk_max_score(); // largest alignment score its cells hold
-void launch_align_pk(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
-                     const u8* r_scls4, const u32* roff, const signed char* b62g, AlnRes* out, hipStream_t st);
+void launch_align_pk(const AlnTask* tasks, const u32* ridx, u32 ntasks, PkCls pk, const u32* qoff, const u32* roff, const signed char* b62g, AlnRes* out,
+                     hipStream_t st);
 
 // k_phase2.hip
 void launch_gather_cands(const u32* src_q, const u32* src_rec, u32 n, const u32* cqoff, const u32* prior, const u32* qcoff,
@@ -218,11 +225,10 @@ void launch_trace_split(const u32* sel_idx, u32 n, const u32* flags, const u32* 
 // k_align.hip: the two halves of launch_align(..., true) on their own (speculative traces: the walk runs long after the alignment)
 void launch_align_traced(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
                          const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out,
-                         u32* tpos_out /*tofs: receives tpos_base + tofs[t]*/, u32 tpos_base, hipStream_t st, u32 n_wide);
+                         u32* tpos_out /*tofs: receives tpos_base + tofs[t]*/, u32 tpos_base, hipStream_t st, u32 n_wide, PkCls pk);
 // k_align16.hip: list positions [t0, t1) by the packed kernel, traces in the same layout (codes = tags: AlnRes.pad = 1)
-void launch_align_pk_traced(const AlnTask* tasks, const u32* ridx, u32 t0, u32 t1, const u8* q_scls, const u8* q_scls4, const u32* qoff, const u8* r_scls,
-                            const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out,
-                            u32* tpos_out, u32 tpos_base, hipStream_t st);
+void launch_align_pk_traced(const AlnTask* tasks, const u32* ridx, u32 t0, u32 t1, PkCls pk, const u32* qoff, const u32* roff, const signed char* b62g,
+                            u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out, u32* tpos_out, u32 tpos_base, hipStream_t st);
 void launch_traceback(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u32* qoff, const u8* r_res, const u32* roff,
                       const u32* trace, u32 trace_stride, const u32* tpos, AlnRes* out, hipStream_t st);
 void launch_stop_round_w(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* ntile, const u32* roffc,
