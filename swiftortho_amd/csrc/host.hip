@@ -275,6 +275,7 @@ struct so_ctx {
     std::vector<std::string> masked;     // indexed by qidx - masked_lo
     i64 masked_lo = 0;
     std::vector<std::vector<u32>> last_cands;  // per query of last search: 4 x u32 per cand
+    u64 qry_gen = 0;                           // bumped by every query load: what a batch's cached slot layout is good for
     i64 last_q_lo = 0;
     so_counters cnt;
     // scratch
@@ -794,6 +795,12 @@ struct Batch {
     // reach the host.  One class only (the usual protein set below 1024 residues): qid is the identity and `permuted` is false.
     std::vector<u32> qid;
     std::vector<u8> qcls;    // length class per slot (query_class)
+    // The slot layout (qid, qcls, h_off, maxqlen and their device copies d_qid, dev.d_off) is a function of the loaded queries and the
+    // range alone: a second search over the same range finds it made (0.5-1 ms of host loops and two pageable uploads in front of the
+    // batch's first kernel, with the GPU idle).
+    u64 lay_gen = 0;
+    i64 lay_lo = -1, lay_hi = -1;
+    bool lay_classes = false;
     bool permuted = false;
     // slots [q_defer, nq): the length class whose longest members' k-mer order is still being computed on the side stream; their
     // frequency cap (and everything after it) waits for ev_korder, the classes before them do not
@@ -848,11 +855,14 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
     b.korder_async = false;
     b.q_lo = q_lo, b.q_hi = q_hi, b.nq = (u32)(q_hi - q_lo);
     const SeqSet& Q = c->qry;
+    const bool classes_on = tune().qclass;   // SOHIT_QCLASS=0: file order
+    const bool lay_cached = b.lay_gen == c->qry_gen && b.lay_lo == q_lo && b.lay_hi == q_hi && b.lay_classes == classes_on && (c->seg_on_device || !c->filter);
+    if (!lay_cached) {
+    b.lay_lo = -1;
     b.h_off.assign((size_t)b.nq + 1, 0);
     b.maxqlen = 0;
     b.qid.resize(b.nq), b.qcls.resize(b.nq);
     {
-        const bool classes_on = tune().qclass;   // SOHIT_QCLASS=0: file order
         u32 cnt[QCLASSES] = {0}, at[QCLASSES] = {0};
         for (u32 i = 0; i < b.nq; ++i) cnt[classes_on ? query_class(Q.len(q_lo + i)) : 0]++;
         for (int k = 1; k < QCLASSES; ++k) at[k] = at[k - 1] + cnt[k - 1];
@@ -869,10 +879,11 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
         b.h_off[i + 1] = b.h_off[i] + ln;
         b.maxqlen = std::max(b.maxqlen, ln);
     }
+    }
     const u32* d_qid = nullptr;
     if (b.permuted) {
         b.d_qid.ensure((size_t)b.nq + 4);
-        HIP_CHECK(hipMemcpyAsync(b.d_qid.p, b.qid.data(), (size_t)b.nq * sizeof(u32), hipMemcpyHostToDevice, c->st));
+        if (!lay_cached) HIP_CHECK(hipMemcpyAsync(b.d_qid.p, b.qid.data(), (size_t)b.nq * sizeof(u32), hipMemcpyHostToDevice, c->st));
         d_qid = b.d_qid.p;
     }
     const size_t nres_b = b.h_off[b.nq];
@@ -881,7 +892,8 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
         // residues never leave the device: SEG kernel (or plain copy) from the resident raw queries
         b.dev.d_res.ensure(nres_b + 64);
         b.dev.d_off.ensure((size_t)b.nq + 1);
-        HIP_CHECK(hipMemcpyAsync(b.dev.d_off.p, b.h_off.data(), ((size_t)b.nq + 1) * sizeof(u32), hipMemcpyHostToDevice, c->st));
+        if (!lay_cached) HIP_CHECK(hipMemcpyAsync(b.dev.d_off.p, b.h_off.data(), ((size_t)b.nq + 1) * sizeof(u32), hipMemcpyHostToDevice, c->st));
+        b.lay_gen = c->qry_gen, b.lay_lo = q_lo, b.lay_hi = q_hi, b.lay_classes = classes_on;
         if (c->filter) {
             c->d_segmask.ensure(nres_b + 64);
             // a class-ordered batch keeps its long queries at the end: the instances for them start there, and the one for the queries
@@ -2312,7 +2324,8 @@ void search_loaded(so_ctx* c, i64 q_lo, i64 q_hi, HitBuf& out) {
     i64 ed = std::min<i64>(q_hi < 0 ? D : q_hi, N);          // 2981 (uses D when -u < 0)
     if (ed < st) ed = st;
     c->last_q_lo = st;
-    c->last_cands.assign((size_t)(ed - st), std::vector<u32>());
+    if (tune().keep_cands) c->last_cands.assign((size_t)(ed - st), std::vector<u32>());   // (tests: so_query_candidates)
+    else c->last_cands.clear();
     c->masked.clear();
     const int nchunks = (int)c->chunks.size();
     if (tune().batch > 0) c->max_batch = (u32)tune().batch;
@@ -2530,6 +2543,7 @@ bool read_file(const char* path, std::string& out) {
 // queries: parse, make the raw residues resident, and prepare the device SEG symbol folding
 void load_queries_common(so_ctx* c, bool parsed = false) {
     SeqSet& Q = c->qry;
+    ++c->qry_gen;
     if (!parsed) Q.parse();
     const size_t nres = Q.res.size();
     Q.d_res.ensure(nres + 64);
