@@ -12,6 +12,7 @@
 #include "../../include/sohit.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -289,6 +290,7 @@ struct so_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t st_rows = nullptr;  // result rows leave on their own stream: the download of one batch overlaps the next batch's kernels
     hipEvent_t ev_rows = nullptr, ev_rows_done = nullptr;
+    hipEvent_t ev_part[8] = {nullptr};   // emission range p's rows have arrived (the worker converts a range while the next is traced)
     // the k-mer order of queries too long for the LDS sort (one wave each, milliseconds for a 30 000-residue protein) runs beside the
     // batch's other preparation and the seed passes of the shorter length classes
     hipStream_t st_side = nullptr;
@@ -2065,6 +2067,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     if (NO) {
         // second aligner pass, with traces + traceback, over the rows that are reported (a few percent of the alignments)
         const int parts = (c->dev_out || NO < emit_min_rows) ? 1 : EMIT_PARTS;
+        u32 part_lo[EMIT_PARTS_MAX] = {0}, part_hi[EMIT_PARTS_MAX] = {0};   // rows of emission range p (what ev_part[p] stands for)
         b.sel_idx.ensure((size_t)NO + 4);
         launch_selected_idx(b.toff.p, b.sel.p, b.nout.p, b.ooff.p, nq, b.sel_idx.p, c->st);
         u32 maxpart = NO;
@@ -2190,7 +2193,9 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                 HIP_CHECK(hipStreamWaitEvent(c->st_rows, c->ev_rows, 0));
                 HIP_CHECK(hipMemcpyAsync((char*)c->pinned + (size_t)r0 * sizeof(HostRow), b.outrec.p + 12 * (size_t)r0, (size_t)(r1 - r0) * sizeof(HostRow),
                                          hipMemcpyDeviceToHost, c->st_rows));
+                HIP_CHECK(hipEventRecord(c->ev_part[p], c->st_rows));
             }
+            part_lo[p] = r0, part_hi[p] = r1;
         }
         sc.lap("phase2.trace_pass");
         {   // SOHIT_TEST_OOM_PHASE2=1 (tests): the first multi-query batch of the process fails here, as a device allocation of the
@@ -2267,11 +2272,16 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         c->emit.base = base, c->emit.n = NO;
         c->emit.dropped.store(0);
         c->emit.active = true;
-        c->emit.th = std::thread([c, rows, dst, NO, D, expect, q_lo, p2p, place] {
+        // The worker converts range p's rows as soon as they have arrived, while the GPU traces range p + 1: behind the last copy only
+        // the last range is left (it used to wait for ALL rows: ~1.3 ms of a config-3 step with the GPU idle).  Its threads are started
+        // once and walk the ranges together.
+        struct PartSpan { u32 lo, hi; };
+        std::array<PartSpan, EMIT_PARTS_MAX> spans{};
+        for (int p = 0; p < parts; ++p) spans[(size_t)p] = {part_lo[p], part_hi[p]};
+        c->emit.th = std::thread([c, rows, dst, NO, D, expect, q_lo, p2p, place, spans, parts] {
             try {
                 HIP_CHECK(hipSetDevice(c->device));
-                HIP_CHECK(hipEventSynchronize(c->ev_rows_done));  // the rows have arrived in the pinned buffer
-                parallel_for((i64)NO, [&](i64 i) {
+                auto convert = [&](i64 i) {
                     const int* v = rows[i].v;
                     so_hit h;
                     i64 di = i;
@@ -2294,7 +2304,35 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                     h.evalue = (double)(D * (i64)h.qlen * (i64)h.slen) * pw;
                     if (!(h.evalue <= expect)) c->emit.dropped.fetch_add(1);
                     dst[di] = h;
-                });
+                };
+                const unsigned nt = NO < 200000 ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+                std::array<std::atomic<i64>, EMIT_PARTS_MAX> next;
+                for (auto& n : next) n.store(0);
+                std::exception_ptr werr;
+                std::mutex wmu;
+                auto worker = [&] {
+                    try {
+                        HIP_CHECK(hipSetDevice(c->device));
+                        for (int p = 0; p < parts; ++p) {
+                            const i64 lo = spans[(size_t)p].lo, n = (i64)spans[(size_t)p].hi - lo;
+                            if (n <= 0) continue;
+                            HIP_CHECK(hipEventSynchronize(c->ev_part[p]));   // the range's rows have arrived in the pinned buffer
+                            for (;;) {
+                                const i64 b0 = next[(size_t)p].fetch_add(4096);
+                                if (b0 >= n) break;
+                                for (i64 i = b0; i < std::min(n, b0 + 4096); ++i) convert(lo + i);
+                            }
+                        }
+                    } catch (...) {
+                        std::lock_guard<std::mutex> g(wmu);
+                        werr = std::current_exception();
+                    }
+                };
+                std::vector<std::thread> th;
+                for (unsigned t = 1; t < nt; ++t) th.emplace_back(worker);
+                worker();
+                for (auto& t : th) t.join();
+                if (werr) std::rethrow_exception(werr);
             } catch (...) {
                 c->emit.err = std::current_exception();
             }
@@ -2668,6 +2706,7 @@ so_ctx* so_create(int device, const so_params* params) {
         HIP_CHECK(hipStreamCreateWithFlags(&c->st_rows, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_rows_done, hipEventDisableTiming));
+        for (auto& e : c->ev_part) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIP_CHECK(hipStreamCreateWithFlags(&c->st_side, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_side_go, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_korder, hipEventDisableTiming));
@@ -2697,6 +2736,8 @@ void so_destroy(so_ctx* c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
     if (c->ev_rows_done) (void)hipEventDestroy(c->ev_rows_done);
+    for (auto& e : c->ev_part)
+        if (e) (void)hipEventDestroy(e);
     if (c->st_rows) (void)hipStreamDestroy(c->st_rows);
     if (c->ev_side_go) (void)hipEventDestroy(c->ev_side_go);
     if (c->ev_korder) (void)hipEventDestroy(c->ev_korder);
