@@ -2056,9 +2056,14 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     launch_stride_gather(b.ooff.p, qstep, (nq + qstep - 1) / qstep, c->d_small.p + 4, c->st);   // d_small[4 + p] = first row of range p
     stash_u32(c, dNO, 0);
     u32 NO, part_row[EMIT_PARTS_MAX + 1];
+    std::vector<u32> h_ooff;   // (permuted batch, host rows: the slots' first rows, for the file-order placement below -- fetched with the totals)
     {
         u32* v = (u32*)small_host(c);
         HIP_CHECK(hipMemcpyAsync(v, c->d_small.p, 12 * sizeof(u32), hipMemcpyDeviceToHost, c->st));
+        if (b.permuted && !c->dev_out) {
+            h_ooff.resize((size_t)nq + 1);
+            HIP_CHECK(hipMemcpyAsync(h_ooff.data(), b.ooff.p, ((size_t)nq + 1) * sizeof(u32), hipMemcpyDeviceToHost, c->st));
+        }
         HIP_CHECK(hipStreamSynchronize(c->st));
         NO = v[0];
         for (int p = 0; p <= EMIT_PARTS; ++p) part_row[p] = (u64)p * qstep < nq ? v[4 + p] : NO;
@@ -2255,9 +2260,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         // slot s's rows, [ooff[s], ooff[s + 1]) of the download, start at row ostart[qid[s]] -- place[s] = {query, destination - source}.
         std::shared_ptr<std::vector<std::pair<u32, i64>>> place;
         if (b.permuted) {
-            std::vector<u32> ooff((size_t)nq + 1);
-            HIP_CHECK(hipMemcpyAsync(ooff.data(), b.ooff.p, ((size_t)nq + 1) * sizeof(u32), hipMemcpyDeviceToHost, c->st));
-            HIP_CHECK(hipStreamSynchronize(c->st));
+            const std::vector<u32>& ooff = h_ooff;
             std::vector<u32> ocnt((size_t)nq + 1, 0);
             for (u32 s = 0; s < nq; ++s) ocnt[b.qid[s]] = ooff[s + 1] - ooff[s];
             u32 run = 0;
