@@ -1580,6 +1580,51 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         // first-touch keys of the passing groups (k_ungap left the head hit's key / position in the third array)
         if (NP) launch_first_touch(ft_walk, b.keys2.p, H, klr, ft_bits_entry, bsp, c->ref.d_off.p + ch.seq_lo, const_cast<u64*>(q_ft), NP, c->st);
         if (NP == 0) break;
+        // Sparse pass (tens of records per query): best diagonal per subject and the candidate order by one wave per query, in LDS -- no
+        // sort of the records (k_q_best, k_group.hip).  A query with more records than the LDS instance holds sends the pass down the
+        // sorting path below (SOHIT_QBEST=0: always).
+        // (not for a pass that holds queries of 4096 residues and more: a giant brings more records than the largest instance sorts, and
+        // one such query sends the whole pass down the old path after the new one has run)
+        if (tune().qbest && pmaxq < 4096 && (kl.ba + kl.bp + ft_bits_entry) - bsp + 1 <= cand_order_lds_key_bits() && qb > qa) {
+            const u32 nqp = qb - qa;
+            BktLayout Lq{};
+            Lq.wb = 31, Lq.nqp = nqp, Lq.qa = qa, Lq.R = 1;   // one "bucket" per query: k_rec_count's returning atomic is the record's rank in it
+            b.bcnt.ensure((size_t)nqp + 2), b.bccnt.ensure((size_t)nqp + 2), b.pidx.ensure((size_t)NP + 2), b.pidx2.ensure((size_t)NP + 2);
+            b.order.ensure((size_t)NP + 2), b.order2.ensure((size_t)NP + 2), b.p_qs2.ensure((size_t)NP + 2), b.tmp64.ensure((size_t)NP + 2);
+            b.c_rec.ensure(4 * (size_t)NP + 8), b.bflag.ensure(4);
+            c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)nqp + 2) + 8);
+            HIP_CHECK(hipMemsetAsync(b.bcnt.p, 0, ((size_t)nqp + 2) * sizeof(u32), c->st));
+            launch_rec_count(q_qs, NP, klr.bs, Lq, b.bcnt.p, b.pidx.p, c->st);
+            scan_u32(b.bcnt.p, b.bcnt.p, (size_t)nqp + 1, false, c->d_scan_tmp.p, c->st);
+            launch_qrec_scatter(q_qs, q_sd, q_ft, b.pidx.p, NP, klr.bs, qa, b.bcnt.p, b.pidx2.p /*query*/, b.order.p /*subject*/, b.p_qs2.p /*score, distance*/,
+                                b.tmp64.p /*first-touch key*/, c->st);
+            HIP_CHECK(hipMemsetAsync(b.bflag.p, 0, sizeof(u32), c->st));
+            launch_q_best(b.bcnt.p, qa, nqp, b.order.p, b.p_qs2.p, b.tmp64.p, (u32)ch.seq_lo, bsp, b.c_rec.p, b.order2.p, qcnt, b.bflag.p, c->st);
+            HIP_CHECK(hipMemcpyAsync(b.bccnt.p, qcnt + qa, (size_t)nqp * sizeof(u32), hipMemcpyDeviceToDevice, c->st));
+            HIP_CHECK(hipMemsetAsync(b.bccnt.p + nqp, 0, 2 * sizeof(u32), c->st));
+            const u32* dT = scan_u32(b.bccnt.p, b.bccnt.p, (size_t)nqp + 1, false, c->d_scan_tmp.p, c->st);
+            stash_u32(c, dT, 0);
+            u32 flag = 0;
+            d2h_pair(c, b.bflag.p, NS, flag);
+            if (!flag) {
+                if (tune().debug) fprintf(stderr, "[sohit] seed pass: queries %u..%u hits %u seeds %u pass records %u candidates %u (per query)\n", qa, qb, H, K, NP, NS);
+                if (NS) {
+                    const u32 base = b.chunk_base.back();
+                    if ((u64)base + NS >= cand_limit()) throw CandOverflow();   // (SOHIT_CAND_LIMIT: tests lower the limit to exercise the split)
+                    b.cand_q.ensure((size_t)base + NS + 4, true, c->st);
+                    b.cand_rec.ensure(4 * ((size_t)base + NS) + 16, true, c->st);
+                    launch_q_emit(b.bcnt.p, qa, nqp, NP, b.pidx2.p, qcnt, b.bccnt.p, b.order2.p, b.c_rec.p, b.cand_q.p + base, b.cand_rec.p + 4 * (size_t)base, c->st);
+                    b.chunk_base.back() = base + NS;
+                    c->cnt.candidates += NS;
+                }
+                sc.lap("group.best_order");
+                c->cnt.seed_ms += (t1 - t0) * 1e3;
+                c->cnt.group_ms += (wall() - t1) * 1e3;
+                return;
+            }
+            // (a query above the LDS instance: k_q_best has written counts for the others -- the path below writes every query's again)
+            NS = 0;
+        }
         // best diagonal per (query, subject): sort pass records by (q, subject)
         b.pidx.ensure((size_t)NP + 2), b.pidx2.ensure((size_t)NP + 2), b.p_qs2.ensure((size_t)NP + 2);
         launch_iota(b.pidx.p, NP, c->st);

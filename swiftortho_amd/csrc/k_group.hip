@@ -711,6 +711,146 @@ __global__ __launch_bounds__(64) void k_cand_order_lds(const u64* __restrict__ c
     }
 }
 
+// ---- sparse path, round 5: best diagonal per subject AND candidate order of a pass, per query, in LDS --------------------------
+// The pass records of a sparse pass (tens per query) used to be sorted device-wide by (query, subject) -- a 7-launch library radix sort of
+// all records --, flagged, scanned, reduced (k_best) and then ordered per query (k_cand_order_lds).  Here the records are counted per query
+// (k_rec_count with one bucket per query: the returning atomic is the record's rank), scattered to their query's segment
+// (k_qrec_scatter), and ONE wave per query does the rest: a bitonic sort of (subject, position) words, a reduction per run of equal
+// subjects -- best = max score, ties to the smaller first-touch key; order key = the run's smallest first-touch key (k_best's rules) --
+// and a second bitonic sort of the candidates by (first-touch word, position in subject order) (k_cand_order_lds's word).  The
+// candidates' records go to a scratch at the segment's start, their order to `perm`; k_q_emit copies them to the dense candidate store
+// once the per-query counts are scanned.
+__global__ __launch_bounds__(256) void k_qrec_scatter(const u64* __restrict__ p_qs, const u64* __restrict__ p_sd, const u64* __restrict__ p_ft,
+                                                      const u32* __restrict__ rnk, u32 n, int bs, u32 qa, const u32* __restrict__ qoff,
+                                                      u32* __restrict__ o_q, u32* __restrict__ o_subj, u64* __restrict__ o_sd, u64* __restrict__ o_ft) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const u64 qs = p_qs[i];
+    if (qs == UG_REC_NONE) return;
+    const u32 q = (u32)(qs >> bs), s = qoff[q - qa] + rnk[i];
+    o_q[s] = q, o_subj[s] = (u32)qs & ((1u << bs) - 1u), o_sd[s] = p_sd[i], o_ft[s] = p_ft[i];
+}
+
+#define QB_LB 11   // position bits of the two sort words (segments of up to 2048 records)
+template <int P>
+__device__ __forceinline__ void qb_bitonic(u64* s_key, u32 Pn, u32 lane) {   // ascending, Pn a power of two <= P, one wave
+    for (u32 k = 2; k <= Pn; k <<= 1)
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 t = lane; t < (Pn >> 1); t += 64) {
+                const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const u64 x = s_key[i], y = s_key[l];
+                if ((x > y) == ((i & k) == 0)) s_key[i] = y, s_key[l] = x;
+            }
+            __syncthreads();
+        }
+}
+
+// CAP: records of a query this instance holds; it serves the queries with lo_n < n <= CAP (the largest instance flags longer ones:
+// the host then takes the sorting path for the pass)
+template <int CAP>
+__global__ __launch_bounds__(64) void k_q_best(const u32* __restrict__ qoff, u32 qa, const u32* __restrict__ o_subj, const u64* __restrict__ o_sd,
+                                               const u64* __restrict__ o_ft, u32 seq_lo, int bsp, u32 lo_n, bool last, u32* __restrict__ t_rec,
+                                               u32* __restrict__ perm, u32* __restrict__ qcnt, u32* __restrict__ fallback) {
+    __shared__ u64 s_key[CAP], s_key2[CAP];
+    const u32 qr = blockIdx.x, lane = threadIdx.x;
+    const u32 a = qoff[qr], n = qoff[qr + 1] - a;
+    if (n == 0 || n <= lo_n) return;
+    if (n > (u32)CAP) {
+        if (last && lane == 0) atomicOr(fallback, 1u);
+        return;
+    }
+    const u64 pm = (1ull << bsp) - 1ull;
+    auto ftword = [&](u64 ft) { return ((ft >> bsp) << 1) | ((ft & pm) == pm ? 1ull : 0ull); };
+    auto store_rec = [&](u32 at, u32 subj, u32 score, int dist) {   // [global subject id, ungapped score, qi, qj]
+        u32 qi, qj;
+        if (dist > 0) qi = 0, qj = (u32)dist;
+        else qi = (u32)(-dist), qj = 0;
+        *reinterpret_cast<uint4*>(t_rec + 4 * (size_t)at) = make_uint4(subj + seq_lo, score, qi, qj);
+    };
+    if (n == 1) {
+        if (lane == 0) {
+            const u64 sd = o_sd[a];
+            store_rec(a, o_subj[a], (u32)(sd >> 32), (int)(u32)sd);
+            perm[a] = 0;
+            qcnt[qa + qr] = 1;
+        }
+        return;
+    }
+    u32 P = 2;
+    while (P < n) P <<= 1;
+    for (u32 i = lane; i < P; i += 64) s_key[i] = i < n ? (((u64)o_subj[a + i] << QB_LB) | (u64)i) : ~0ull;
+    __syncthreads();
+    qb_bitonic<CAP>(s_key, P, lane);
+    // runs of equal subjects -> candidates, numbered in subject order
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    u32 nc = 0;
+    for (u32 c0 = 0; c0 < n; c0 += 64) {
+        const u32 i = c0 + lane;
+        bool head = false;
+        u32 subj = 0;
+        if (i < n) {
+            subj = (u32)(s_key[i] >> QB_LB);
+            head = i == 0 || (u32)(s_key[i - 1] >> QB_LB) != subj;
+        }
+        const unsigned long long hm = __ballot(head);
+        if (head) {
+            const u32 ci = nc + (u32)__popcll(hm & lt);
+            u64 minft = ~0ull, bft = ~0ull;
+            u32 bscore = 0;
+            int bdist = 0;
+            for (u32 j = i; j < n && (u32)(s_key[j] >> QB_LB) == subj; ++j) {
+                const u32 r = (u32)s_key[j] & ((1u << QB_LB) - 1u);
+                const u64 sd = o_sd[a + r], ft = o_ft[a + r];
+                const u32 sc = (u32)(sd >> 32);
+                minft = ft < minft ? ft : minft;
+                if (sc > bscore || (sc == bscore && ft < bft)) bscore = sc, bft = ft, bdist = (int)(u32)sd;
+            }
+            s_key2[ci] = (ftword(minft) << QB_LB) | (u64)ci;
+            store_rec(a + ci, subj, bscore, bdist);
+        }
+        nc += (u32)__popcll(hm);
+    }
+    u32 P2 = 2;
+    while (P2 < nc) P2 <<= 1;
+    __syncthreads();
+    for (u32 i = nc + lane; i < P2; i += 64) s_key2[i] = ~0ull;
+    __syncthreads();
+    if (nc > 1) qb_bitonic<CAP>(s_key2, P2, lane);
+    for (u32 k = lane; k < nc; k += 64) perm[a + k] = (u32)s_key2[k] & ((1u << QB_LB) - 1u);
+    if (lane == 0) qcnt[qa + qr] = nc;
+}
+
+// candidate k of query q (k < qcnt[q]) to the dense store: slot s = qoff[q - qa] + k of the scratch holds its rank-k candidate's
+// position in perm
+__global__ __launch_bounds__(256) void k_q_emit(const u32* __restrict__ qoff, u32 qa, u32 nqp, const u32* __restrict__ o_q, const u32* __restrict__ qcnt,
+                                                const u32* __restrict__ coff, const u32* __restrict__ perm, const u32* __restrict__ t_rec,
+                                                u32* __restrict__ out_q, u32* __restrict__ out_rec) {
+    const u32 s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= qoff[nqp]) return;
+    const u32 q = o_q[s], a = qoff[q - qa], k = s - a;
+    if (k >= qcnt[q]) return;
+    const u32 dst = coff[q - qa] + k;
+    out_q[dst] = q;
+    *reinterpret_cast<uint4*>(out_rec + 4 * (size_t)dst) = *reinterpret_cast<const uint4*>(t_rec + 4 * (size_t)(a + perm[s]));
+}
+
+int q_best_max() { return 2048; }
+void launch_qrec_scatter(const u64* p_qs, const u64* p_sd, const u64* p_ft, const u32* rnk, u32 n, int bs, u32 qa, const u32* qoff, u32* o_q, u32* o_subj,
+                         u64* o_sd, u64* o_ft, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_qrec_scatter, dim3((n + 255) / 256), dim3(256), 0, st, p_qs, p_sd, p_ft, rnk, n, bs, qa, qoff, o_q, o_subj, o_sd, o_ft);
+}
+void launch_q_best(const u32* qoff, u32 qa, u32 nqp, const u32* o_subj, const u64* o_sd, const u64* o_ft, u32 seq_lo, int bsp, u32* t_rec, u32* perm,
+                   u32* qcnt, u32* fallback, hipStream_t st) {
+    if (!nqp) return;
+    hipLaunchKernelGGL((k_q_best<128>), dim3(nqp), dim3(64), 0, st, qoff, qa, o_subj, o_sd, o_ft, seq_lo, bsp, 0u, false, t_rec, perm, qcnt, fallback);
+    hipLaunchKernelGGL((k_q_best<512>), dim3(nqp), dim3(64), 0, st, qoff, qa, o_subj, o_sd, o_ft, seq_lo, bsp, 128u, false, t_rec, perm, qcnt, fallback);
+    hipLaunchKernelGGL((k_q_best<2048>), dim3(nqp), dim3(64), 0, st, qoff, qa, o_subj, o_sd, o_ft, seq_lo, bsp, 512u, true, t_rec, perm, qcnt, fallback);
+}
+void launch_q_emit(const u32* qoff, u32 qa, u32 nqp, u32 nslots, const u32* o_q, const u32* qcnt, const u32* coff, const u32* perm, const u32* t_rec,
+                   u32* out_q, u32* out_rec, hipStream_t st) {
+    if (nslots) hipLaunchKernelGGL(k_q_emit, dim3((nslots + 255) / 256), dim3(256), 0, st, qoff, qa, nqp, o_q, qcnt, coff, perm, t_rec, out_q, out_rec);
+}
+
 int cand_order_lds_max() { return 2048; }
 int cand_order_lds_key_bits() { return 64 - 11; }  // widest first-touch word the packed sort word holds
 

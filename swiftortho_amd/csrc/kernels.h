@@ -130,6 +130,14 @@ int cand_order_lds_max();
 int cand_order_lds_key_bits();
 // (both over the pass's queries [q0, q1) of the batch)
 void launch_qseg(const u64* sorted_qs, u32 n, const u32* gidx, const u32* total, int bs, u32 q0, u32 q1, u32* seg, u32* maxseg, hipStream_t st);
+// k_group.hip: best diagonal + candidate order of a sparse pass per query in LDS (no sort of the pass records)
+int q_best_max();
+void launch_qrec_scatter(const u64* p_qs, const u64* p_sd, const u64* p_ft, const u32* rnk, u32 n, int bs, u32 qa, const u32* qoff, u32* o_q, u32* o_subj,
+                         u64* o_sd, u64* o_ft, hipStream_t st);
+void launch_q_best(const u32* qoff, u32 qa, u32 nqp, const u32* o_subj, const u64* o_sd, const u64* o_ft, u32 seq_lo, int bsp, u32* t_rec, u32* perm,
+                   u32* qcnt, u32* fallback, hipStream_t st);
+void launch_q_emit(const u32* qoff, u32 qa, u32 nqp, u32 nslots, const u32* o_q, const u32* qcnt, const u32* coff, const u32* perm, const u32* t_rec,
+                   u32* out_q, u32* out_rec, hipStream_t st);
 void launch_cand_order_lds(const u64* c_ft, const u32* c_rec, const u32* seg, u32 q0, u32 q1, u32 maxseg, int bsp, u32* out_q, u32* out_rec, u32* qcnt,
                            hipStream_t st);
 void launch_best(const u64* sorted_qs, const u32* idx, const u32* shead, u32 nseg, u32 n, const u64* p_sd, const u64* p_ft,

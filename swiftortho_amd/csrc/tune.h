@@ -39,6 +39,7 @@
     X(I, seg_cfg, "SOHIT_SEG_CFG", -1, "segmented key sort: kernel configuration (-1: by segment length)")                                                     \
     X(I, cseg_cfg, "SOHIT_CSEG_CFG", -1, "segmented candidate sort: kernel configuration")                                                                     \
     /* ---- candidate order ---- */                                                                                                                             \
+    X(B, qbest, "SOHIT_QBEST", 1, "sparse passes: best diagonal and candidate order per query in LDS (0: sort of the pass records, k_best, k_cand_order_lds)") \
     X(B, cand_order_lds, "SOHIT_CAND_ORDER_LDS", 1, "bucketed passes: candidate order by the hand-written per-query sort + gather (0: library segmented sort)")   \
     X(B, cand_keys, "SOHIT_CAND_KEYS", 1, "candidate order as a keys-only segmented sort (0: pairs)")                                                          \
     X(B, cand_segsort, "SOHIT_CAND_SEGSORT", 1, "candidate order sorted inside each query's segment (0: device-wide)")                                         \
