@@ -115,6 +115,13 @@ int so_load_ref(so_ctx *ctx, const char *fasta_path, int64_t r_lo, int64_t r_hi)
 int so_load_ref_mem(so_ctx *ctx, const char *fasta_bytes, int64_t nbytes, int64_t r_lo, int64_t r_hi);
 int so_build_index(so_ctx *ctx);
 int so_drop_index(so_ctx *ctx); /* forget the built chunk indexes (residues stay resident) */
+/* Replaces: Fasta.load (fsearch.py:2355-2444).  Reads the chunk indexes `<prefix>.<k>.idx / .soas / .bin`, k = 0, 1, ... (the files
+ * Fasta.write produces, fsearch.py:2298-2352; swiftortho_amd.fsearch.makedb writes the same bytes) and makes them resident in place
+ * of a built index: locus slots -> entries, start[] -> bucket directory, threshold from the .bin trailer.  As in the reference the
+ * files hold no sequences -- so_load_ref() the FASTA file first -- and the context must have been created with the trailer's -M, -s
+ * and -r (an error otherwise, as when sequence lengths and the .soas file disagree).  Searches then run from the loaded chunks until
+ * the next so_load_ref / so_drop_index. */
+int so_load_index(so_ctx *ctx, const char *prefix);
 
 /* Query side.  Replaces: Fasta(open(qry)) (fsearch.py:2971-2973).  Parses the FASTA and
  * makes the query residues resident in HBM. */

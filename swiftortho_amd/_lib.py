@@ -36,7 +36,7 @@ class SoCounters(C.Structure):
 
 
 # every symbol include/sohit.h declares
-EXPORTS = ["so_abi_version", "so_set_option", "so_create", "so_destroy", "so_last_error", "so_load_ref", "so_load_ref_mem", "so_build_index", "so_drop_index",
+EXPORTS = ["so_abi_version", "so_set_option", "so_create", "so_destroy", "so_last_error", "so_load_ref", "so_load_ref_mem", "so_build_index", "so_drop_index", "so_load_index",
            "so_load_queries", "so_load_queries_mem", "so_num_queries", "so_num_refs", "so_query_len", "so_search_loaded",
            "so_search", "so_free_hits", "so_write_sc", "so_format_hit", "so_get_counters", "so_reset_counters", "so_timing_report",
            "so_chunk_threshold", "so_chunk_entries", "so_chunk_download", "so_masked_query", "so_query_candidates", "so_set_profile",
@@ -95,6 +95,7 @@ def load():
     L.so_load_ref_mem.argtypes = [vp, cp, i64, i64, i64]
     L.so_build_index.argtypes = [vp]
     L.so_drop_index.argtypes = [vp]
+    L.so_load_index.argtypes = [vp, cp]
     L.so_load_queries.argtypes = [vp, cp]
     L.so_load_queries_mem.argtypes = [vp, cp, i64]
     for f in ("so_num_queries", "so_num_refs"):

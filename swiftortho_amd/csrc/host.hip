@@ -783,6 +783,186 @@ void build_index(so_ctx* c) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fasta.load (fsearch.py:2355-2444): chunk indexes read back from the reference's on-disk format -- `<prefix>.<k>.idx` (locus:
+// int32 per slot = soas[j] + pos, a bucket's members in the reference's slot order), `.soas` (prefix lengths of the chunk's
+// sequences), `.bin` (start[NC] + trailer `offset;offend;max weight;threshold;NC;seeds;alphabet` + its length in one byte) -- and
+// made resident in the layout build_index() produces.  Like the reference's load, the sequences come from the FASTA file (loaded
+// with so_load_ref), the threshold from the trailer.  The FILE's slot order is kept (so the slot the reference never reads,
+// fsearch.py:2277 / 2539, is the file's last one: no k_index_fixlast); an entry's tag (alphabet x pattern), which the file does not
+// hold and the consumers derive the visiting order from, is recovered by hashing the entry's window under every (alphabet, pattern)
+// and matching the bucket: equal (subject, position) members of one bucket were inserted in ascending tag order, i.e. stand in
+// descending tag order in the file.
+// ---------------------------------------------------------------------------------------------
+bool read_file(const char* path, std::string& out);
+
+// bucket of the window at `pos` of `seq` under (alphabet a, pattern s), fsearch.py:519-556; false = no window (too short, x / X inside)
+bool host_window_bucket(const so_ctx* c, const u8* seq, u32 len, u32 pos, int a, int s, u32* bucket) {
+    const int k = c->cfg.klen[s];
+    if ((u64)pos + (u64)k > (u64)len) return false;
+    const u32 care = c->cfg.care[s];
+    u32 n = 0x811c9dc5u;
+    for (int j = 0; j < k; ++j) {
+        const u8 ch = seq[pos + j];
+        if (ch == 'x' || ch == 'X') return false;
+        if ((care >> j) & 1u) n = (n ^ (u32)c->codes[a][ch]) * 0x01000193u;
+    }
+    n = (n ^ (u32)s) * 0x01000193u;
+    *bucket = n % (u32)c->nc;
+    return true;
+}
+
+void load_index(so_ctx* c, const char* prefix) {
+    if (!c->ref_loaded) throw SoError("so_load_index: no reference loaded (the index files hold no sequences: so_load_ref first)");
+    if (!prefix || !*prefix) throw SoError("so_load_index: empty prefix");
+    if (c->warm.joinable()) c->warm.join();
+    const double t0 = wall();
+    c->chunks.clear();
+    c->spare_chunks.clear();
+    c->index_built = false;
+    c->cnt.index_entries = 0;
+    const u32 NC = (u32)c->nc;
+    const int AS = c->cfg.A * c->cfg.S;
+    for (int k = 0;; ++k) {
+        const std::string name = std::string(prefix) + "." + std::to_string(k);
+        std::string bin, idx, soas_b;
+        if (!read_file((name + ".bin").c_str(), bin)) {
+            if (k == 0) throw SoError("so_load_index: cannot read " + name + ".bin");
+            break;
+        }
+        if (!read_file((name + ".idx").c_str(), idx)) throw SoError("so_load_index: cannot read " + name + ".idx");
+        if (!read_file((name + ".soas").c_str(), soas_b)) throw SoError("so_load_index: cannot read " + name + ".soas");
+        // trailer (fsearch.py:2380-2387): the last byte is its length
+        if (bin.empty()) throw SoError("so_load_index: " + name + ".bin is empty");
+        const size_t tl = (u8)bin.back();
+        if (bin.size() < tl + 1) throw SoError("so_load_index: " + name + ".bin has no parameter trailer");
+        const size_t tbeg = bin.size() - tl - 1;
+        auto f = split(bin.substr(tbeg, tl), ';');
+        if (f.size() != 7) throw SoError("so_load_index: " + name + ".bin: malformed parameter trailer");
+        i64 offset, nc_f, thr_f;
+        try {
+            offset = std::stoll(f[0]), thr_f = std::stoll(f[3]), nc_f = std::stoll(f[4]);
+        } catch (...) {
+            throw SoError("so_load_index: " + name + ".bin: malformed parameter trailer");
+        }
+        if (f[6] == "aa9") f[6] = "AST,CFILMVY,DN,EQ,G,H,KR,P,W";
+        if (f[6] == "aa20") f[6] = "A,S,T,C,F,I,L,M,V,Y,D,N,E,Q,G,H,K,R,P,W";
+        if (nc_f != (i64)NC || f[5] != c->seeds || f[6] != c->alphabet)
+            throw SoError("so_load_index: " + name + " was built with -M " + f[4] + " -s " + f[5] + " -r " + f[6] + ", the context with -M " +
+                          std::to_string(NC) + " -s " + c->seeds + " -r " + c->alphabet);
+        if (tbeg != (size_t)NC * 4) throw SoError("so_load_index: " + name + ".bin does not hold NC start values");
+        if (soas_b.size() < 4 || soas_b.size() % 4 || idx.size() % 4) throw SoError("so_load_index: " + name + ": truncated .soas / .idx");
+        const u32* start = reinterpret_cast<const u32*>(bin.data());
+        const u32* soas = reinterpret_cast<const u32*>(soas_b.data());
+        const u32* locus = reinterpret_cast<const u32*>(idx.data());
+        const i64 M = (i64)(soas_b.size() / 4) - 1;
+        const u64 E64 = idx.size() / 4;
+        if (E64 >= (1ull << 29)) throw SoError("chunk index exceeds 2^29 entries (the lookup kernel addresses 8-byte slots with 32-bit byte offsets)");
+        const u32 E = (u32)E64;
+        offset = std::max<i64>(offset, 0);   // build_msav writes `start` unclamped (-1 = from the first sequence)
+        if (offset + M > c->ref.N || soas[0] != 0) throw SoError("so_load_index: " + name + " does not belong to the loaded reference (sequence range)");
+        for (i64 j = 0; j < M; ++j)
+            if (soas[j + 1] - soas[j] != c->ref.len(offset + j))
+                throw SoError("so_load_index: " + name + " does not belong to the loaded reference (sequence lengths)");
+        auto ch = std::make_unique<ChunkIndex>();
+        ch->seq_lo = offset, ch->seq_hi = offset + M;
+        ch->p_lo = c->ref.off[ch->seq_lo] + (u32)ch->seq_lo;
+        ch->p_hi = c->ref.off[ch->seq_hi] + (u32)ch->seq_hi;
+        ch->maxslen = 0;
+        for (i64 j = ch->seq_lo; j < ch->seq_hi; ++j) ch->maxslen = std::max(ch->maxslen, c->ref.len(j));
+        ch->use_dir = (u64)NC <= (tune().dir_max >= 0 ? (u64)tune().dir_max : (1ull << 28));
+        ch->E = E;
+        ch->threshold = thr_f;
+        // occupied buckets: start[b] = first slot of bucket b, bucket b ends where b + 1 begins (the last one at E)
+        std::vector<u32> ub, ubeg, ucnt;
+        u64 s2 = 0;
+        for (u32 b = 0; b < NC; ++b) {
+            const u64 st = start[b], ed = b + 1 < NC ? (u64)start[b + 1] : (u64)E;
+            if (ed < st || ed > E) throw SoError("so_load_index: " + name + ".bin: start values are not a prefix sum of the .idx slots");
+            if (ed > st) ub.push_back(b), ubeg.push_back((u32)st), ucnt.push_back((u32)(ed - st)), s2 += (ed - st) * (ed - st);
+        }
+        if (E && (ub.empty() || ubeg[0] != 0)) throw SoError("so_load_index: " + name + ".bin: slots in front of the first bucket");
+        const u32 U = (u32)ub.size();
+        ubeg.push_back(E);
+        ch->U = U, ch->s2 = s2;
+        // slots -> entries
+        std::vector<u64> ent((size_t)E);
+        std::atomic<bool> bad(false);
+        const u8* res = c->ref.res.data();
+        parallel_for((i64)E, [&](i64 i) {
+            const u32 x = locus[i];
+            const u32* p = std::upper_bound(soas, soas + M + 1, x);   // offset 0 of sequence j is soas[j] itself: largest j with soas[j] <= x
+            const i64 j = (p - soas) - 1;
+            if (j < 0 || j >= M || x - soas[j] >= (1u << 24)) {
+                bad = true;
+                return;
+            }
+            ent[(size_t)i] = ((u64)j << 32) | (u64)(x - soas[j]);
+        });
+        if (bad) throw SoError("so_load_index: " + name + ".idx: slot outside the chunk's sequences");
+        if (AS > 1) {
+            parallel_for((i64)U, [&](i64 kb) {
+                const u32 b = ub[(size_t)kb];
+                std::vector<u64> seen;   // (subject, pos) of the slots of this bucket so far
+                for (u32 i = ubeg[(size_t)kb]; i < ubeg[(size_t)kb + 1]; ++i) {
+                    const u64 e = ent[i];
+                    const i64 j = (i64)(e >> 32);
+                    const u32 pos = (u32)e;
+                    const u8* sq = res + c->ref.off[offset + j];
+                    const u32 ln = c->ref.len(offset + j);
+                    int tags[MAX_ALPHA * MAX_PATTERNS], nt = 0;
+                    for (int a = 0; a < c->cfg.A; ++a) {
+                        u32 bk[MAX_PATTERNS];
+                        bool ok[MAX_PATTERNS];
+                        for (int s = 0; s < c->cfg.S; ++s) {
+                            ok[s] = host_window_bucket(c, sq, ln, pos, a, s, &bk[s]);
+                            for (int s2i = 0; ok[s] && s2i < s; ++s2i)
+                                if (ok[s2i] && bk[s2i] == bk[s]) ok[s] = false;   // the reference's `visit`
+                            if (ok[s] && bk[s] == b) tags[nt++] = a * c->cfg.S + s;
+                        }
+                    }
+                    const int before = (int)std::count(seen.begin(), seen.end(), e);
+                    if (before >= nt) {
+                        bad = true;
+                        return;
+                    }
+                    seen.push_back(e);
+                    ent[i] = e | ((u64)tags[nt - 1 - before] << 24);
+                }
+            });
+            if (bad) throw SoError("so_load_index: " + name + ".idx does not match the loaded reference under these seeds (a slot's window does not hash to its bucket)");
+        }
+        ch->entries.ensure((size_t)E + 4);
+        ch->ub.ensure((size_t)U + 4), ch->ubeg.ensure((size_t)U + 4), ch->ucnt.ensure((size_t)U + 4);
+        if (E) HIP_CHECK(hipMemcpyAsync(ch->entries.p, ent.data(), (size_t)E * sizeof(u64), hipMemcpyHostToDevice, c->st));
+        if (U) {
+            HIP_CHECK(hipMemcpyAsync(ch->ub.p, ub.data(), (size_t)U * sizeof(u32), hipMemcpyHostToDevice, c->st));
+            HIP_CHECK(hipMemcpyAsync(ch->ucnt.p, ucnt.data(), (size_t)U * sizeof(u32), hipMemcpyHostToDevice, c->st));
+        }
+        HIP_CHECK(hipMemcpyAsync(ch->ubeg.p, ubeg.data(), ((size_t)U + 1) * sizeof(u32), hipMemcpyHostToDevice, c->st));
+        if (ch->use_dir) {
+            const size_t nd = (size_t)NC / 32 + 2;
+            ch->dir.ensure(nd);
+            HIP_CHECK(hipMemsetAsync(ch->dir.p, 0, nd * sizeof(u64), c->st));
+            if (U) launch_dir_build(ch->ub.p, U, ch->dir.p, c->st);
+        } else {
+            u32 cap = 1024;
+            int lg = 10;
+            while (cap < 2 * U) cap <<= 1, ++lg;
+            ch->hkey.ensure(cap), ch->hval.ensure(cap);
+            ch->hshift = 32 - lg, ch->hmask = cap - 1;
+            HIP_CHECK(hipMemsetAsync(ch->hkey.p, 0xFF, (size_t)cap * sizeof(u32), c->st));
+            if (U) launch_htab_insert(ch->ub.p, ch->ubeg.p, U, ch->hkey.p, ch->hval.p, ch->hshift, ch->hmask, c->st);
+        }
+        HIP_CHECK(hipStreamSynchronize(c->st));   // the host vectors must outlive the copies
+        c->cnt.index_entries += ch->E;
+        c->chunks.push_back(std::move(ch));
+    }
+    c->cnt.n_chunks = (i64)c->chunks.size();
+    c->index_built = true;
+    c->cnt.index_ms += (wall() - t0) * 1e3;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Search
 // ---------------------------------------------------------------------------------------------
 struct Batch {
@@ -2820,6 +3000,10 @@ int so_load_ref_mem(so_ctx* c, const char* bytes, int64_t n, int64_t r_lo, int64
 
 int so_build_index(so_ctx* c) {
     return guarded(c, [&] { build_index(c); });
+}
+
+int so_load_index(so_ctx* c, const char* prefix) {
+    return guarded(c, [&] { load_index(c, prefix); });
 }
 
 int so_drop_index(so_ctx* c) {

@@ -65,6 +65,11 @@ class Searcher:
     def drop_index(self):
         self._chk(self.L.so_drop_index(self.h))
 
+    def load_index(self, prefix):
+        """Fasta.load (fsearch.py:2355-2444): make the chunk indexes `<prefix>.<k>.idx/.soas/.bin` resident instead of building them
+        (the reference FASTA must be loaded: the files hold no sequences)."""
+        self._chk(self.L.so_load_index(self.h, os.fsencode(prefix)))
+
     # query side -------------------------------------------------------------------------------
     def load_queries(self, path):
         self._chk(self.L.so_load_queries(self.h, os.fsencode(path)))
@@ -314,6 +319,37 @@ def makedb(ref, space='11111111', nr=AA9, step=1, ht=-1, chk=500000, device=0):
     finally:
         s.close()
     return out
+
+
+def index_params(name):
+    """The parameter trailer of one chunk's `.bin` file as Fasta.load reads it (fsearch.py:2380-2387): the last byte is the length
+    of `offset;offend;max weight;threshold;NC;seeds;alphabet`."""
+    with open(name + '.bin', 'rb') as f:
+        f.seek(0, os.SEEK_END)
+        n = f.tell()
+        f.seek(n - 1)
+        m = f.read(1)[0]
+        start = max(n - m - 1, 0)
+        f.seek(start)
+        para = f.read(m).decode('latin-1')
+    offset, offend, mw, thr, nc, space, nr = para.split(';')
+    return dict(offset=int(offset), offend=int(offend), mw=int(mw), threshold=int(thr), NC=int(nc), space=space, nr=nr)
+
+
+def load(ref, name=None, device=0, **search_kw):
+    """Fasta.load (fsearch.py:2355-2444) for every chunk `makedb` wrote: a Searcher over `ref` whose index comes from the files
+    `<name>.<k>.idx/.soas/.bin` (name defaults to `ref`, as makedb names them), created with the seeds, alphabet and bucket count
+    of the files' own trailer; `search_kw` = the search-side parameters (v, expect, max_miss, thr, flt, step is irrelevant here)."""
+    name = name or ref
+    p = index_params('%s.0' % name)
+    s = Searcher(ssd=p['space'], nr=p['nr'], ht=p['NC'], device=device, **search_kw)
+    try:
+        s.load_ref(ref)
+        s.load_index(name)
+    except Exception:
+        s.close()
+        raise
+    return s
 
 
 def manual_print(out=None):

@@ -494,6 +494,104 @@ def test_makedb_writes_the_reference_index_files(fs, tmp_path):
         assert open(ref + suffix, "rb").read() == open(os.path.join(GOLD, "idx_toy" + suffix), "rb").read(), suffix
 
 
+def _bucket_members(s, k, NC):
+    start, ent = s.chunk_index(k)
+    bucket = np.repeat(np.arange(NC), np.diff(start.astype(np.int64)))
+    order = np.lexsort((ent, bucket))
+    return start, ent[order]
+
+
+def test_load_index_reads_the_reference_files(fs, oracle, tmp_path):
+    """Fasta.load (fsearch.py:2355-2444): the index files the REAL reference wrote (tests/golden/idx_toy.*: three chunks of 25 sequences,
+    two seed patterns, 5003 buckets, so buckets mix patterns and the tag of every slot has to be recovered) are made resident with
+    so_load_index and searched: the chunk indexes equal a freshly built one's member for member, and the rows equal the oracle's."""
+    import shutil
+    meta = json.load(open(os.path.join(GOLD, "idx_toy.json")))
+    a = meta["args"]
+    ref = str(tmp_path / "ref.fsa")
+    shutil.copyfile(os.path.join(GOLD, "idx_toy.ref.fsa"), ref)
+    for suffix in meta["files"]:
+        shutil.copyfile(os.path.join(GOLD, "idx_toy" + suffix), ref + suffix)
+    assert fs.index_params(ref + ".1")["NC"] == a["ht"] and fs.index_params(ref + ".1")["offset"] == 25
+    kw = dict(v=500, expect=1e-5, flt="T")
+    want_path = str(tmp_path / "o.sc")
+    oracle.blastp(ref, ref, want_path, ssd=a["space"], nr=a["nr"], expect=1e-5, v=500, step=a["step"], flt="T", ht=a["ht"], chk=a["chk"])
+    want = open(want_path, "rb").read()
+    assert want.count(b"\n") > 50
+    s = fs.load(ref, **kw)
+    s.load_queries(ref)
+    hits = s.search()
+    got = b"".join(hits.rows())
+    hits.close()
+    assert s.counters()["n_chunks"] == 3
+    fresh = fs.Searcher(ssd=a["space"], nr=a["nr"], ht=a["ht"], chk=a["chk"], step=a["step"], **kw)
+    fresh.load_ref(ref)
+    fresh.load_queries(ref)
+    h2 = fresh.search()
+    rows2 = b"".join(h2.rows())
+    h2.close()
+    for k in range(3):
+        assert s.chunk_threshold(k) == fresh.chunk_threshold(k)
+        st_l, ent_l = _bucket_members(s, k, a["ht"])
+        st_f, ent_f = _bucket_members(fresh, k, a["ht"])
+        assert np.array_equal(st_l, st_f) and np.array_equal(ent_l, ent_f), k
+        # the file's slot order is kept: descending (subject, tag, pos) inside every bucket
+        start, ent = s.chunk_index(k)
+        bucket = np.repeat(np.arange(a["ht"]), np.diff(start.astype(np.int64)))
+        same = bucket[1:] == bucket[:-1]
+        assert np.all(ent[1:][same] < ent[:-1][same])
+    assert got == want and rows2 == want
+    # a context with other seeds refuses the files; so does another reference
+    other = fs.Searcher(ssd="111111", nr=a["nr"], ht=a["ht"], chk=a["chk"], step=1, **kw)
+    other.load_ref(ref)
+    with pytest.raises(fs.SohitError, match="was built with"):
+        other.load_index(ref)
+    other.close()
+    wrong = str(tmp_path / "wrong.fsa")
+    fa = open(ref, "rb").read()
+    open(wrong, "wb").write(fa.replace(b"\n", b"\nA", 2))
+    with pytest.raises(fs.SohitError, match="does not belong"):
+        fs.load(wrong, name=ref, **kw)
+    s.close()
+    fresh.close()
+
+
+@pytest.mark.parametrize("space,ht", [("111111", 120000000), ("11111011111,1101011", 1000003)])
+def test_makedb_then_load_equals_a_fresh_build(fs, tmp_path, space, ht):
+    """makedb -> load round trip on a 3-chunk synthetic set (default bucket count: the 480 MB start table per chunk; and two patterns
+    with collisions): rows from the loaded index are byte-identical to those of an index built in memory."""
+    from swiftortho_amd import synthprot
+    fa = synthprot.synthprot(700, 180, 11)
+    ref = str(tmp_path / "r.fsa")
+    open(ref, "wb").write(fa)
+    chunks = fs.makedb(ref, space=space, nr=fs.AA9, step=1, ht=ht, chk=250)
+    assert len(chunks) == 3
+    kw = dict(v=500, expect=1e-5, flt="T")
+    fresh = fs.Searcher(ssd=space, nr=fs.AA9, ht=ht, chk=250, step=1, **kw)
+    fresh.load_ref(ref)
+    fresh.load_queries(ref)
+    h = fresh.search()
+    want = b"".join(h.rows())
+    h.close()
+    s = fs.load(ref, chk=250, **kw)
+    s.load_queries(ref)
+    h = s.search()
+    got = b"".join(h.rows())
+    h.close()
+    assert len(want) > 10000 and got == want
+    assert [s.chunk_threshold(k) for k in range(3)] == [fresh.chunk_threshold(k) for k in range(3)]
+    # drop + rebuild after a load goes back to the built index
+    s.drop_index()
+    h = s.search()
+    assert b"".join(h.rows()) == want
+    h.close()
+    s.close()
+    fresh.close()
+    for k in range(3):
+        for suf in (".idx", ".soas", ".bin"):
+            os.remove("%s.%d%s" % (ref, k, suf))
+
+
 @pytest.mark.parametrize("n,ln,avg", [(40, 4300, "100000"), (24, 5200, "64"), (300, 900, "100000")])
 def test_bucketed_binning_long_sequences_vs_oracle(fs, oracle, tmp_path, monkeypatch, n, ln, avg):
     """Forced bucketed binning on long proteins: a self hit brings thousands of hits on one diagonal to ONE subject -- segments of
