@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SOHIT_ABI_VERSION 2
+#define SOHIT_ABI_VERSION 3
 
 typedef struct so_ctx so_ctx;
 
@@ -96,6 +96,10 @@ typedef struct so_counters {
     int64_t ungap_steps;               /* b62 lookups of the ungapped extension = the reference's `flag` (fsearch.py:2467, 2482)  */
     int64_t groups_single;             /* groups of one seed hit, extended by k_ungap1                                            */
     int64_t groups_chain;              /* groups of two and more hits, chained by k_ungap2 (the rest of `groups`: k_ungap)        */
+    /* round 6 (ABI 3): the third kernel of the seed-lookup + diagonal-binning stage, so that the STAGE (count + scatter + grouping) can be
+     * priced against the HBM roofline, not one pass of it (params.profile) */
+    int64_t bgroup_launches;           /* launches of the bucket grouping kernel (k_bkt_group)                                    */
+    double bgroup_ms;                  /* their summed duration                                                                   */
 } so_counters;
 
 /* Lifetime.  Replaces: spawning `fsearch-c` with its flags (find_hit.py:119-123). */

@@ -29,7 +29,8 @@ class SoCounters(C.Structure):
                 ("index_ms", C.c_double), ("seed_ms", C.c_double), ("group_ms", C.c_double), ("phase2_ms", C.c_double),
                 ("total_ms", C.c_double), ("count_launches", C.c_int64), ("count_ms", C.c_double),
                 ("hits_bucketed", C.c_int64), ("align_wide", C.c_int64), ("cells_wide", C.c_int64), ("seed_passes", C.c_int64),
-                ("ungap_steps", C.c_int64), ("groups_single", C.c_int64), ("groups_chain", C.c_int64)]
+                ("ungap_steps", C.c_int64), ("groups_single", C.c_int64), ("groups_chain", C.c_int64),
+                ("bgroup_launches", C.c_int64), ("bgroup_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -144,7 +145,7 @@ def load():
     L.so_mcl_free.argtypes = [C.POINTER(SoMclResult)]
     L.so_mcl_last_error.restype = cp
     L.so_set_option.argtypes = [vp, cp, cp]
-    if L.so_abi_version() != 2:
+    if L.so_abi_version() != 3:
         raise ImportError("libsohit.so ABI version mismatch")
     _lib = L
     return L

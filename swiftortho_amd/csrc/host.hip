@@ -320,6 +320,7 @@ struct so_ctx {
     size_t h_qhits_cap = 0;
     unsigned long long* h_small = nullptr;  // pinned scratch for the small device -> host reads (counts, totals): 1 KB
     std::map<std::string, double> tm;  // per-stage wall ms (only with params.profile)
+    std::map<std::string, double> lt;  // wall ms of the last loads, always kept: load.ref_parse / load.ref_h2d_layout / load.qry_parse / load.qry_h2d (reported beside the step)
     std::shared_ptr<void> batch;       // persistent per-batch scratch (struct Batch)
     // device-resident results (so_search_device): so_hit records stay in HBM until the caller has exchanged them
     // the library sorts' code objects (rocPRIM: megabytes each) are loaded by their first launch: a thread started by so_create does two
@@ -580,9 +581,12 @@ void parallel_for(i64 n, F f) {
 // Reference side
 // ---------------------------------------------------------------------------------------------
 void load_ref_common(so_ctx* c, i64 r_lo, i64 r_hi) {
+    const double t0 = wall();
     c->ref.parse();
+    const double t1 = wall();
     c->r_lo = r_lo, c->r_hi = r_hi;
-    upload_set(c, c->ref, c->ref.res.data(), c->ref.off, (u32)c->ref.N);
+    upload_set(c, c->ref, c->ref.res.data(), c->ref.off, (u32)c->ref.N);   // (ends with a stream synchronisation)
+    c->lt["load.ref_parse"] = (t1 - t0) * 1e3, c->lt["load.ref_h2d_layout"] = (wall() - t1) * 1e3;
     c->ref_loaded = true;
     c->band_plans.clear();
     c->index_built = false;
@@ -1511,7 +1515,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     b.p_qs.ensure(pcap), b.p_sd.ensure(pcap), b.p_ft.ensure(pcap);
     b.shard.ensure(2 * UG_SHARDS + 8);
     b.stepshard.ensure(UG_SHARDS + 4);   // group counts, then (Tune::count_steps) b62 lookups, singleton groups, chained groups
-    b.bflag.ensure(4);
+    b.bflag.ensure(8);
     double t1 = wall();
     bool bbest = false;   // set by group_bucketed: pass records were flushed per bucket, k_bkt_best reduces them
     BktLayout bL;
@@ -1521,7 +1525,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     auto reset_pass_lists = [&] {
         HIP_CHECK(hipMemsetAsync(b.shard.p, 0, (2 * UG_SHARDS + 8) * sizeof(u32), c->st));
         HIP_CHECK(hipMemsetAsync(b.stepshard.p, 0, (UG_SHARDS + 4) * sizeof(unsigned long long), c->st));
-        HIP_CHECK(hipMemsetAsync(b.bflag.p, 0, 4 * sizeof(u32), c->st));
+        HIP_CHECK(hipMemsetAsync(b.bflag.p, 0, 8 * sizeof(u32), c->st));
     };
 
     // ---- diagonal binning, bucketed (k_bucket.hip): no sort; count -> scan -> scatter (4 B per hit) -> LDS hash grouping ----
@@ -1594,7 +1598,11 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         else b.keys2.ensure((size_t)H + 2);
         b.bext.ensure((size_t)nb + 4);
         launch_bkt_extents(b.bmat.p, b.bt0.p, NT, L.R, nqp, nb, c->d_small.p + 2, b.bext.p, c->st);
-        launch_bkt_group(b.hits32.p, b.bext.p, nb, L, kl, w32 ? nullptr : b.keys2.p, w32 ? b.hits32s.p : nullptr, b.bflag.p, c->st);
+        {
+            ProfTimer pt(c, &c->cnt.bgroup_ms, &c->cnt.bgroup_launches);
+            launch_bkt_group(b.hits32.p, b.bext.p, nb, L, kl, w32 ? nullptr : b.keys2.p, w32 ? b.hits32s.p : nullptr, b.bflag.p, c->st);
+            pt.stop();
+        }
         // a group too large for a wave's LDS table (or pool) leaves key slots unwritten: never walk them -- sorted path instead
         const u32 refused = d2h_u32(c, b.bflag.p);
         sc.lap("group.bucket_group");
@@ -2117,6 +2125,8 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     const bool pk_on = tune().align_pk && align_pk_supported(c->st);
     const bool pk_mixed = pk_on && (int)std::min(maxwin_q, maxwin_s) > align_pk_max_len();
     const PkCls pkc{b.dev.d_pcls.p, b.dev.d_pcls4.p, c->ref.d_pcls.p, c->ref.d_pcls4.p};
+    // score-only rounds by k_align_lane (a lane per alignment pair) when every task's windows end where its sequences end: no tiles
+    const bool lane_on = pk_on && tune().align_lane && b.maxqlen < LONG_SEQ && c->ref.maxlen < LONG_SEQ;
     const bool traced_pk = pk_on && tune().align_pk_trace;   // traced alignments by the packed kernel too (SOHIT_ALIGN_PK_TRACE=0: k_align<true>)
     auto sort_by_rows = [&](const u32* list, u32 n, u32* n_wide) -> const u32* {
         const bool split = n_wide && pk_mixed;
@@ -2248,8 +2258,10 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                 launch_align(b.tasks.p, rlist, n_wide, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
                              c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, nullptr, b.ares.p, false, wst, 0u);
             if (wide_aside) HIP_CHECK(hipEventRecord(c->ev_ug_done, c->st_side));
-            if (NR > n_wide)
-                launch_align_pk(b.tasks.p, rlist + n_wide, NR - n_wide, pkc, b.dev.d_off.p, c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->st);
+            if (NR > n_wide) {
+                if (lane_on) launch_align_lane(b.tasks.p, rlist + n_wide, NR - n_wide, pkc, b.dev.d_off.p, c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->st);
+                else launch_align_pk(b.tasks.p, rlist + n_wide, NR - n_wide, pkc, b.dev.d_off.p, c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->st);
+            }
             if (wide_aside) HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_ug_done, 0));
             pt.stop();
             c->cnt.align_wide += n_wide;
@@ -2810,7 +2822,9 @@ bool read_file(const char* path, std::string& out) {
 void load_queries_common(so_ctx* c, bool parsed = false) {
     SeqSet& Q = c->qry;
     ++c->qry_gen;
+    const double t0 = wall();
     if (!parsed) Q.parse();
+    const double t1 = wall();
     const size_t nres = Q.res.size();
     Q.d_res.ensure(nres + 64);
     Q.d_off.ensure((size_t)Q.N + 1);
@@ -2846,6 +2860,7 @@ void load_queries_common(so_ctx* c, bool parsed = false) {
     }
     HIP_CHECK(hipStreamSynchronize(c->st));
     c->qry_loaded = true;
+    c->lt["load.qry_parse"] = (t1 - t0) * 1e3, c->lt["load.qry_h2d"] = (wall() - t1) * 1e3;
 }
 
 // per-query seed-hit counts over all chunks (what the lookup kernel will visit): the work estimate used to shard queries
@@ -3229,11 +3244,12 @@ int so_get_counters(const so_ctx* c, so_counters* out) {
 int64_t so_timing_report(const so_ctx* c, char* buf, int64_t cap) {
     if (!c) return -1;
     std::string s;
-    for (auto& kv : c->tm) {
-        char tmp[128];
-        snprintf(tmp, sizeof tmp, "%s=%.3f;", kv.first.c_str(), kv.second);
-        s += tmp;
-    }
+    for (const auto* m : {&c->tm, &c->lt})
+        for (auto& kv : *m) {
+            char tmp[128];
+            snprintf(tmp, sizeof tmp, "%s=%.3f;", kv.first.c_str(), kv.second);
+            s += tmp;
+        }
     if (buf && cap > 0) {
         size_t k = std::min<size_t>(s.size(), (size_t)cap - 1);
         memcpy(buf, s.data(), k);

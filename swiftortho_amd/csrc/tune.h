@@ -48,6 +48,7 @@
     /* ---- phase 2 ---- */                                                                                                                                     \
     X(B, align_pk, "SOHIT_ALIGN_PK", 1, "packed 16-bit score-only aligner where the scores fit")                                                               \
     X(B, align_pk_trace, "SOHIT_ALIGN_PK_TRACE", 1, "... and the packed aligner for the traced alignments too (0: k_align<true>)")                               \
+    X(B, align_lane, "SOHIT_ALIGN_LANE", 1, "score-only rounds: one lane per alignment pair (k_align_lane) when no sequence reaches 4096 residues (0: k_align_pk)")                      \
     X(B, csort_aside, "SOHIT_CSORT_ASIDE", 1, "candidate lists above 4096 entries sorted (k_csort) on the side stream beside the LDS instances")               \
     X(B, wide_aside, "SOHIT_WIDE_ASIDE", 1, "the 32-bit score-only aligner of a round's wide tasks on a second stream beside the packed one")                 \
     X(B, align_sort, "SOHIT_ALIGN_SORT", 1, "launch lists ordered by band rows")                                                                               \

@@ -36,7 +36,7 @@ def test_struct_layouts_match_header(lib):
     # so_hit: 2 x i64, 2 x f64, 12 x i32 ; so_params: 2 ptr, 5 x i64, 2 x f64, 2 x i32
     assert C.sizeof(lib.SoHit) == 80
     assert C.sizeof(lib.SoParams) == 2 * C.sizeof(C.c_void_p) + 5 * 8 + 2 * 8 + 2 * 4
-    assert lib.load().so_abi_version() == 2
+    assert lib.load().so_abi_version() == 3
 
 
 def test_no_cpu_fallback(lib):

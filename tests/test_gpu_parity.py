@@ -706,6 +706,19 @@ def test_collapse_search_expand_chain(oracle, tmp_path):
     assert open(full).read().count("\n") > got_nr.count("\n")
 
 
+def _check_per_rank(line, world):
+    """the multi-rank bench line explains itself: every rank's stage times and the model's terms are there"""
+    pr = line["per_rank_ms_per_step"]
+    for k in ("index_ms", "search_ms", "gather_ms_incl_wait", "d2h_ms", "query_aa", "queries"):
+        assert len(pr[k]) == world, k
+    assert sum(pr["query_aa"]) == line["config"]["query_aa"]
+    m = pr["model"]
+    for k in ("records_bytes", "index_ms_replicated_max", "index_build_decision", "search_ms_max", "search_ms_even_split", "gather_ms_rank0_incl_wait",
+              "gather_ms_predicted", "d2h_mode", "d2h_ms_after_gather_max", "d2h_ms_predicted", "step_ms_sum_of_terms"):
+        assert k in m and m[k] is not None, k
+    assert m["records_bytes"] == 80 * line["config"]["rows"] and m["search_ms_max"] > 0 and "own records" in m["d2h_mode"]
+
+
 def test_bench_plain_command_two_ranks():
     """The driver's command shape `python bench.py --gpus N ...` with no torch.distributed environment: bench.py starts its
     own ranks.  Two ranks over gloo sharing GPU 0 (the box has one GPU: functional check of the N > 1 flow, not a timing):
@@ -720,6 +733,7 @@ def test_bench_plain_command_two_ranks():
         assert len(lines) == 1, p.stdout.decode()[-2000:]
         outs[n] = json.loads(lines[0])
         assert outs[n]["n_gpus"] == n and outs[n]["value"] > 0 and outs[n]["scaling"] == "strong"
+    _check_per_rank(outs[2], 2)
     assert outs[1]["config"]["rows"] == outs[2]["config"]["rows"] > 10000
     assert outs[1]["config"]["workload"] == outs[2]["config"]["workload"]
 
@@ -843,6 +857,14 @@ def test_two_rank_search_over_rccl_on_two_gpus(tmp_path):
         assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
         outs.append(out.read_bytes())
     assert outs[0].count(b"\n") > 5000 and outs[0] == outs[1]
+    # ... and the bench's strong-scaling flow over RCCL: one JSON line that carries every rank's terms
+    p = _cli(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "c2", "--no-cpu-baseline"], env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    _check_per_rank(line, 2)
 
 
 @pytest.mark.parametrize("spec", ["0", "1"])
