@@ -60,7 +60,7 @@ def _preload_torch_hip_runtime():
     reuses the same mapping.  Without torch installed this is a no-op (system ROCm is used)."""
     import importlib.util
     import sys
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("SOHIT_TORCH_PRELOAD") == "0":   # ("0": a process that will never import torch -- the one-GPU CLI)
         return
     try:
         spec = importlib.util.find_spec("torch")

@@ -135,8 +135,9 @@ struct SeqSet {
         rec.clear();
         rec.push_back(0);
         const i64 n = (i64)data.size();
-        for (i64 i = 1; i < n; ++i)
-            if (data[i] == '>' && data[i - 1] == '\n') rec.push_back(i);
+        for (const char *d0 = data.data(), *q = n > 1 ? (const char*)memchr(d0 + 1, '>', (size_t)n - 1) : nullptr; q;
+             q = q + 1 < d0 + n ? (const char*)memchr(q + 1, '>', (size_t)(d0 + n - q - 1)) : nullptr)
+            if (q[-1] == '\n') rec.push_back((i64)(q - d0));
         N = (i64)rec.size();
         off.assign((size_t)N + 1, 0);
         hd_beg.resize((size_t)N);
@@ -148,7 +149,10 @@ struct SeqSet {
         for (i64 x = 0; x < N; ++x) {
             i64 st = rec[x], ed = (x == N - 1) ? n : rec[x + 1];
             i64 p = st;
-            while (p < ed && data[p] != '\n') ++p;
+            {
+                const void* nl = memchr(data.data() + st, '\n', (size_t)(ed - st));
+                p = nl ? (i64)((const char*)nl - data.data()) : ed;
+            }
             hd_beg[x] = (u32)std::min<i64>(st + 1, p);
             hd_len[x] = (u32)(p > st ? p - st - 1 : 0);
             {
@@ -157,8 +161,8 @@ struct SeqSet {
             }
             ++p;
             while (p < ed) {
-                i64 q = p;
-                while (q < ed && data[q] != '\n') ++q;
+                const void* nl = memchr(data.data() + p, '\n', (size_t)(ed - p));
+                const i64 q = nl ? (i64)((const char*)nl - data.data()) : ed;
                 res.insert(res.end(), data.begin() + p, data.begin() + q);
                 p = q + 1;
             }
@@ -2125,8 +2129,6 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     const bool pk_on = tune().align_pk && align_pk_supported(c->st);
     const bool pk_mixed = pk_on && (int)std::min(maxwin_q, maxwin_s) > align_pk_max_len();
     const PkCls pkc{b.dev.d_pcls.p, b.dev.d_pcls4.p, c->ref.d_pcls.p, c->ref.d_pcls4.p};
-    // score-only rounds by k_align_lane (a lane per alignment pair) when every task's windows end where its sequences end: no tiles
-    const bool lane_on = pk_on && tune().align_lane && b.maxqlen < LONG_SEQ && c->ref.maxlen < LONG_SEQ;
     const bool traced_pk = pk_on && tune().align_pk_trace;   // traced alignments by the packed kernel too (SOHIT_ALIGN_PK_TRACE=0: k_align<true>)
     auto sort_by_rows = [&](const u32* list, u32 n, u32* n_wide) -> const u32* {
         const bool split = n_wide && pk_mixed;
@@ -2258,10 +2260,8 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                 launch_align(b.tasks.p, rlist, n_wide, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
                              c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, nullptr, b.ares.p, false, wst, 0u);
             if (wide_aside) HIP_CHECK(hipEventRecord(c->ev_ug_done, c->st_side));
-            if (NR > n_wide) {
-                if (lane_on) launch_align_lane(b.tasks.p, rlist + n_wide, NR - n_wide, pkc, b.dev.d_off.p, c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->st);
-                else launch_align_pk(b.tasks.p, rlist + n_wide, NR - n_wide, pkc, b.dev.d_off.p, c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->st);
-            }
+            if (NR > n_wide)
+                launch_align_pk(b.tasks.p, rlist + n_wide, NR - n_wide, pkc, b.dev.d_off.p, c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->st);
             if (wide_aside) HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_ug_done, 0));
             pt.stop();
             c->cnt.align_wide += n_wide;
@@ -3140,7 +3140,7 @@ int so_write_sc(so_ctx* c, const so_hit* hits, int64_t n, const char* path, cons
         // than 4 * nt slabs ahead of the writer: with a slow disk the text of a 300 M-row result would otherwise pile up in memory.
         const int64_t SLAB = 16384;
         const int64_t nslab = (n + SLAB - 1) / SLAB;
-        const unsigned nt = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())), nslab));
+        const unsigned nt = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min((unsigned)std::max(1ll, tune().write_threads), std::max(1u, std::thread::hardware_concurrency())), nslab));
         std::vector<std::vector<char>> bufs((size_t)nslab);
         std::vector<std::atomic<int>> ready((size_t)nslab);
         for (auto& r : ready) r.store(0);

@@ -33,6 +33,7 @@
     X(I, segsort, "SOHIT_SEGSORT", 1, "sorted path: segmented sort of the keys inside each query (0: device-wide sort)")                                        \
     X(I, lk_variant, "SOHIT_LK_VARIANT", 0, "ABLATION (1, 2: lookup timing only, results invalid): variants of k_lookup")                                      \
     X(I, lk_iters, "SOHIT_LK_ITERS", 16, "k_lookup: hits per thread")                                                                                          \
+    X(I, write_threads, "SOHIT_WRITE_THREADS", 48, "so_write_sc: formatter threads (at most the host's cores)")                                                                          \
     X(B, bk_staged, "SOHIT_BK_STAGED", 1, "k_bkt_pass scatter staged through LDS (0: direct scatter)")                                                         \
     X(B, bk_skew, "SOHIT_BK_SKEW", 1, "k_bkt_pass histogram copies skewed over the LDS banks")                                                                 \
     X(I, bk_wpe, "SOHIT_BK_WPE", 6, "k_bkt_pass scatter: waves per SIMD the register budget is cut for (4, 5, 6)")                                             \
@@ -48,7 +49,6 @@
     /* ---- phase 2 ---- */                                                                                                                                     \
     X(B, align_pk, "SOHIT_ALIGN_PK", 1, "packed 16-bit score-only aligner where the scores fit")                                                               \
     X(B, align_pk_trace, "SOHIT_ALIGN_PK_TRACE", 1, "... and the packed aligner for the traced alignments too (0: k_align<true>)")                               \
-    X(B, align_lane, "SOHIT_ALIGN_LANE", 1, "score-only rounds: one lane per alignment pair (k_align_lane) when no sequence reaches 4096 residues (0: k_align_pk)")                      \
     X(B, csort_aside, "SOHIT_CSORT_ASIDE", 1, "candidate lists above 4096 entries sorted (k_csort) on the side stream beside the LDS instances")               \
     X(B, wide_aside, "SOHIT_WIDE_ASIDE", 1, "the 32-bit score-only aligner of a round's wide tasks on a second stream beside the packed one")                 \
     X(B, align_sort, "SOHIT_ALIGN_SORT", 1, "launch lists ordered by band rows")                                                                               \

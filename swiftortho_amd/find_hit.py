@@ -84,8 +84,10 @@ def query_range(start, end, n_queries, ncpu=1):
     return lo, max(lo, hi)
 
 
-def run_single(p):
+def run_single(p, fast_exit=False):
     import time
+    if fast_exit:
+        os.environ.setdefault('SOHIT_TORCH_PRELOAD', '0')   # this process never imports torch: libsohit binds the system HIP runtime
     laps, t0 = [], time.perf_counter()
 
     def lap(name):   # SOHIT_TIMING=1: where the wall time of one command goes (stderr)
@@ -108,8 +110,11 @@ def run_single(p):
         hits.write(p['outfile'], 'w')
         lap('write')
         n = len(hits)
-        hits.close()
+        if not fast_exit:
+            hits.close()
     finally:
+        # (fast_exit still destroys the context: a process that ends with gigabytes of device memory mapped leaves their release to the
+        # driver, and the NEXT process's first search waited for it -- 0.2-0.7 s instead of 0.1 in one run of three)
         s.close()
     lap('close')
     if os.environ.get('SOHIT_TIMING'):
@@ -271,10 +276,10 @@ def merge_parts(part_files, bv, out_path):
         f.close()
 
 
-def search_to_file(p, argv):
+def search_to_file(p, argv, fast_exit=False):
     """One reference file -> one output file: in-process on one GPU, or one rank per GPU through torch.distributed.run."""
     if p['ngpu'] <= 1:
-        run_single(p)
+        run_single(p, fast_exit)
         return 0
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:  # a free rendezvous port, so concurrent runs do not collide
@@ -289,7 +294,8 @@ def search_to_file(p, argv):
     return subprocess.call(cmd, env=env)
 
 
-def main(argv=None):
+def main(argv=None, fast_exit=False):
+    """fast_exit: the caller ends the process right after (bin/find_hit.py): the one-GPU path skips its own clean-up"""
     argv = list(sys.argv if argv is None else argv)
     args = parse(argv)
     p = resolve(args)
@@ -306,7 +312,7 @@ def main(argv=None):
     # find_hit.py:286-351.  SWIFTORTHO_MAX_CHR stands in for the author's commented test value (line 288).
     max_chr = int(os.environ.get('SWIFTORTHO_MAX_CHR', '4200000000'))
     if os.path.getsize(p['ref']) < max_chr:
-        return search_to_file(p, argv)
+        return search_to_file(p, argv, fast_exit)
     # Reference files of >= max_chr bytes: the reference searches consecutive parts as separate databases (so D, the chunk
     # boundaries and the per-chunk thresholds are those of the part) and merges the part outputs.  288 GB of HBM would hold
     # the whole file, but the rows would differ; the observable behaviour is kept instead.

@@ -15,9 +15,20 @@ import ctypes as C
 import os
 import sys
 
-import numpy as np
-
 from . import _lib
+
+
+class _LazyNumpy:
+    """numpy is imported by the first function that uses it: the one-GPU command line (find_hit.py -> Searcher -> Hits.write) never does,
+    and its import is ~0.1 s of a 0.7 s command."""
+
+    def __getattr__(self, name):
+        import numpy
+        globals()["np"] = numpy
+        return getattr(numpy, name)
+
+
+np = _LazyNumpy()
 
 AA9 = "AST,CFILMVY,DN,EQ,G,H,KR,P,W"
 AA20 = "A,S,T,C,F,I,L,M,V,Y,D,N,E,Q,G,H,K,R,P,W"
