@@ -19,7 +19,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 SOURCES = ["k_util.hip", "k_sort.hip", "k_sortseg.hip", "k_prep.hip", "k_index.hip", "k_ixsort.hip", "k_seed.hip", "k_group.hip", "k_ungap1.hip", "k_bucket.hip", "k_align.hip", "k_align16.hip", "k_phase2.hip", "mcl.hip",
-           "tsv.hip", "host.hip"]
+           "tsv.hip", "host_load.hip", "host_index.hip", "host_seed.hip", "host_phase2.hip", "host_search.hip", "host_abi.hip"]
 # -ffp-contract=off: host-side SEG/threshold arithmetic must round exactly like the reference's
 # (no fused multiply-add), and device fp64 compares stay IEEE.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=off", "-Wall", "-Wno-unused-function",
@@ -51,7 +51,7 @@ def _compile(src, force):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         res = list(ex.map(lambda s: _compile(s, force), SOURCES))
     objs = [o for o, _ in res]
     if any(ch for _, ch in res) or not os.path.isfile(LIB):

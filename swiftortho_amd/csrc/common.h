@@ -36,7 +36,7 @@ struct DevOom : SoError {
                           std::to_string(__LINE__) + " in " #expr);                                       \
     } while (0)
 
-extern int g_poison;   // Tune::poison of the last so_create (-1: none)
+extern thread_local int g_poison;   // Tune::poison of the context whose call runs on this thread (-1: none)
 
 // Grow-only device buffer.
 template <class T>

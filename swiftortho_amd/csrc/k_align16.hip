@@ -23,7 +23,7 @@
 // in-matrix maximum.  Only the first and last groups of an alignment need the sentinels (their windows are masked); interior
 // groups run on raw windows.
 // Range: (score << 2) + 47 must fit int16: 11 * min(rows, columns) <= 8179; launch_align_pk() is only used when the longest
-// possible window allows it (host.hip), longer inputs take the 32-bit kernel.
+// possible window allows it (host_phase2.hip), longer inputs take the 32-bit kernel.
 // Per cell pair: 11 packed VALU + 1 DPP move + 2 address permutes + 1 pack of the two looked-up scores = 15, i.e. 7.5 per cell
 // against 13 in k_align<false>.
 #include "common.h"

@@ -726,21 +726,15 @@ void launch_bkt_pass(bool scatter, const void* td, const u32* qseg, u32 NT, cons
                      const u32* dk32, const u32* roff, const BktLayout& L, u32* mat, u32* out, hipStream_t st) {
     if (!NT) return;
     const dim3 g(((NT + BK_WAVES - 1) / BK_WAVES + 7u) & ~7u), bl(64 * BK_WAVES);  // multiple of 8: the XCD-aware tile order
-    // SOHIT_BK_STAGED=0: direct scatter (round 2); SOHIT_BK_SKEW=0: histogram copies a power of two apart (round 2)
-    const bool staged_on = tune().bk_staged, skewed = tune().bk_skew;
-    const bool staged = scatter && staged_on && L.R <= BK_STAGE_RMAX;
-    const BkHist HL = bk_hist_layout(L.R, staged, skewed);
+    // the scatter is staged through LDS whenever the tile's runs fit the stage (the direct scatter serves passes with more ranges)
+    const bool staged = scatter && L.R <= BK_STAGE_RMAX;
+    const BkHist HL = bk_hist_layout(L.R, staged, true);
     // (the count pass at a budget of 8 waves per SIMD cannot be met either -- LDS, not registers, bounds it at 7: 0.752 against 0.749 ms)
     if (!scatter) hipLaunchKernelGGL((k_bkt_pass<false, false>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
-    else if (staged) {
-        // waves per SIMD the register budget is cut for.  Round 3: 5 (93 VGPRs; 6 spilled four dwords and was 4-5 % slower).  Round 4: the
-        // banded hit word needs fewer registers -- 6 fits in 80 VGPRs without a spill and is 6 % faster (1.89 -> 1.77 ms per 928 M-hit
-        // launch: 0.49 -> 0.52-0.53 of the HBM roofline); a budget of 7 cannot be met (the compiler falls back to 5 waves: 1.88 ms)
-        const int wpe = (int)tune().bk_wpe;
-        if (wpe == 5) hipLaunchKernelGGL((k_bkt_pass<true, true, 5>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
-        else if (wpe == 4) hipLaunchKernelGGL((k_bkt_pass<true, true, 4>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
-        else hipLaunchKernelGGL((k_bkt_pass<true, true, 6>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
-    }
+    // waves per SIMD the register budget is cut for.  Round 3: 5 (93 VGPRs; 6 spilled four dwords and was 4-5 % slower).  Round 4: the
+    // banded hit word needs fewer registers -- 6 fits in 80 VGPRs without a spill and is 6 % faster (1.89 -> 1.77 ms per 928 M-hit
+    // launch); a budget of 7 cannot be met (the compiler falls back to 5 waves: 1.88 ms)
+    else if (staged) hipLaunchKernelGGL((k_bkt_pass<true, true, 6>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
     else hipLaunchKernelGGL((k_bkt_pass<true, false>), g, bl, 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, cs_kbase, dk32, L, HL, mat, out);
 }
 

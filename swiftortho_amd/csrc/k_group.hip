@@ -885,19 +885,15 @@ void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& 
                   u64* p_ft, unsigned long long* group_count, hipStream_t st, const u32* words, const u32* bext, u32 nb, const BktLayout* L, bool skip_single,
                   unsigned long long* stat) {
     if (!H) return;
-    // SOHIT_UG_CPI / SOHIT_UG_WAIT: tuning switches (results do not depend on them)
-    const int cpi = (int)tune().ug_cpi;
-    const u32 wait_n = (u32)tune().ug_wait;
+    const u32 wait_n = 20;   // waiting lanes that trigger the bookkeeping section (16 ... 32 measured alike)
     BktLayout L0 = BktLayout();
     L0.nqp = 1;
     // A wave walks its range's groups one after the other on each lane: with 4096 positions per wave a pass of a few million hits (the
     // long length classes of a mixed batch) fills a fraction of the 8192 wave slots and lasts as long as one wave does.  Passes below
     // half a fill get shorter ranges, down to 256 positions (heterogeneous 100 k set: 14.4 -> 13.0 ms of extension per step; config 3's
-    // passes keep 4096 -- shorter ranges there only add table set-ups).  SOHIT_UG_RANGE: a fixed range.
+    // passes keep 4096 -- shorter ranges there only add table set-ups).
     u32 range = UW_RANGE;
-    if (tune().ug_range > 0) range = (u32)std::max(64ll, tune().ug_range);
-    else
-        while (range > 256u && (u64)H / range < 4096ull) range >>= 1;
+    while (range > 256u && (u64)H / range < 4096ull) range >>= 1;
     const dim3 g((unsigned)(((u64)H + (u64)range * UW_WAVES - 1) / ((u64)range * UW_WAVES))), bl(64 * UW_WAVES);
 #define UG_LAUNCH(K) hipLaunchKernelGGL(K, g, bl, 0, st, keys, words, bext, nb, words ? *L : L0, H, kl, klr.bs, klr.sh_subj, klr.sh_diag, (int)klr.diag_off, (const uint2*)btab, \
                                         (ft_walk ? 1 : 0) | (skip_single && words ? 2 : 0), wait_n, range, q_scls, qoff, r_scls, roff, b62g, shard_cnt, shard_cap, p_qs, p_sd, p_ft, group_count, stat)
@@ -921,14 +917,7 @@ void launch_ungap(const u64* keys, u32 H, const KeyLayout& kl, const KeyLayout& 
         UG_BY_FLAGS(true, false);
         return;
     }
-    if (gallop || cpi == 3) UG_BY_FLAGS(false, false);
-    else if (btab) {
-        if (cpi == 1) UG_PICK(1, true, false, false, false);
-        else UG_PICK(2, true, false, false, false);
-    } else {
-        if (cpi == 1) UG_PICK(1, false, false, false, false);
-        else UG_PICK(2, false, false, false, false);
-    }
+    UG_BY_FLAGS(false, false);   // (three chunk steps per loop iteration: instances with one and two measured slower, rounds 1-2)
 #undef UG_BY_FLAGS
 #undef UG_PICK
 #undef UG_LAUNCH

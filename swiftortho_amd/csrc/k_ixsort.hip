@@ -69,7 +69,8 @@ __global__ __launch_bounds__(IXS_T1) void k_ixs_scatter(const u32* __restrict__ 
 
 // counting pass of one id range inside a workgroup: pairs [a, b) of (sk, sv), ids in [idbase, idbase + IXS_W), to (dk, dv) at the same
 // positions, grouped by id
-__device__ __forceinline__ void ixs_group(const u32* __restrict__ sk, const u64* __restrict__ sv, u32 a, u32 b, u32 idbase, u32* __restrict__ dk,
+// (sk / sv carry no __restrict__: the split path of k_ixs_bin hands in the scratch pairs the same workgroup has just written)
+__device__ __forceinline__ void ixs_group(const u32* sk, const u64* sv, u32 a, u32 b, u32 idbase, u32* __restrict__ dk,
                                           u64* __restrict__ dv, u32* s_cnt, u32* s_ws) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     constexpr int PER = IXS_W / IXS_T2;   // counters per thread in the scan
@@ -107,7 +108,7 @@ __device__ __forceinline__ void ixs_group(const u32* __restrict__ sk, const u64*
 }
 
 __global__ __launch_bounds__(IXS_T2) void k_ixs_bin(const u32* __restrict__ tk, const u64* __restrict__ tv, const u32* __restrict__ plan, int wsh,
-                                                    u32* __restrict__ ak, u64* __restrict__ av /*scratch (the level-1 input), bins wider than IXS_W only*/,
+                                                    u32* ak, u64* av /*scratch (the level-1 input), bins wider than IXS_W only: written, then re-read by this workgroup*/,
                                                     u32* __restrict__ ok, u64* __restrict__ ov) {
     __shared__ u32 s_cnt[IXS_W];
     __shared__ u32 s_ws[IXS_T2 / 64];

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64) void k_emit_hits(const AlnTask* __restrict__ ta
 }
 
 // so_hit records (include/sohit.h: 2 x i64, 2 x f64, 12 x i32 = 80 bytes) built on the device from the 12-int rows of k_emit_hits,
-// for the device-resident result path (so_search_device).  Same IEEE expressions as the host emission in host.hip:
+// for the device-resident result path (so_search_device).  Same IEEE expressions as the host emission in host_phase2.hip:
 // identity = matches * (100. / aln) (fsearch.py:1458-1459, 1471), e = D * qlen * slen * 2^-bit (1086) with the powers of two from
 // a table filled by libm on the host.  The library is built with -ffp-contract=off.
 struct DevHit {

@@ -234,10 +234,7 @@ __global__ __launch_bounds__(256) void k_compact_seeds(const u32* __restrict__ e
 // bit 63 of their delta and redone after the main loop.
 #define LW_SEEDS 256
 #define LW_WAVES 4
-static int lw_iters() {  // 64-hit steps per wave tile (tuning knob; config 2: 4 -> 0.54 ms, 8 -> 0.48 ms, 16 -> 0.46 ms)
-    const int v = (int)tune().lk_iters;
-    return v == 4 || v == 8 ? v : 16;
-}
+static constexpr int lw_iters() { return 16; }  // 64-hit steps per wave tile (config 2: 4 -> 0.54 ms per launch, 8 -> 0.48 ms, 16 -> 0.46 ms)
 
 // first compacted seed of every lookup wave: largest k with cs_hoff[k] <= wave * LW_HITS
 __global__ __launch_bounds__(256) void k_lookup_blockfirst(const u32* __restrict__ cs_hoff, u32 K, u32 H, u32 nw, u32 LW_HITS,
@@ -306,7 +303,7 @@ struct Addend<u32> {
     static __device__ __forceinline__ u32 tag(u32, const KeyLayout&) { return 0u; }
 };
 
-template <int LW_ITERS, int VAR /*0 = real; diagnostic ablations: 1 = no index read, 2 = no key write, 3 = plain (temporal) key stores*/, class ENT>
+template <int LW_ITERS, class ENT>
 __global__ __launch_bounds__(64 * LW_WAVES, 8) void k_lookup(const u32* __restrict__ cs_hoff, const u32* __restrict__ cs_base,
                                                           const u64* __restrict__ cs_kbase, const u32* __restrict__ wave_first, u32 K,
                                                           u32 H, u32 nw, const ENT* __restrict__ dkeys,
@@ -358,23 +355,16 @@ __global__ __launch_bounds__(64 * LW_WAVES, 8) void k_lookup(const u32* __restri
             carry = max(carry, (u32)__builtin_amdgcn_readlane((int)inc, 63));
             own[it] = a;
             const u32 byte_off = (s_base[a] + (lo + it * 64 + lane)) * (u32)sizeof(ENT);  // < 2^32: chunk entries < 2^29 (host check)
-            if (VAR == 1) e[it] = (ENT)(byte_off >> 4);
-            else e[it] = *reinterpret_cast<const ENT*>(reinterpret_cast<const char*>(dkeys) + byte_off);
+            e[it] = *reinterpret_cast<const ENT*>(reinterpret_cast<const char*>(dkeys) + byte_off);
         }
         u32 fix = 0;
 #pragma unroll
         for (int it = 0; it < LW_ITERS; ++it) {
             const u64 key = s_kb[own[it]] + Addend<ENT>::expand(e[it], kl);
-            if (VAR == 2) {
-                if (key == 0x1234567ull) kp[it * 64 + lane] = key;
-            } else if (VAR == 3) {
-                kp[it * 64 + lane] = key;
-            } else {
-                // streamed once, read back by the sort: non-temporal stores keep the 1.9 GB key stream from evicting
-                // the index addends out of L2 / Infinity Cache (0.64 -> 0.47 ms on config 2)
-                __builtin_nontemporal_store(key, kp + it * 64 + lane);
-            }
-            if (VAR == 0 || VAR == 3) fix |= (u32)Addend<ENT>::offset0(e[it], kl) << it;
+            // streamed once, read back by the sort: non-temporal stores keep the 1.9 GB key stream from evicting
+            // the index addends out of L2 / Infinity Cache (0.64 -> 0.47 ms on config 2)
+            __builtin_nontemporal_store(key, kp + it * 64 + lane);
+            fix |= (u32)Addend<ENT>::offset0(e[it], kl) << it;
         }
         if (fix) {  // rare: entries at offset 0 of their sequence
 #pragma unroll 1
@@ -465,23 +455,9 @@ void launch_lookup(const u32* cs_hoff, const u32* cs_base, const u64* cs_kbase, 
                    const void* dkeys, bool compact, const u32* roff, const KeyLayout& kl, u32 maxslen, u64* keys, hipStream_t st) {
     if (!H) return;
     const u32 nw = lookup_num_blocks(H);
-    const int var = (int)tune().lk_variant;
     const dim3 g((nw + LW_WAVES - 1) / LW_WAVES), bl(64 * LW_WAVES);
-#define LK_LAUNCH(I, V)                                                                                                              \
-    do {                                                                                                                             \
-        if (compact)                                                                                                                 \
-            hipLaunchKernelGGL((k_lookup<I, V, u32>), g, bl, 0, st, cs_hoff, cs_base, cs_kbase, wave_first, K, H, nw, (const u32*)dkeys, \
-                               roff, kl, maxslen, keys);                                                                            \
-        else                                                                                                                         \
-            hipLaunchKernelGGL((k_lookup<I, V, u64>), g, bl, 0, st, cs_hoff, cs_base, cs_kbase, wave_first, K, H, nw, (const u64*)dkeys, \
-                               roff, kl, maxslen, keys);                                                                            \
-    } while (0)
-    const int it = lw_iters();
-    if (var == 1) LK_LAUNCH(8, 1);
-    else if (var == 2) LK_LAUNCH(8, 2);
-    else if (var == 3) LK_LAUNCH(8, 3);
-    else if (it == 4) LK_LAUNCH(4, 0);
-    else if (it == 16) LK_LAUNCH(16, 0);
-    else LK_LAUNCH(8, 0);
-#undef LK_LAUNCH
+    if (compact)
+        hipLaunchKernelGGL((k_lookup<lw_iters(), u32>), g, bl, 0, st, cs_hoff, cs_base, cs_kbase, wave_first, K, H, nw, (const u32*)dkeys, roff, kl, maxslen, keys);
+    else
+        hipLaunchKernelGGL((k_lookup<lw_iters(), u64>), g, bl, 0, st, cs_hoff, cs_base, cs_kbase, wave_first, K, H, nw, (const u64*)dkeys, roff, kl, maxslen, keys);
 }

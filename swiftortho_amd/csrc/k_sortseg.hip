@@ -12,7 +12,7 @@
 // rocPRIM ships no tuned segmented-sort configuration for gfx950 and falls back to its generic one (6-bit digits,
 // 128 x 17 keys per block: four passes over our 24 bits).  Measured on config 2 (247 M keys, 10 k segments;
 // generic 5.09 ms; 8-bit digits with 256 x 8 keys 4.16, 256 x 16 keys 3.97-4.06 (default
-// here), 256 x 32 6.0, 512 x 16 4.64, 1024 x 8 4.35.  SOHIT_SEG_CFG selects (0 = library default).
+// here), 256 x 32 6.0, 512 x 16 4.64, 1024 x 8 4.35.
 template <int IPT, int BLOCK = 256, int BITS = 8>
 using SegCfg = rocprim::segmented_radix_sort_config<BITS, rocprim::kernel_config<BLOCK, IPT>, rocprim::WarpSortConfig<8, 4, 256, 64, 16, 8, 256>, true>;
 
@@ -23,8 +23,6 @@ using SegCfg = rocprim::segmented_radix_sort_config<BITS, rocprim::kernel_config
 // keys cost the same per pass as 8-bit / 256 x 16 (3.96 vs 3.97 ms on config 2) and keep widths up to 27 at three passes.
 // (10-bit digits with 1024 x 4 keys: 5.3 ms per three passes -- no better than four 8-bit ones.)
 static int seg_variant(size_t n, u32 nseg, int width) {
-    const int v = (int)tune().seg_cfg;
-    if (v >= 0) return v;
     if (!(nseg && n / nseg >= 4096)) return 0;
     if (width > 24 && width <= 27) return 6;
     return 2;
@@ -60,43 +58,13 @@ void sort_keys_u64_seg(void* temp, size_t temp_bytes, const u64* in, u64* out, s
     HIP_CHECK(seg_sort_dispatch(temp, temp_bytes, in, out, n, nseg, seg, seg + 1, begin_bit, end_bit, st));
 }
 
-// ---- segmented (key, value) variant: the candidates of a bucketed pass leave k_bkt_best query-major, so ordering them by first-touch
-// key inside each query needs the key's low bits only -- the query bits on top of the sort word stay where they are (k_emit_cands
-// reads them) and are not sorted: four 8-bit passes inside LDS-sized segments instead of six device-wide ones.
-template <class Cfg>
-static hipError_t seg_sort_pairs(void* temp, size_t& bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, u32 nseg, const u32* sb,
-                                 const u32* se, int b0, int b1, hipStream_t st) {
-    return rocprim::segmented_radix_sort_pairs<Cfg>(temp, bytes, kin, kout, vin, vout, (unsigned)n, nseg, sb, se, (unsigned)b0, (unsigned)b1, st, false);
-}
-static hipError_t seg_sort_pairs_dispatch(void* temp, size_t& bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, u32 nseg,
-                                          const u32* sb, const u32* se, int b0, int b1, hipStream_t st) {
-    const int v = (int)tune().cseg_cfg;   // tuning switch: 0 default, 1 = 256 x 16, 2 = 512 x 16
-    const size_t avg = nseg ? n / nseg : 0;
-    // 100k weight-6 set (7.5 k candidates per query and pass), best / candidate-order stage per step: device-wide sort 166.7 ms, 256 x 16
-    // 166.7, 512 x 16 145.4, 1024 x 16 148.9
-    const int cfg = v >= 0 ? v : avg >= 3072 ? 2 : 0;
-    // (this (key, index) form is the fallback of the keys-only candidate order, SOHIT_CAND_KEYS=0: two instances are kept)
-    if (cfg >= 1) return seg_sort_pairs<SegCfg<16, 512>>(temp, bytes, kin, kout, vin, vout, n, nseg, sb, se, b0, b1, st);
-    return seg_sort_pairs<rocprim::default_config>(temp, bytes, kin, kout, vin, vout, n, nseg, sb, se, b0, b1, st);
-}
-size_t sort_pairs_u64_u32_seg_temp_bytes(size_t n, u32 nseg, int begin_bit, int end_bit) {
-    size_t bytes = 0;
-    (void)seg_sort_pairs_dispatch(nullptr, bytes, nullptr, nullptr, nullptr, nullptr, n, nseg, nullptr, nullptr, begin_bit, end_bit, (hipStream_t)0);
-    return bytes;
-}
-void sort_pairs_u64_u32_seg(void* temp, size_t temp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, u32 nseg, const u32* seg,
-                            int begin_bit, int end_bit, hipStream_t st) {
-    if (n == 0) return;
-    HIP_CHECK(seg_sort_pairs_dispatch(temp, temp_bytes, kin, kout, vin, vout, n, nseg, seg, seg + 1, begin_bit, end_bit, st));
-}
 // ---- keys-only variant for the candidate order of a bucketed pass (the position rides in the low bits of the sort word) ----------
 // NOTE end_bit must stay below 64: rocPRIM's comparator for short segments builds its mask as (1 << (begin + bits)) - 1, which for
 // begin + bits == 64 shifts by the word size and ends up comparing the bits BELOW begin_bit (ROCm 7.2) -- the caller keeps bit 63 free.
 static hipError_t cand_keys_dispatch(void* temp, size_t& bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* sb, const u32* se, int b0,
                                      int b1, hipStream_t st) {
-    const int v = (int)tune().cseg_cfg;
     const size_t avg = nseg ? n / nseg : 0;
-    const int cfg = v >= 0 ? v : avg >= 3072 ? 2 : avg >= 1024 ? 1 : 0;
+    const int cfg = avg >= 3072 ? 2 : avg >= 1024 ? 1 : 0;
     if (cfg == 2) return seg_sort<SegCfg<16, 512>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
     if (cfg == 1) return seg_sort<SegCfg<16>>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);
     return seg_sort<rocprim::default_config>(temp, bytes, in, out, n, nseg, sb, se, b0, b1, st);

@@ -683,9 +683,10 @@ static void ungap1_launch(u32 ncu, const u32* words, const u32* bext, u32 nb, co
                        group_count, mlist, mlist_cnt, stat);
 }
 
-// variant: 0 = 32-bit table entries, one workgroup per CU (4 waves per SIMD); 1 = 16-bit entries, one workgroup; 2 = 16-bit entries and
-// 512-residue query slots, two workgroups per CU (8 waves per SIMD; only for passes whose queries fit)
-void launch_ungap1(u32 ncu, int variant, u32 pmaxq, const u32* words, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, const KeyLayout& klr,
+// 16-bit table entries; 512-residue query slots and two workgroups per CU (8 waves per SIMD) for the passes whose queries fit, else one
+// workgroup with 1024-residue or U1_QCAP slots.  (An instance with 32-bit entries -- every lane of a 32-lane group its own bank -- measured
+// slower at its one workgroup per CU, round 5.)
+void launch_ungap1(u32 ncu, u32 pmaxq, const u32* words, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, const KeyLayout& klr,
                    const void* btab, u32 wait_n, const u8* q_scls, const u32* qoff, const u8* r_ug, const u32* roff, const signed char* b62g, u32* work_ctr, u32* shard_cnt,
                    u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, u64* mlist, u32* mlist_cnt, unsigned long long* stat, hipStream_t st) {
     if (!nb) return;
@@ -696,12 +697,9 @@ void launch_ungap1(u32 ncu, int variant, u32 pmaxq, const u32* words, const u32*
         else U1_GOC(false);
         return;
     }
-    if (variant == 2 && pmaxq <= 512) {
+    if (pmaxq <= 512) {
         if (btab) U1_GO(true, 3, 512, 2);
         else U1_GO(false, 3, 512, 2);
-    } else if (variant == 0 && pmaxq <= 1024) {
-        if (btab) U1_GO(true, 4, 1024, 1);
-        else U1_GO(false, 4, 1024, 1);
     } else if (pmaxq <= 1024) {
         if (btab) U1_GO(true, 3, 1024, 1);
         else U1_GO(false, 3, 1024, 1);

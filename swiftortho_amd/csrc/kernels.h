@@ -17,9 +17,6 @@ void launch_query_segments(const u32* hoff, const u32* qoff, u32 qa, u32 qb, int
 size_t sort_keys_u64_seg_temp_bytes(size_t n, u32 nseg, int begin_bit, int end_bit);
 void sort_keys_u64_seg(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* seg, int begin_bit,
                        int end_bit, hipStream_t st);
-size_t sort_pairs_u64_u32_seg_temp_bytes(size_t n, u32 nseg, int begin_bit, int end_bit);
-void sort_pairs_u64_u32_seg(void* temp, size_t temp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, u32 nseg,
-                            const u32* seg /*nseg + 1 offsets*/, int begin_bit, int end_bit, hipStream_t st);
 void launch_stride_gather(const u32* src, u32 stride, u32 n, u32* dst, hipStream_t st);   // dst[i] = src[i * stride]
 size_t sort_pairs_u64_u32_temp_bytes(size_t n, int bits);
 void sort_pairs_u64_u32(void* temp, size_t temp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, int bits,
@@ -112,7 +109,8 @@ void launch_make_ug(const u8* scls, const u32* off, u32 nseq, size_t nres, u32 m
 size_t ungap1_mlist_cap(u32 H, u32 ncu);   // entries of the chain list of a pass of H hits
 // mlist / mlist_cnt (nullable; counter zeroed): the heads of the groups of two and more hits, for launch_ungap2; without them those
 // groups are launch_ungap's (skip_single)
-void launch_ungap1(u32 ncu, int variant, u32 pmaxq, const u32* words, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, const KeyLayout& klr,
+#define U1_WAIT 4u   // k_ungap1 / k_ungap2: idle lanes that trigger a hand-out
+void launch_ungap1(u32 ncu, u32 pmaxq, const u32* words, const u32* bext, u32 nb, const BktLayout& L, const KeyLayout& kl, const KeyLayout& klr,
                    const void* btab, u32 wait_n, const u8* q_scls, const u32* qoff, const u8* r_ug, const u32* roff, const signed char* b62g, u32* work_ctr /*zeroed*/,
                    u32* shard_cnt, u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, u64* mlist, u32* mlist_cnt,
                    unsigned long long* stat /*nullable: [0] += b62 lookups, [1] += singleton groups*/, hipStream_t st);

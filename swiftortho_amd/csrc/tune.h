@@ -10,15 +10,8 @@
     /* ---- ungapped extension ---- */                                                                                                                          \
     X(B, ug1, "SOHIT_UG1", 1, "bucketed passes: singleton groups to k_ungap1 (0: everything to k_ungap)")                                                     \
     X(B, ug1_chain, "SOHIT_UG1_CHAIN", 1, "... and the groups of two and more hits to k_ungap2 (0: to k_ungap, which then skips the singletons)")              \
-    X(I, ug1_variant, "SOHIT_UG1_VARIANT", 2, "k_ungap1: 0 = 32-bit table entries, 1 = 16-bit, 2 = 16-bit and two workgroups per CU where the queries fit")     \
-    X(I, ug1_wait, "SOHIT_UG1_WAIT", 4, "k_ungap1 / k_ungap2: idle lanes that trigger a hand-out")                                                           \
-    X(B, ug1_overlap, "SOHIT_UG1_OVERLAP", 0, "k_ungap (chains, SOHIT_UG1_CHAIN=0) on a second stream beside k_ungap1")                                        \
     X(B, count_steps, "SOHIT_UG_COUNT", 0, "counting instances of the extension kernels: so_counters.ungap_steps, groups_single, groups_chain")                \
     X(B, ug_w32, "SOHIT_UG_W32", 1, "bucketed passes hand k_ungap the buckets' 32-bit words (0: 64-bit keys; no k_ungap1 then)")                               \
-    X(I, ug_gallop, "SOHIT_UG_GALLOP", 1024, "k_ungap's GALLOP instance from this query length on")                                                           \
-    X(I, ug_cpi, "SOHIT_UG_CPI", 3, "k_ungap (sorted path): chunk steps per loop iteration (1, 2, 3)")                                                        \
-    X(I, ug_wait, "SOHIT_UG_WAIT", 20, "k_ungap: waiting lanes that trigger the bookkeeping section")                                                         \
-    X(I, ug_range, "SOHIT_UG_RANGE", 0, "k_ungap: head positions per wave (0: 4096, shorter for small passes)")                                               \
     /* ---- seed stage: which path a pass takes ---- */                                                                                                         \
     X(B, bucket, "SOHIT_BUCKET", 1, "bucketed diagonal binning (0: every pass on the sorted path)")                                                            \
     X(I, bucket_min, "SOHIT_BUCKET_MIN", 192, "hits per bucket below which a pass takes the sorted path (0: bucketed whenever possible)")                      \
@@ -28,37 +21,18 @@
     X(B, lk_wide, "SOHIT_LK_WIDE", 0, "8-byte index addends whatever the field widths")                                                                        \
     X(B, qclass, "SOHIT_QCLASS", 1, "queries of a batch in length-class order (0: file order)")                                                                \
     X(B, pass_merge, "SOHIT_PASS_MERGE", 1, "neighbouring length classes that take the sorted path anyway share one pass")                                     \
-    X(B, seg_aside, "SOHIT_SEG_ASIDE", 1, "SEG masking of queries above 4096 residues on the side stream beside the shorter ones")                              \
-    X(B, ksc_async, "SOHIT_KSC_ASYNC", 1, "k-mer order of queries above 4096 windows on a side stream")                                                        \
     X(I, segsort, "SOHIT_SEGSORT", 1, "sorted path: segmented sort of the keys inside each query (0: device-wide sort)")                                        \
-    X(I, lk_variant, "SOHIT_LK_VARIANT", 0, "ABLATION (1, 2: lookup timing only, results invalid): variants of k_lookup")                                      \
-    X(I, lk_iters, "SOHIT_LK_ITERS", 16, "k_lookup: hits per thread")                                                                                          \
     X(I, write_threads, "SOHIT_WRITE_THREADS", 48, "so_write_sc: formatter threads (at most the host's cores)")                                                                          \
-    X(B, bk_staged, "SOHIT_BK_STAGED", 1, "k_bkt_pass scatter staged through LDS (0: direct scatter)")                                                         \
-    X(B, bk_skew, "SOHIT_BK_SKEW", 1, "k_bkt_pass histogram copies skewed over the LDS banks")                                                                 \
-    X(I, bk_wpe, "SOHIT_BK_WPE", 6, "k_bkt_pass scatter: waves per SIMD the register budget is cut for (4, 5, 6)")                                             \
-    X(I, seg_cfg, "SOHIT_SEG_CFG", -1, "segmented key sort: kernel configuration (-1: by segment length)")                                                     \
-    X(I, cseg_cfg, "SOHIT_CSEG_CFG", -1, "segmented candidate sort: kernel configuration")                                                                     \
     /* ---- candidate order ---- */                                                                                                                             \
-    X(B, qbest, "SOHIT_QBEST", 1, "sparse passes: best diagonal and candidate order per query in LDS (0: sort of the pass records, k_best, k_cand_order_lds)") \
-    X(B, cand_order_lds, "SOHIT_CAND_ORDER_LDS", 1, "bucketed passes: candidate order by the hand-written per-query sort + gather (0: library segmented sort)")   \
-    X(B, cand_keys, "SOHIT_CAND_KEYS", 1, "candidate order as a keys-only segmented sort (0: pairs)")                                                          \
-    X(B, cand_segsort, "SOHIT_CAND_SEGSORT", 1, "candidate order sorted inside each query's segment (0: device-wide)")                                         \
-    X(B, cand_lds, "SOHIT_CAND_LDS", 1, "sparse path: a query's candidates ordered in LDS")                                                                    \
     X(I, cand_limit, "SOHIT_CAND_LIMIT", 0, "tests: candidate-store size at which a batch is split (0: 2^32 - 16)")                                            \
     /* ---- phase 2 ---- */                                                                                                                                     \
     X(B, align_pk, "SOHIT_ALIGN_PK", 1, "packed 16-bit score-only aligner where the scores fit")                                                               \
-    X(B, align_pk_trace, "SOHIT_ALIGN_PK_TRACE", 1, "... and the packed aligner for the traced alignments too (0: k_align<true>)")                               \
-    X(B, csort_aside, "SOHIT_CSORT_ASIDE", 1, "candidate lists above 4096 entries sorted (k_csort) on the side stream beside the LDS instances")               \
-    X(B, wide_aside, "SOHIT_WIDE_ASIDE", 1, "the 32-bit score-only aligner of a round's wide tasks on a second stream beside the packed one")                 \
     X(B, align_sort, "SOHIT_ALIGN_SORT", 1, "launch lists ordered by band rows")                                                                               \
-    X(B, trace_sort, "SOHIT_TRACE_SORT", 1, "trace pass lists ordered by band rows on mixed-length batches")                                                   \
     X(I, trace_wave_rows, "SOHIT_TRACE_WAVE_ROWS", 1024, "traceback: bands of this many rows and more are walked by a wave of their own (0: never)")         \
     X(I, trace_wave_max, "SOHIT_TRACE_WAVE_MAX", 32768, "... among the first this many positions of a launch list")                                            \
     X(I, spec, "SOHIT_SPEC", -1, "speculative traces in the first round: 0 off, 1 on, -1 from 2^21 tasks on")                                                  \
-    X(D, spec_slack, "SOHIT_SPEC_SLACK", 1e3, "... the guess tests the ungapped score against expect x this")                                                  \
+    X(D, spec_slack, "SOHIT_SPEC_SLACK", 1e3, "... the guess tests the ungapped score against expect x this (tests: 1e30 = every first-round task traced, 1e-30 = none)")          \
     X(I, spec_cap, "SOHIT_SPEC_CAP", -1, "tests: most speculative traces kept (-1: all)")                                                                      \
-    X(I, spec_parts, "SOHIT_SPEC_PARTS", 2, "row emission in this many parts when speculative traces exist")                                                   \
     X(I, emit_parts, "SOHIT_EMIT_PARTS", 4, "... and otherwise")                                                                                               \
     X(I, emit_min_rows, "SOHIT_EMIT_MIN_ROWS", 1 << 18, "rows below which the emission is one part")                                                           \
     X(P, test_oom_phase2, "SOHIT_TEST_OOM_PHASE2", 0, "tests: phase 2 of the first batch fails once with an out-of-memory error")                              \
@@ -67,7 +41,6 @@
     X(I, max_hits, "SOHIT_MAX_HITS", 0, "seed hits per pass (0: 2^30)")                                                                                        \
     X(I, poison, "SOHIT_POISON", -1, "tests: byte every fresh device allocation is filled with (-1: none)")                                                    \
     X(B, hit_cache, "SOHIT_HIT_CACHE", 1, "one released result array is kept for the next search")                                                             \
-    X(B, warm, "SOHIT_WARM", 1, "so_create starts a thread that loads the library sorts' code objects")                                                        \
     X(P, keep_cands, "SOHIT_KEEP_CANDS", 0, "tests: keep every query's candidate list (so_query_candidates)")                                                  \
     X(P, keep_masked, "SOHIT_KEEP_MASKED", 0, "tests: keep the masked queries (so_masked_query)")                                                              \
     /* ---- index ---- */                                                                                                                                       \

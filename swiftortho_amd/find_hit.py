@@ -155,9 +155,13 @@ def run_rank(p):
         # copy done by all ranks at once.  The RCCL record gather stays the exchange of so_search_device / bench.py.
         hits = s.search(lo, hi)   # hi == lo: no rows, still takes part in the exchange
         part = '%s.part%d' % (p['outfile'], rank)
-        hits.write(part, 'w')
-        hits.close()
-        place_parts(p['outfile'], part, rank, world, dist)
+        try:
+            hits.write(part, 'w')
+            hits.close()
+            place_parts(p['outfile'], part, rank, world, dist)
+        finally:
+            if os.path.exists(part):   # (a rank that failed on the way leaves no part file behind)
+                os.remove(part)
     finally:
         s.close()
         dist.destroy_process_group()
@@ -165,7 +169,9 @@ def run_rank(p):
 
 def place_parts(outfile, part, rank, world, dist):
     """The ranks' part files -> `outfile`, each copied to the offset its predecessors' sizes give (os.copy_file_range: no user-space
-    copy; plain reads / pwrites where the kernel or the file system lacks it); parts are removed."""
+    copy; plain reads / pwrites where the kernel or the file system lacks it); parts are removed.  All ranks must see ONE file system
+    (one node: find_hit.py's own part files + `cat` assume the same, find_hit.py:133-146), and the part and the output exist side by
+    side for the duration of the copy."""
     import torch
     n = os.path.getsize(part)
     sizes = torch.zeros(world, dtype=torch.int64)
@@ -197,6 +203,8 @@ def place_parts(outfile, part, rank, world, dist):
                     done += len(buf)
     os.remove(part)
     dist.barrier()
+    if rank == 0 and os.path.getsize(outfile) != sum(sizes):
+        raise IOError('%s holds %d bytes, the ranks wrote %d' % (outfile, os.path.getsize(outfile), sum(sizes)))
 
 
 def fasta_parse(f):

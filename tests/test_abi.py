@@ -71,7 +71,7 @@ def test_product_never_imports_the_oracle():
                 if f.endswith((".py", ".hip", ".h", ".cpp")):
                     txt = open(os.path.join(d, f), errors="ignore").read()
                     if re.search(r"^\s*(from|import)\s+oracle\b|liboracle|sohit_cpu|mcl_scipy_oracle|^\s*(from|import)\s+scipy", txt, flags=re.M):
-                        if f == "host.hip" and "oracle/" in txt:
+                        if f == "host.h" and "oracle/" in txt:
                             # the header comment forbids it; make sure there is no include/link
                             if not re.search(r"#include\s+\"[^\"]*oracle", txt):
                                 continue

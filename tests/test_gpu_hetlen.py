@@ -96,12 +96,11 @@ def test_generator_shape():
 
 @pytest.mark.parametrize("env", [{}, {"SOHIT_BUCKET_MIN": "0"}, {"SOHIT_BANDS": "0"}, {"SOHIT_QCLASS": "0"}, {"SOHIT_ALIGN_PK": "0"},
                                  {"SOHIT_BUCKET_MIN": "0", "SOHIT_BUCKET_BEST": "0"}, {"SOHIT_BUCKET_MIN": "0", "SOHIT_POISON": "0xFF"},
-                                 {"SOHIT_BATCH": "700", "SOHIT_BUCKET_MIN": "0", "SOHIT_MAX_HITS": "300000"}, {"SOHIT_KSC_ASYNC": "0"},
+                                 {"SOHIT_BATCH": "700", "SOHIT_BUCKET_MIN": "0", "SOHIT_MAX_HITS": "300000"},
                                  {"SOHIT_TRACE_WAVE_ROWS": "16", "SOHIT_TRACE_WAVE_MAX": "100000000", "SOHIT_POISON": "0x3C"},
-                                 {"SOHIT_ALIGN_PK_TRACE": "0"},
-                                 {"SOHIT_SEG_ASIDE": "0", "SOHIT_CSORT_ASIDE": "0", "SOHIT_WIDE_ASIDE": "0", "SOHIT_TRACE_WAVE_ROWS": "0"}],
+                                 {"SOHIT_TRACE_WAVE_ROWS": "0"}],
                          ids=["default", "bucket_forced", "no_bands", "no_classes", "no_packed", "bucket_sortbest", "poison", "small_batches",
-                              "kmer_order_on_main_stream", "every_walk_by_a_wave", "traced_alignments_32bit", "nothing_on_the_side_stream"])
+                              "every_walk_by_a_wave", "every_walk_by_a_thread"])
 def test_mixed_lengths_vs_oracle(fs, coracle, tmp_path, monkeypatch, env):
     """3000 proteins, median 277 residues, a tail to 5000 and one of 30 000: rows, candidate lists and counters equal the
     oracle's, whatever the path switches say."""

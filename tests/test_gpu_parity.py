@@ -232,7 +232,7 @@ def test_query_subrange_and_small_batches(fs, oracle, tmp_path, monkeypatch):
 
 
 def test_full_candidate_store_splits_the_batch(fs, oracle, tmp_path, monkeypatch):
-    """A batch whose 32-bit candidate store would overflow is run again as two halves (host.hip run_batch).  SOHIT_CAND_LIMIT lowers
+    """A batch whose 32-bit candidate store would overflow is run again as two halves (host_search.hip run_batch).  SOHIT_CAND_LIMIT lowers
     the limit from 2^32 so that the first attempt -- and the first halves -- overflow: rows, candidates and counters are unchanged;
     a limit below one query's own candidates is an error, not a loop."""
     from swiftortho_amd import synthprot
@@ -251,7 +251,7 @@ def test_full_candidate_store_splits_the_batch(fs, oracle, tmp_path, monkeypatch
 
 @pytest.mark.parametrize("parts", [3, 8])
 def test_rows_leave_in_query_ranges(fs, oracle, tmp_path, monkeypatch, parts):
-    """Large results are traced, written and downloaded in several query ranges (host.hip phase2, SOHIT_EMIT_PARTS); forced here on a
+    """Large results are traced, written and downloaded in several query ranges (host_phase2.hip phase2, SOHIT_EMIT_PARTS); forced here on a
     small input (SOHIT_EMIT_MIN_ROWS=1), with more ranges than some batches have queries, several batches, and queries without rows."""
     from swiftortho_amd import synthprot
     monkeypatch.setenv("SOHIT_EMIT_PARTS", str(parts))
@@ -265,9 +265,9 @@ def test_rows_leave_in_query_ranges(fs, oracle, tmp_path, monkeypatch, parts):
 
 @pytest.mark.parametrize("env", [{"SOHIT_SPEC": "0"}, {"SOHIT_SPEC": "1", "SOHIT_SPEC_SLACK": "1e30"}, {"SOHIT_SPEC": "1", "SOHIT_SPEC_SLACK": "1e-30"},
                                  {"SOHIT_SPEC": "1", "SOHIT_SPEC_CAP": "50"}, {"SOHIT_SPEC": "1"},
-                                 {"SOHIT_SPEC": "1", "SOHIT_SPEC_SLACK": "1e4", "SOHIT_SPEC_PARTS": "3", "SOHIT_EMIT_MIN_ROWS": "1"}])
+                                 {"SOHIT_SPEC": "1", "SOHIT_SPEC_SLACK": "1e4", "SOHIT_EMIT_MIN_ROWS": "1"}])
 def test_speculative_traces_do_not_change_rows(fs, oracle, tmp_path, monkeypatch, env):
-    """First-round tasks whose ungapped score alone would pass the e-value test are aligned WITH traces at once (host.hip phase2,
+    """First-round tasks whose ungapped score alone would pass the e-value test are aligned WITH traces at once (host_phase2.hip phase2,
     k_round_counts_spec); reported rows that have a trace skip the second alignment.  Rows are the oracle's with the guess switched
     off, with every first-round task traced, with none, with a trace budget the first round does not fit (the round is redone without
     traces), and together with the ranged row emission; long candidates (tiled alignments) included."""

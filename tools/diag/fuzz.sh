@@ -1,6 +1,6 @@
 #!/bin/bash
 # randomised GPU-vs-oracle differentials (tools/diag/fuzz_parity.py) under the path switches that matter:
-#   bash tools/diag/fuzz.sh <cases per mode> <seed> [modes...]      modes: default bucket poison long het hetbucket w64 nobands noug1 nochain ug1v0 ug1v1 wavetb longwave nopktrace
+#   bash tools/diag/fuzz.sh <cases per mode> <seed> [modes...]      modes: default bucket poison long het hetbucket w64 nobands noug1 nochain wavetb longwave
 N=${1:-30}; SEED=${2:-1}; shift; shift
 MODES=${@:-default bucket het hetbucket}
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
@@ -16,11 +16,8 @@ for m in $MODES; do
     nobands)   E="FUZZ_HET=1 SOHIT_BUCKET_MIN=0 SOHIT_BANDS=0";;
     noug1)     E="FUZZ_HET=1 SOHIT_BUCKET_MIN=0 SOHIT_UG1=0";;
     nochain)   E="SOHIT_BUCKET_MIN=0 SOHIT_UG1_CHAIN=0";;
-    ug1v0)     E="FUZZ_HET=1 SOHIT_BUCKET_MIN=0 SOHIT_UG1_VARIANT=0 SOHIT_UG1_WAIT=1";;
-    ug1v1)     E="SOHIT_BUCKET_MIN=0 SOHIT_UG1_VARIANT=1 SOHIT_UG1_WAIT=24 SOHIT_POISON=0x5A";;
     wavetb)    E="FUZZ_HET=1 SOHIT_TRACE_WAVE_ROWS=16 SOHIT_TRACE_WAVE_MAX=100000000 SOHIT_POISON=0x3C";;   # every walk by a wave
     longwave)  E="FUZZ_LONG=1 SOHIT_TRACE_WAVE_ROWS=16 SOHIT_TRACE_WAVE_MAX=100000000";;
-    nopktrace) E="FUZZ_HET=1 SOHIT_ALIGN_PK_TRACE=0 SOHIT_SEG_ASIDE=0 SOHIT_CSORT_ASIDE=0 SOHIT_WIDE_ASIDE=0";;
   esac
   env $E python3 tools/diag/fuzz_parity.py $N $SEED > gpurun_out/fuzz_$m.log 2>&1
   echo "$m rc=$? ok=$(grep -c ' ok ' gpurun_out/fuzz_$m.log) fail=$(grep -c FAIL gpurun_out/fuzz_$m.log)"
