@@ -146,6 +146,11 @@ struct ChunkIndex {
         DevBuf<u32> dk32, gbase; // E addends; per chunk sequence: (first band << k) + (C or, for a multi-band subject, its length)
         DevBuf<u64> btab;        // nband x (chunk sequence | gbase << 32)
         u64 used = 0;
+        // the index was rebuilt (so_drop_index + so_build_index) over the same sequences: layout, gbase and btab -- functions of the sequence
+        // lengths alone -- still hold, only the entries' addends are encoded again
+        bool stale = false;
+        u64 ref_gen = 0;
+        i64 seq_lo = -1, seq_hi = -1;
     };
     std::vector<std::unique_ptr<BandEnc>> encs;
     u64 enc_clock = 0;
@@ -177,6 +182,7 @@ struct so_ctx {
     std::string ref_path;   // file the reference was read from ("" when it came from memory) and its size / mtime then
     long long ref_fsize = -1, ref_mtime_ns = -1;
     bool ref_loaded = false, qry_loaded = false, index_built = false;
+    u64 ref_gen = 0;        // bumped by every reference load
     // band_plan()'s answers: a function of a chunk's sequence lengths only, so they outlive index rebuilds (cleared with the reference)
     struct BandPlan { i64 lo, hi; int bp; bool multi_ok; int k; u64 nband; };
     std::vector<BandPlan> band_plans;

@@ -82,10 +82,10 @@ void build_index(so_ctx* c) {
     for (i64 s = Start; s < End; s += c->chunk) {
         std::unique_ptr<ChunkIndex> ch;
         if (!c->spare_chunks.empty()) {
-            ch = std::move(c->spare_chunks.back());
-            c->spare_chunks.pop_back();
+            ch = std::move(c->spare_chunks.front());   // (in order: chunk k gets chunk k's object back, with its band layouts)
+            c->spare_chunks.erase(c->spare_chunks.begin());
             ch->d_sh_subj = ch->d_sh_diag = -1;  // key addends belong to the old entries
-            for (auto& e : ch->encs) e->k = -1;
+            for (auto& e : ch->encs) e->stale = true;   // (band_encoding re-encodes the entries; the layout survives when the sequences are the same)
         } else {
             ch = std::make_unique<ChunkIndex>();
         }
@@ -411,8 +411,15 @@ void band_plan(so_ctx* c, ChunkIndex& ch, int bp, bool multi_ok, int* k_out, u64
 ChunkIndex::BandEnc* band_encoding(so_ctx* c, ChunkIndex& ch, int ba, int bp, bool multi_ok) {
     ++ch.enc_clock;
     for (auto& e : ch.encs)
+        if (e->stale && (e->ref_gen != c->ref_gen || e->seq_lo != ch.seq_lo || e->seq_hi != ch.seq_hi)) e->k = -1, e->stale = false;   // other sequences: nothing to keep
+    for (auto& e : ch.encs)
         if (e->k >= 0 && e->ba == ba && e->bp == bp && e->multi_ok == multi_ok) {
             e->used = ch.enc_clock;
+            if (e->stale && e->k > 0) {   // same sequences, new entries: the addends alone (no host loop, no upload, no round trip)
+                e->dk32.ensure((size_t)ch.E + 4);
+                launch_encode_band32(ch.entries.p, ch.E, ba, e->gbase.p, c->ref.d_off.p + ch.seq_lo, e->dk32.p, c->st);
+            }
+            e->stale = false;
             return e->k == 0 ? nullptr : e.get();   // k == 0: "does not fit" remembered
         }
     const u32 nseq = (u32)(ch.seq_hi - ch.seq_lo);
@@ -434,6 +441,7 @@ ChunkIndex::BandEnc* band_encoding(so_ctx* c, ChunkIndex& ch, int ba, int bp, bo
             if (x->used < e->used) e = x.get();
     }
     e->ba = ba, e->bp = bp, e->multi_ok = multi_ok, e->used = ch.enc_clock;
+    e->stale = false, e->ref_gen = c->ref_gen, e->seq_lo = ch.seq_lo, e->seq_hi = ch.seq_hi;
     if (ceil_log2(std::max<u64>(nband, 2)) + k + ba > 31) {
         e->k = 0;
         return nullptr;

@@ -324,6 +324,7 @@ void load_ref_common(so_ctx* c, i64 r_lo, i64 r_hi) {
     upload_set(c, c->ref, c->ref.res.data(), c->ref.off, (u32)c->ref.N);   // (ends with a stream synchronisation)
     c->lt["load.ref_parse"] = (t1 - t0) * 1e3, c->lt["load.ref_h2d_layout"] = (wall() - t1) * 1e3;
     c->ref_loaded = true;
+    ++c->ref_gen;
     c->band_plans.clear();
     c->index_built = false;
     c->chunks.clear();

@@ -125,6 +125,8 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     const bool pk_on = tune().align_pk && align_pk_supported(c->st);
     const bool pk_mixed = pk_on && (int)std::min(maxwin_q, maxwin_s) > align_pk_max_len();
     const PkCls pkc{b.dev.d_pcls.p, b.dev.d_pcls4.p, c->ref.d_pcls.p, c->ref.d_pcls4.p};
+    // score-only rounds by k_align_lane (a lane per alignment pair) when every task's windows end where its sequences end: no tiles
+    const bool lane_on = pk_on && tune().align_lane && b.maxqlen < LONG_SEQ && c->ref.maxlen < LONG_SEQ;
     const bool traced_pk = pk_on;   // traced alignments by the packed kernel too (k_align<true> keeps the tasks whose scores need 32-bit cells)
     auto sort_by_rows = [&](const u32* list, u32 n, u32* n_wide) -> const u32* {
         const bool split = n_wide && pk_mixed;
@@ -256,8 +258,14 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                 launch_align(b.tasks.p, rlist, n_wide, b.dev.d_res.p, b.dev.d_scls.p, b.dev.d_scls4.p, b.dev.d_off.p, c->ref.d_res.p, c->ref.d_scls.p,
                              c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, nullptr, b.ares.p, false, wst, 0u);
             if (wide_aside) HIP_CHECK(hipEventRecord(c->ev_ug_done, c->st_side));
-            if (NR > n_wide)
-                launch_align_pk(b.tasks.p, rlist + n_wide, NR - n_wide, pkc, b.dev.d_off.p, c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->st);
+            if (NR > n_wide) {
+                if (lane_on) {
+                    c->d_small.ensure(16);
+                    launch_align_lane(b.tasks.p, rlist + n_wide, NR - n_wide, pkc, b.dev.d_off.p, c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->d_small.p + 13, c->ncu, c->st);
+                } else {
+                    launch_align_pk(b.tasks.p, rlist + n_wide, NR - n_wide, pkc, b.dev.d_off.p, c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->st);
+                }
+            }
             if (wide_aside) HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_ug_done, 0));
             pt.stop();
             c->cnt.align_wide += n_wide;

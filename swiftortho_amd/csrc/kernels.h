@@ -161,6 +161,9 @@ void launch_trace_units(const AlnTask* tasks, const u32* ridx, u32 n, const u32*
 bool align_pk_supported(hipStream_t st);   // the d16 load behaviour k_align_pk relies on (probed once per process)
 int align_pk_max_len();   // largest min(rows, columns) it can score whatever the residues
 u32 align_pk_max_score(); // largest alignment score its cells hold
+// one lane per alignment pair, score-only, persistent waves (k_alignl.hip): tasks whose windows end where their sequences end
+void launch_align_lane(const AlnTask* tasks, const u32* ridx, u32 ntasks, PkCls pk, const u32* qoff, const u32* roff, const signed char* b62g, AlnRes* out,
+                       u32* work_ctr, u32 ncu, hipStream_t st);
 void launch_align_pk(const AlnTask* tasks, const u32* ridx, u32 ntasks, PkCls pk, const u32* qoff, const u32* roff, const signed char* b62g, AlnRes* out,
                      hipStream_t st);
 

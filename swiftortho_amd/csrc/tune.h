@@ -27,6 +27,7 @@
     X(I, cand_limit, "SOHIT_CAND_LIMIT", 0, "tests: candidate-store size at which a batch is split (0: 2^32 - 16)")                                            \
     /* ---- phase 2 ---- */                                                                                                                                     \
     X(B, align_pk, "SOHIT_ALIGN_PK", 1, "packed 16-bit score-only aligner where the scores fit")                                                               \
+    X(B, align_lane, "SOHIT_ALIGN_LANE", 1, "score-only rounds: one lane per alignment pair (k_align_lane) when no sequence reaches 4096 residues (0: k_align_pk)")            \
     X(B, align_sort, "SOHIT_ALIGN_SORT", 1, "launch lists ordered by band rows")                                                                               \
     X(I, trace_wave_rows, "SOHIT_TRACE_WAVE_ROWS", 1024, "traceback: bands of this many rows and more are walked by a wave of their own (0: never)")         \
     X(I, trace_wave_max, "SOHIT_TRACE_WAVE_MAX", 32768, "... among the first this many positions of a launch list")                                            \
