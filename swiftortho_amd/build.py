@@ -18,7 +18,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-SOURCES = ["k_util.hip", "k_sort.hip", "k_sortseg.hip", "k_prep.hip", "k_index.hip", "k_ixsort.hip", "k_seed.hip", "k_group.hip", "k_ungap1.hip", "k_bucket.hip", "k_align.hip", "k_align16.hip", "k_alignl.hip", "k_phase2.hip", "mcl.hip",
+SOURCES = ["k_util.hip", "k_sort.hip", "k_sortseg.hip", "k_prep.hip", "k_index.hip", "k_ixsort.hip", "k_seed.hip", "k_group.hip", "k_ungap1.hip", "k_ungapq.hip", "k_bucket.hip", "k_align.hip", "k_align16.hip", "k_alignl.hip", "k_phase2.hip", "mcl.hip",
            "tsv.hip", "host_load.hip", "host_index.hip", "host_seed.hip", "host_phase2.hip", "host_search.hip", "host_abi.hip"]
 # -ffp-contract=off: host-side SEG/threshold arithmetic must round exactly like the reference's
 # (no fused multiply-add), and device fp64 compares stay IEEE.

@@ -484,15 +484,40 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
 
     // ---- the sorted path: 8-byte keys, segmented radix sort by (subject, diagonal), group walk over the sorted keys ----
     auto group_sorted = [&] {
+    b.keys.ensure((size_t)H + 2), b.keys2.ensure((size_t)H + 2);
+    const u32 nseg = qb - qa;
+    // Sparse passes of short queries (one alphabet x one pattern, compact addends): the hits that are ALONE on their diagonal -- about half
+    // of them -- are found and extended by k_ungapq, a wave per query, without a key being written for them; the rest are written as
+    // k_lookup's keys into an array of all-ones (= dropped) and take the sort + k_ungap below.
+    const bool uq = tune().ungapq && tune().segsort && AS == 1 && compact && !ft_walk && UG_SHARDS == 1 && pmaxq <= ungapq_qcap() && nseg >= 256;
+    if (uq || nseg >= 256) {
+        b.qseg.ensure((size_t)b.nq + 4);
+        launch_query_segments(b.hoff.p, b.dev.d_off.p, qa, qb, AS, H, b.qseg.p, c->st);
+    }
+    if (uq) {
+        if (!c->ref.ug_valid) {
+            const size_t nres = c->ref.res.size();
+            c->ref.d_ug_store.ensure(nres + 2 * (size_t)U1_UG_PAD);
+            launch_make_ug(c->ref.d_scls.p, c->ref.d_off.p, (u32)c->ref.N, nres, 8u, c->ref.d_ug_store.p + U1_UG_PAD, c->st);
+            c->ref.ug_valid = true;
+        }
+        b.blk_first.ensure((size_t)nseg + 4), b.flags.ensure((size_t)nseg + 4);
+        ProfTimer pt(c, &c->cnt.lookup_ms, &c->cnt.lookup_launches);
+        launch_ungapq(c->ncu, b.qseg.p + qa, nseg, qa, b.blk_first.p, b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, K, dk32, kl, klr, btab, b.dev.d_scls.p, b.dev.d_off.p,
+                      c->ref.d_ug_store.p + U1_UG_PAD, c->ref.d_off.p + ch.seq_lo, c->d_b62c.p, b.bflag.p + 1, b.shard.p, b.p_qs.p, b.p_sd.p, b.p_ft.p, b.stepshard.p,
+                      b.keys.p, b.keys2.p, b.flags.p, ugstat, c->st);
+        pt.stop();
+        if (c->profile) c->cnt.lookup_bytes += (i64)8 * (i64)H;
+    } else {
     b.blk_first.ensure((size_t)lookup_num_blocks(H) + 2);
     launch_lookup_blockfirst(b.cs_hoff.p, K, H, b.blk_first.p, c->st);
-    b.keys.ensure((size_t)H + 2), b.keys2.ensure((size_t)H + 2);
     {
         ProfTimer pt(c, &c->cnt.lookup_ms, &c->cnt.lookup_launches);
         launch_lookup(b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, b.blk_first.p, K, H, compact ? (const void*)dk32 : (const void*)ch.dkeys.p,
                       compact, c->ref.d_off.p + ch.seq_lo, kl, ch.maxslen, b.keys.p, c->st);
         pt.stop();
         if (c->profile) c->cnt.lookup_bytes += (i64)8 * (i64)H;
+    }
     }
     t1 = wall();
     sc.lap("seed.compact_lookup");
@@ -502,12 +527,10 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     // passes with few queries (huge per-query hit lists) use the device-wide sort instead.
     // (Dropped hits carry ~0 and sort last in their segment.)
     const int seg_mode = (int)tune().segsort;
-    const u32 nseg = qb - qa;
     if (seg_mode && nseg >= 256) {
-        b.qseg.ensure((size_t)b.nq + 4);
-        launch_query_segments(b.hoff.p, b.dev.d_off.p, qa, qb, AS, H, b.qseg.p, c->st);
         ensure_sort_tmp(c, sort_keys_u64_seg_temp_bytes(H, nseg, kl.sh_diag, kl.sh_q));
-        sort_keys_u64_seg(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.keys.p, b.keys2.p, H, nseg, b.qseg.p + qa, kl.sh_diag, kl.sh_q, c->st);
+        if (uq) sort_keys_u64_seg2(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.keys.p, b.keys2.p, H, nseg, b.qseg.p + qa, b.flags.p, kl.sh_diag, kl.sh_q, c->st);
+        else sort_keys_u64_seg(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.keys.p, b.keys2.p, H, nseg, b.qseg.p + qa, kl.sh_diag, kl.sh_q, c->st);
     } else {
     ensure_sort_tmp(c, sort_keys_u64_temp_bytes(H, kl.total));
     sort_keys_u64(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.keys.p, b.keys2.p, H, kl.sh_diag, kl.total, c->st);

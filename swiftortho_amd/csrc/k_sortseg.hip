@@ -57,6 +57,11 @@ void sort_keys_u64_seg(void* temp, size_t temp_bytes, const u64* in, u64* out, s
     if (n == 0) return;
     HIP_CHECK(seg_sort_dispatch(temp, temp_bytes, in, out, n, nseg, seg, seg + 1, begin_bit, end_bit, st));
 }
+void sort_keys_u64_seg2(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* seg_begin, const u32* seg_end, int begin_bit,
+                        int end_bit, hipStream_t st) {
+    if (n == 0) return;
+    HIP_CHECK(seg_sort_dispatch(temp, temp_bytes, in, out, n, nseg, seg_begin, seg_end, begin_bit, end_bit, st));
+}
 
 // ---- keys-only variant for the candidate order of a bucketed pass (the position rides in the low bits of the sort word) ----------
 // NOTE end_bit must stay below 64: rocPRIM's comparator for short segments builds its mask as (1 << (begin + bits)) - 1, which for

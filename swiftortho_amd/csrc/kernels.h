@@ -17,6 +17,9 @@ void launch_query_segments(const u32* hoff, const u32* qoff, u32 qa, u32 qb, int
 size_t sort_keys_u64_seg_temp_bytes(size_t n, u32 nseg, int begin_bit, int end_bit);
 void sort_keys_u64_seg(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* seg, int begin_bit,
                        int end_bit, hipStream_t st);
+// ... with the segments' ends given apart from their starts (seg_end[k] <= seg_begin[k + 1]: what lies between is not touched)
+void sort_keys_u64_seg2(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* seg_begin, const u32* seg_end, int begin_bit,
+                        int end_bit, hipStream_t st);
 void launch_stride_gather(const u32* src, u32 stride, u32 n, u32* dst, hipStream_t st);   // dst[i] = src[i * stride]
 size_t sort_pairs_u64_u32_temp_bytes(size_t n, int bits);
 void sort_pairs_u64_u32(void* temp, size_t temp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, size_t n, int bits,
@@ -114,6 +117,12 @@ void launch_ungap1(u32 ncu, u32 pmaxq, const u32* words, const u32* bext, u32 nb
                    const void* btab, u32 wait_n, const u8* q_scls, const u32* qoff, const u8* r_ug, const u32* roff, const signed char* b62g, u32* work_ctr /*zeroed*/,
                    u32* shard_cnt, u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, u64* mlist, u32* mlist_cnt,
                    unsigned long long* stat /*nullable: [0] += b62 lookups, [1] += singleton groups*/, hipStream_t st);
+// sparse passes, a wave per query (k_ungapq.hip): hits alone on their diagonal extended at once, the others written as k_lookup's keys
+u32 ungapq_qcap();
+void launch_ungapq(u32 ncu, const u32* qseg, u32 nqp, u32 qa, u32* qk, const u32* cs_hoff, const u32* cs_base, const u64* cs_kbase, u32 K, const u32* dk32,
+                   const KeyLayout& kl, const KeyLayout& klr, const void* btab, const u8* q_scls, const u32* qoff, const u8* r_ug, const u32* roff, const signed char* b62g,
+                   u32* work_ctr, u32* shard_cnt, u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, u64* keys, u64* keys_sorted, u32* seg_end,
+                   unsigned long long* stat, hipStream_t st);
 void launch_ungap2(u32 ncu, const u64* mlist, const u32* mlist_cnt, const u32* words, const u32* bext, const BktLayout& L, const KeyLayout& kl, const KeyLayout& klr,
                    const void* btab, u32 wait_n, const u8* q_ug, const u32* qoff, const u8* r_ug, const u32* roff, const signed char* b62g, u32* work_ctr /*zeroed*/,
                    u32* shard_cnt, u64* p_qs, u64* p_sd, u64* p_ft, unsigned long long* group_count, unsigned long long* stat /*nullable: [0], [2] += chained groups*/,

@@ -11,6 +11,7 @@
     X(B, ug1, "SOHIT_UG1", 1, "bucketed passes: singleton groups to k_ungap1 (0: everything to k_ungap)")                                                     \
     X(B, ug1_chain, "SOHIT_UG1_CHAIN", 1, "... and the groups of two and more hits to k_ungap2 (0: to k_ungap, which then skips the singletons)")              \
     X(B, count_steps, "SOHIT_UG_COUNT", 0, "counting instances of the extension kernels: so_counters.ungap_steps, groups_single, groups_chain")                \
+    X(B, ungapq, "SOHIT_UNGAPQ", 1, "sparse passes of queries up to 512 residues: hits alone on their diagonal by k_ungapq, a wave per query (0: every hit through the sorted keys)")     \
     X(B, ug_w32, "SOHIT_UG_W32", 1, "bucketed passes hand k_ungap the buckets' 32-bit words (0: 64-bit keys; no k_ungap1 then)")                               \
     /* ---- seed stage: which path a pass takes ---- */                                                                                                         \
     X(B, bucket, "SOHIT_BUCKET", 1, "bucketed diagonal binning (0: every pass on the sorted path)")                                                            \
