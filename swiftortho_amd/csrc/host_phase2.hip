@@ -259,7 +259,9 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                              c->ref.d_scls4.p, c->ref.d_off.p, c->d_b62c.p, nullptr, stride, nullptr, b.ares.p, false, wst, 0u);
             if (wide_aside) HIP_CHECK(hipEventRecord(c->ev_ug_done, c->st_side));
             if (NR > n_wide) {
-                if (lane_on) {
+                // (a lane walks a whole alignment alone: a launch lasts at least one alignment's ~0.4 ms however few tasks it holds -- the last
+                // rounds of config 3, 6.6 k and 64 tasks, took 0.63 and 0.40 ms; sixteen lanes per pair finish those in 0.1)
+                if (lane_on && NR - n_wide >= (1u << 18)) {
                     c->d_small.ensure(16);
                     launch_align_lane(b.tasks.p, rlist + n_wide, NR - n_wide, pkc, b.dev.d_off.p, c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->d_small.p + 13, c->ncu, c->st);
                 } else {
