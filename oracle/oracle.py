@@ -250,6 +250,59 @@ class Result:
             self.h = None
 
 
+class MergedResult:
+    """The Results of consecutive query ranges behind Result's interface (blastp_parallel)."""
+
+    def __init__(self, parts):
+        self.parts = parts
+        self.ints = np.vstack([p.ints for p in parts]) if parts else np.zeros((0, 13), dtype=np.int64)
+        self.dbl = np.vstack([p.dbl for p in parts]) if parts else np.zeros((0, 2), dtype=np.float64)
+        self.stats = {}
+        for p in parts:
+            for k, v in p.stats.items():
+                self.stats[k] = self.stats.get(k, 0) + v
+        self._first = np.cumsum([0] + [p.nqueries for p in parts])
+
+    def cands(self, qrel):
+        k = int(np.searchsorted(self._first, qrel, side="right")) - 1
+        return self.parts[k].cands(qrel - int(self._first[k]))
+
+    @property
+    def nqueries(self):
+        return int(self._first[-1])
+
+
+def blastp_parallel(qry, ref, out_path="", threads=0, st=-1, ed=-1, min_piece=64, **kw):
+    """blastp() with the query range cut into consecutive pieces, one thread each (ctypes releases the GIL; every piece indexes the
+    reference itself, as every find_hit.py block does): same rows, records, candidate lists and counters as one call -- per-query
+    results do not depend on the range (find_hit.py:107-146 relies on that).  Test infrastructure for the hosts with many cores."""
+    import concurrent.futures
+    import os
+    data = open(qry, "rb").read()
+    n = data.count(b"\n>") + (1 if data[:1] == b">" else 0)
+    nref = n if ref == qry else None
+    if nref is None:
+        d2 = open(ref, "rb").read()
+        nref = d2.count(b"\n>") + (1 if d2[:1] == b">" else 0)
+    lo = min(max(0, st), n)
+    hi = min(nref if ed < 0 else ed, n)
+    threads = threads or min(32, os.cpu_count() or 1)
+    k = max(1, min(threads, (hi - lo) // max(1, min_piece)))
+    if k == 1 or kw.get("mode", "w") != "w":
+        return blastp(qry, ref, out_path, st=st, ed=ed, **kw)
+    lib().oc_b62(65, 65)   # (the score table is filled by its first user: not from several threads at once)
+    cuts = [lo + (hi - lo) * i // k for i in range(k + 1)]
+    outs = ["%s.part%d" % (out_path, i) if out_path else "" for i in range(k)]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=k) as ex:
+        parts = list(ex.map(lambda i: blastp(qry, ref, outs[i], st=cuts[i], ed=cuts[i + 1], **kw), range(k)))
+    if out_path:
+        with open(out_path, "wb") as f:
+            for o in outs:
+                f.write(open(o, "rb").read())
+                os.remove(o)
+    return MergedResult(parts)
+
+
 def blastp(qry, ref, out_path="", ssd="111111", nr=AA9, expect=1e-3, v=500, max_miss=1e-3, st=-1, ed=-1, rst=-1, red=-1,
            thr=-1, step=1, flt="T", ht=120000000, chk=50000, mode="w"):
     """End-to-end reference path for queries [st, ed) (fsearch.py blastp + entry_point)."""

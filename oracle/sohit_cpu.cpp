@@ -923,7 +923,7 @@ int blastp(const char* qry, const char* ref, const Params& p0, FILE* out, Stats&
     const i64 N = seqs.N, D = DB.N;
     i64 st = std::min<i64>(std::max<i64>(0, p.st), N);
     i64 ed = std::min<i64>(p.ed < 0 ? D : p.ed, N);
-    static Mats* mats = nullptr;
+    static thread_local Mats* mats = nullptr;   // (per thread: oracle.blastp_parallel runs query ranges side by side)
     if (!mats) mats = new Mats();
     std::vector<std::vector<Cand>> KDB((size_t)std::max<i64>(0, ed - st));
     std::vector<std::string> masked((size_t)std::max<i64>(0, ed - st));

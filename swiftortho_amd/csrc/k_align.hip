@@ -189,13 +189,13 @@ __global__ __launch_bounds__(256) void k_align(const AlnTask* __restrict__ tasks
             // per bit; invalid cells shift in zeros
             if (TRACE) tw = shl1_in(shl1_in(shl1_in(shl1_in(tw, to1), to0), te1), te0);
         }
-        // Trace words are laid out by ITERATION, not by row: word [(m >> 3) - 1][lane] holds the lane's cells of iterations
+        // Trace words are laid out by ITERATION, not by row: word TRACE_WORD((m >> 3) - 1, lane) (kernels.h) holds the lane's cells of iterations
         // 8 (m >> 3) .. + 7, iteration m in nibble 7 - (m & 7) -- so all lanes store together, every second group (a row-aligned
         // layout has two lanes of every row storing in EVERY iteration: a masked store sequence per iteration, 40 of the 158
         // VALU of a traced group).  A lane's last group may end half a word: stored left-aligned.
         if (TRACE) {
             const bool full = (m0 & 4) != 0;
-            if (full || m0 + 4 > m_end) tr[(u32)((m0 >> 3) - 1) * 16u + (u32)l] = full ? tw : (tw << 16);
+            if (full || m0 + 4 > m_end) tr[TRACE_WORD((m0 >> 3) - 1, l)] = full ? tw : (tw << 16);
             if (full) tw = 0;
         }
     };
@@ -282,6 +282,12 @@ __global__ __launch_bounds__(64) void k_traceback(const AlnTask* __restrict__ ta
     traceback_one<false>(tid, tasks, ridx, q_res, qoff, r_res, roff, trace, trace_stride, tpos, tofs, out, nw, wrows);
 }
 
+__device__ __forceinline__ uint4 u1_load16g(const u8* p) {   // unaligned 16-byte global load
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
 template <bool WAVE>
 __device__ __forceinline__ void traceback_one(const u32 tid, const AlnTask* __restrict__ tasks, const u32* __restrict__ ridx,
                                               const u8* __restrict__ q_res, const u32* __restrict__ qoff, const u8* __restrict__ r_res,
@@ -316,7 +322,7 @@ __device__ __forceinline__ void traceback_one(const u32 tid, const AlnTask* __re
             int tcl = 0;
             if (inband && it > 0 && jt > 0) {
                 const int m = it + (d >> 1);
-                tcl = (int)((tr[((m >> 3) - 1) * 16 + (d >> 1)] >> (((7 - (m & 7)) << 2) + ((d & 1) << 1))) & 3u);
+                tcl = (int)((tr[TRACE_WORD((m >> 3) - 1, d >> 1)] >> (((7 - (m & 7)) << 2) + ((d & 1) << 1))) & 3u);
                 tcl ^= (tcl & tagged) << 1;
             }
             const int a0l = jt > 0 ? (int)craw[jt - 1] : (int)'-', a1l = it > 0 ? (int)rraw[it - 1] : (int)'-';
@@ -364,87 +370,72 @@ __device__ __forceinline__ void traceback_one(const u32 tid, const AlnTask* __re
     // the machine from its start: f_s = openings counted from the current column to the end if the machine enters it in
     // state s; three counters, updated per column, and the answer is f(-1) at the first column.
     int i = bi, j = bj, AL = 0, matches = 0, fm1 = 0, f0 = 0, f1 = 0;
-    int wkey = -1;  // (8-row block, lane) of the cached trace word
-    u32 wv = 0;
-    // residues through 8-byte register windows (one load per 8 steps instead of one per step: the walk is a chain of dependent
-    // loads at one wave per SIMD); the residue arrays are padded, so a window may reach past its sequence
-    int cwin = -1, rwin = -1;
-    u64 cw8 = 0, rw8 = 0;
-    // The 64 walks of a wave run in lockstep but reach their 8-step boundaries (next trace word, next residue windows) at different
-    // steps, so a wave that fetched on demand paid a memory round trip in nearly EVERY step, not every eighth (2.4 ms per config-3
-    // step for 1.6 M walks).  Every eighth step ALL lanes therefore request, together, what they may need before the next such step:
-    // the current items if missing and the ones behind them (same lane, previous block of 8 iterations; previous 8 residues); a lane
-    // crosses at most one boundary of each kind in 8 steps, so a boundary finds its word parked in a register.  Only a gap column,
-    // which moves the walk to another lane's words, still fetches on demand.
-    int nkey = -2, pcwin = -2, prwin = -2;
-    u32 nv = 0, step = 0;
-    u64 pcw8 = 0, prw8 = 0;
-    while (i > 0 || j > 0) {
-        if ((step++ & 7u) == 0u) {
-            if (i > 0 && j > 0) {
-                const int d = j - i + KB;
-                if (d >= 0) {
-                    const int m = i + (d >> 1);
-                    const int key = ((m >> 3) - 1) * 16 + (d >> 1);
-                    if (key != wkey) wkey = key, wv = tr[key];
-                    nkey = key - 16;
-                    if (nkey >= 0) nv = tr[nkey];
-                }
-            }
-            if (j > 0) {
-                const int k = j - 1;
-                if ((k >> 3) != cwin) cwin = k >> 3, __builtin_memcpy(&cw8, craw + (k & ~7), 8);
-                pcwin = cwin - 1;
-                if (pcwin >= 0) __builtin_memcpy(&pcw8, craw + 8 * pcwin, 8);
-            }
-            if (i > 0) {
-                const int k = i - 1;
-                if ((k >> 3) != rwin) rwin = k >> 3, __builtin_memcpy(&rw8, rraw + (k & ~7), 8);
-                prwin = rwin - 1;
-                if (prwin >= 0) __builtin_memcpy(&prw8, rraw + 8 * prwin, 8);
-            }
-        }
-        int tc;
-        if (i == 0) tc = 2;
-        else if (j == 0) tc = 3;
-        else {
+    // The walk in rounds of EIGHT BRANCH-FREE columns behind one checkpoint (round 6).  The 64 walks of a wave reach their boundaries (next
+    // trace word, next residues) at different steps; written with a branch per case the loop compiled to ~25 exec-mask regions per column and
+    // the kernel was bound by the scalar unit (150 scalar beside 100 vector instructions per column).  Now every eighth column each lane makes
+    // sure it holds what eight columns can touch -- its lane's group of four trace blocks and the group behind it (two aligned 16-byte
+    // pieces, TRACE_WORD), 16 residues of either sequence ending at the current column -- loading only what is missing (a piece fetched
+    // again comes from the Infinity Cache, not the L1: unconditional reloads made the launch twice as long), and the columns are selects: m
+    // falls by at most one per column, so by at most one block per round; a gap column that moves the walk to another lane's words waits
+    // for the next round.  Config 3, 720 k walks per launch: 1.19 -> 0.83 ms.  Measured and not kept: 32-byte residue windows (1.17 ms), a
+    // run of up to eight plain diagonal columns taken in one go from the shifted trace nibbles + two single columns per round (1.22 ms: the
+    // wave lasts as long as its slowest lane's rounds, and the 64-bit arithmetic of the run is not cheaper than eight selected columns).
+    // Finished walks idle until the wave's longest ends, as before.
+    bool run = true;   // no stop cell met yet
+    auto byte16 = [](const uint4& v, int o) -> int {
+        const u32 lo = (o & 8) ? v.z : v.x, hi = (o & 8) ? v.w : v.y;
+        return (int)__builtin_amdgcn_ubfe((o & 4) ? hi : lo, (u32)(o & 3) << 3, 8u);
+    };
+    auto word4 = [](const uint4& v, int blk) -> u32 {
+        const u32 lo = (blk & 1) ? v.y : v.x, hi = (blk & 1) ? v.w : v.z;
+        return (blk & 2) ? hi : lo;
+    };
+    int gkey = -1, ngkey = -1;   // first words (TRACE_WORD(block & ~3, lane)) of the two trace pieces held; -1: none
+    uint4 gv = make_uint4(0, 0, 0, 0), ngv = make_uint4(0, 0, 0, 0);
+    int cb = 0x40000000, rb = 0x40000000;   // residue positions cb .. cb + 15 / rb .. rb + 15 are held (none yet)
+    uint4 cw = make_uint4(0, 0, 0, 0), rw = make_uint4(0, 0, 0, 0);
+    while (__ballot(run && (i > 0 || j > 0)) != 0ull) {
+        {   // ---- checkpoint ----
             const int d = j - i + KB;
-            if (d < 0) tc = 3;  // left boundary cell (i, i-17): '|'
-            else {
-                const int m = i + (d >> 1);  // the iteration that computed the cell in lane d >> 1 (k_align's trace layout)
-                const int key = ((m >> 3) - 1) * 16 + (d >> 1);
-                if (key != wkey) wv = key == nkey ? nv : tr[key], wkey = key;
-                tc = (int)((wv >> (((7 - (m & 7)) << 2) + ((d & 1) << 1))) & 3u);
-                tc ^= (tc & tagged) << 1;
+            const bool inb = run && i > 0 && j > 0 && d >= 0;
+            const int m = i + (d >> 1), blk = (m >> 3) - 1;
+            const int g = (int)TRACE_WORD(blk & ~3, d >> 1);
+            if (inb && g != gkey) {
+                if (g == ngkey) gv = ngv;
+                else gv = *reinterpret_cast<const uint4*>(tr + g);
+                gkey = g;
             }
+            if (inb && g >= 64 && ngkey != g - 64) ngkey = g - 64, ngv = *reinterpret_cast<const uint4*>(tr + (g - 64));
         }
-        if (tc == 0) break;
-        ++AL;
-        int a0 = '-', a1 = '-';  // the column's two characters (1419-1432)
-        if (tc != 3) {
-            const int k = j - 1;
-            if ((k >> 3) != cwin) {
-                cwin = k >> 3;
-                if (cwin == pcwin) cw8 = pcw8;
-                else __builtin_memcpy(&cw8, craw + (k & ~7), 8);
-            }
-            a0 = (int)((cw8 >> ((k & 7) << 3)) & 0xFFu);
+        // the round's residues are positions j - 8 .. j - 1 at most (the arrays are padded behind: a window may reach past its sequence)
+        // (32-byte windows -- half the line fetches, a select level more per residue -- measured: 1.17 against 0.83 ms per launch)
+        if (run && j > 0 && (j - 8 < cb || j > cb + 16)) cb = max(j - 16, 0), cw = u1_load16g(craw + cb);
+        if (run && i > 0 && (i - 8 < rb || i > rb + 16)) rb = max(i - 16, 0), rw = u1_load16g(rraw + rb);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const bool alive = run && (i > 0 || j > 0);
+            const int d = j - i + KB;
+            const bool inb = i > 0 && j > 0 && d >= 0;
+            const int m = i + (d >> 1), blk = (m >> 3) - 1;  // the iteration that computed the cell in lane d >> 1 (k_align's trace layout)
+            const int g = (int)TRACE_WORD(blk & ~3, d >> 1);
+            const bool cur = g == gkey, prv = g == ngkey;
+            const u32 w = prv ? word4(ngv, blk) : word4(gv, blk);
+            int code = (int)((w >> (((7 - (m & 7)) << 2) + ((d & 1) << 1))) & 3u);
+            code ^= (code & tagged) << 1;
+            const bool held = !inb || cur || prv;            // else: another lane's words, or a block further back -- next round
+            const int tc = i == 0 ? 2 : (j == 0 ? 3 : (d < 0 ? 3 : code));   // row 0: '-', column 0 and the left boundary cell (i, i-17): '|'
+            const bool go = alive && held && tc != 0;
+            run = run && !(alive && held && tc == 0);
+            // the column's two characters (1419-1432)
+            const int a0 = tc != 3 ? byte16(cw, j - 1 - cb) : (int)'-', a1 = tc != 2 ? byte16(rw, i - 1 - rb) : (int)'-';
+            const bool g0 = a0 == '-', g1 = a1 == '-';
+            const int nm1 = g0 ? 1 + f0 : (g1 ? 1 + f1 : fm1), n0 = g1 ? 1 + f1 : fm1, n1 = g0 ? 1 + f0 : fm1;
+            AL += go ? 1 : 0;
+            matches += (go && a0 == a1) ? 1 : 0;
+            fm1 = go ? nm1 : fm1, f0 = go ? n0 : f0, f1 = go ? n1 : f1;
+            j -= (go && tc != 3) ? 1 : 0;
+            i -= (go && tc != 2) ? 1 : 0;
         }
-        if (tc != 2) {
-            const int k = i - 1;
-            if ((k >> 3) != rwin) {
-                rwin = k >> 3;
-                if (rwin == prwin) rw8 = prw8;
-                else __builtin_memcpy(&rw8, rraw + (k & ~7), 8);
-            }
-            a1 = (int)((rw8 >> ((k & 7) << 3)) & 0xFFu);
-        }
-        matches += (a0 == a1) ? 1 : 0;
-        const bool g0 = a0 == '-', g1 = a1 == '-';
-        const int nm1 = g0 ? 1 + f0 : (g1 ? 1 + f1 : fm1), n0 = g1 ? 1 + f1 : fm1, n1 = g0 ? 1 + f0 : fm1;
-        fm1 = nm1, f0 = n0, f1 = n1;
-        if (tc != 3) --j;
-        if (tc != 2) --i;
     }
     r.aln = AL, r.matches = matches, r.gap = fm1;
     if (swp) {  // rows = query, columns = subject (1473-1474)
@@ -456,9 +447,9 @@ __device__ __forceinline__ void traceback_one(const u32 tid, const AlnTask* __re
 }
 
 u32 align_trace_stride(int max_cols_plus) {
-    // words per task: 16 per block of 8 iterations, iterations 8 .. R + 15, R <= max_cols_plus; rounded to 32 words (128 B)
+    // words per task: 16 per block of 8 iterations, iterations 8 .. R + 15, R <= max_cols_plus; rounded to groups of four blocks (256 B)
     u32 w = (u32)((max_cols_plus + 15) / 8 + 1) * 16u;
-    return (w + 31u) & ~31u;
+    return (w + 63u) & ~63u;   // whole groups of four blocks (TRACE_WORD)
 }
 
 // Trace words of one task: what a band of R rows writes (align_trace_stride(R + 1)), in units of TRACE_UNIT words.  A launch whose
@@ -478,7 +469,7 @@ __global__ __launch_bounds__(256) void k_trace_units(const AlnTask* __restrict__
     const int la = lq - min((int)tk.qi, lq), lb = ls - min((int)tk.qj, ls);
     const int R = min(max(la, lb), min(la, lb) + KB);
     const u32 w = (u32)((R + 1 + 15) / 8 + 1) * 16u;
-    units[t] = ((w + 31u) & ~31u) / TRACE_UNIT;
+    units[t] = ((w + 63u) & ~63u) / TRACE_UNIT;
 }
 u32 align_trace_unit() { return TRACE_UNIT; }
 void launch_trace_units(const AlnTask* tasks, const u32* ridx, u32 n, const u32* qoff, const u32* roff, u32* units /*n + 1*/, hipStream_t st) {

@@ -128,7 +128,7 @@ __device__ __forceinline__ void pk_setup(PkSide& s, const AlnTask& tk, u32 slot,
 // TRACE = true (round 5): the same cells with their traces written and the position of the maximum kept, for the alignments that are
 // reported -- k_align<true>'s job at 10.5 instead of 15 vector instructions per cell.  A cell's trace IS its tag: the four iterations of a
 // group shift their (odd tag << 2 | even tag) nibbles into a register, both alignments at once, and every second group ends with one
-// store per alignment into the 32-bit kernel's own trace layout (word [(m >> 3) - 1][lane], iteration m in nibble 7 - (m & 7): a group is
+// store per alignment into the 32-bit kernel's own trace layout (word TRACE_WORD((m >> 3) - 1, lane), iteration m in nibble 7 - (m & 7): a group is
 // the upper or the lower half of such a word).  The codes differ -- tag 3 diagonal, 1 up against trace 1 diagonal, 3 up -- so the
 // result says which it is (AlnRes.pad = 1) and k_traceback swaps the two when it reads them.  The maximum's position: four 32-bit keys
 // (alignment A / B x even / odd cell) of (value | 3) << 16 | (0xFFFF - iteration), two instructions per cell and alignment.
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     u32 *trA = nullptr, *trB = nullptr;
     if (TRACE) {
         tuA = tofs ? tofs[tA] : tA, tuB = tofs ? tofs[tB] : tB;
-        trA = trace + (size_t)tuA * trace_stride + l;
-        trB = trace + (size_t)tuB * trace_stride + l;
+        trA = trace + (size_t)tuA * trace_stride + TRACE_WORD(0, l);
+        trB = trace + (size_t)tuB * trace_stride + TRACE_WORD(0, l);
     }
     const int mendA = A.R + 15, mendB = tB != tA ? B.R + 15 : -1;
     const int m_end = max(A.R, B.R) + 15;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             if (!(m0 & 4)) {
                 twh = tw;
             } else {
-                const u32 at = (u32)((m0 >> 3) - 1) * 16u;
+                const u32 at = TRACE_WORD((m0 >> 3) - 1, 0);
                 if (m0 - 4 <= mendA) trA[at] = (twh << 16) | (tw & 0xFFFFu);
                 if (m0 - 4 <= mendB) trB[at] = (twh & 0xFFFF0000u) | (tw >> 16);
             }
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     if (TRACE) {   // a last group that is an upper half: left-aligned, as k_align<true> stores it
         const int ml = 8 + ((m_end - 8) & ~3);
         if (!(ml & 4)) {
-            const u32 at = (u32)((ml >> 3) - 1) * 16u;
+            const u32 at = TRACE_WORD((ml >> 3) - 1, 0);
             if (ml <= mendA) trA[at] = twh << 16;
             if (ml <= mendB) trB[at] = twh & 0xFFFF0000u;
         }

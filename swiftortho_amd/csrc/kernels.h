@@ -156,6 +156,13 @@ void launch_emit_cands(const u32* order, u32 n, const u64* sorted_key /*the fina
                        const u32* c_rec, u32* out_q, u32* out_rec, u32* qcnt, u32* seg_first, hipStream_t st);
 
 // k_align.hip
+// Trace words of one alignment (k_align<true>, k_align_pk<true> -> k_traceback): word (b, l) holds lane l's two band cells of the eight
+// iterations 8 (b + 1) .. + 7.  Laid out in groups of FOUR blocks, lane-major inside a group: a walk stays in one lane for many columns and
+// steps back through the blocks, so its next four words are one aligned 16-byte piece (a 64-byte line = 4 lanes x 4 blocks) -- with the
+// blocks 64 bytes apart (rounds 1-5) every word a walk read was a line of its own, and k_traceback was bound by those line fetches (1.44 M
+// walks of config 3: ~35 lines of trace each).  The aligner's 16 lanes store 16 bytes apart instead of side by side; a line is
+// complete after four blocks.
+#define TRACE_WORD(b, l) ((((u32)(b) >> 2) << 6) | ((u32)(l) << 2) | ((u32)(b) & 3u))
 u32 align_trace_stride(int max_rows);
 void launch_align(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u8* q_scls, const u8* q_scls4, const u32* qoff,
                   const u8* r_res, const u8* r_scls, const u8* r_scls4, const u32* roff, const signed char* b62g, u32* trace, u32 trace_stride,

@@ -132,6 +132,34 @@ def test_query_partition_invariance(oracle, tmp_path):
     assert parts == open(os.path.join(GOLD, name + ".sc"), "rb").read()
 
 
+def test_parallel_query_ranges_equal_one_call(oracle, tmp_path):
+    """oracle.blastp_parallel (the GPU parity tests' oracle runs on many-core hosts: query ranges on threads, matrices per thread) gives
+    the rows, records, candidate lists and counters of one call -- on a golden the REAL reference wrote, and on a synthetic set."""
+    import numpy as np
+    from swiftortho_amd import synthprot
+    name = "toy_default"
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    ref = os.path.join(GOLD, name + ".ref.fsa")
+    d = dict(zip(meta["flags"][0::2], meta["flags"][1::2]))
+    kw = dict(ssd=d["-s"], nr=d["-r"], expect=float(d["-e"]), v=int(d["-v"]), step=int(d["-j"]), flt=d["-F"], ht=int(d["-M"]), chk=int(d["-c"]),
+              max_miss=float(d.get("-m", 1e-3)), thr=int(d.get("-t", -1)))
+    out = str(tmp_path / "g.sc")
+    r = oracle.blastp_parallel(ref, ref, out, threads=3, min_piece=8, **kw)
+    assert len(r.parts) == 3
+    if int(d.get("-L", -1)) < 0 and int(d.get("-U", -1)) < 0:
+        assert open(out, "rb").read() == open(os.path.join(GOLD, name + ".sc"), "rb").read()
+    fa = str(tmp_path / "s.fsa")
+    open(fa, "wb").write(synthprot.synthprot(500, 150, 3))
+    kw = dict(ssd="111111", nr=oracle.AA9, expect=1e-5, v=500, step=1, flt="T", ht=1000003, chk=200)
+    a = oracle.blastp(fa, fa, str(tmp_path / "a.sc"), st=30, ed=480, **kw)
+    b = oracle.blastp_parallel(fa, fa, str(tmp_path / "b.sc"), threads=5, st=30, ed=480, **kw)
+    assert len(b.parts) == 5
+    assert open(str(tmp_path / "a.sc"), "rb").read() == open(str(tmp_path / "b.sc"), "rb").read()
+    assert np.array_equal(a.ints, b.ints) and np.array_equal(a.dbl, b.dbl) and a.nqueries == b.nqueries == 450
+    assert all(np.array_equal(a.cands(q), b.cands(q)) for q in range(a.nqueries))
+    assert all(a.stats[k] == b.stats[k] for k in a.stats if not k.startswith("t_"))
+
+
 def native_flags(p):
     """resolved launcher parameters -> the flags find_hit.py puts on the fsearch-c command line (find_hit.py:119-121)"""
     return ["-e", repr(p["exp"]), "-v", str(p["bv"]), "-L", str(p["rstart"]), "-U", str(p["rend"]), "-m", repr(p["miss"]), "-t", str(p["thr"]),
