@@ -183,6 +183,23 @@ def test_ungap_steps_equal_the_reference_count(fs, oracle, tmp_path, monkeypatch
             assert (c["groups_chain"] > 0) == ("SOHIT_UG1_CHAIN" not in env)
 
 
+@pytest.mark.parametrize("uq", ["1", "0"], ids=["wave_per_query", "sorted_keys_only"])
+def test_sparse_pass_singletons_vs_oracle(fs, oracle, tmp_path, monkeypatch, uq):
+    """A sparse pass (long seed: a few hundred hits per query and chunk) takes the sorted path; the hits that are alone on their diagonal
+    are found and extended by k_ungapq, a wave per query, without a key (default), or every hit goes through the sorted keys
+    (SOHIT_UNGAPQ=0).  Rows, candidates and the number of BLOSUM lookups are the oracle's both ways, on uniform and mixed lengths, and
+    the counters say which kernel took the singletons."""
+    from swiftortho_amd import synthprot
+    monkeypatch.setenv("SOHIT_UG_COUNT", "1")
+    monkeypatch.setenv("SOHIT_UNGAPQ", uq)
+    kw = dict(ssd="11111011111", nr=oracle.AA9, ht=120000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    c, st = oracle_vs_gpu(fs, oracle, synthprot.synthprot(1500, 300, 91), kw, tmp_path)
+    assert c["hits_bucketed"] == 0 and c["groups_chain"] == 0
+    assert (c["groups_single"] > 0.3 * c["groups"]) if uq == "1" else c["groups_single"] == 0
+    # mixed lengths: the classes above 512 residues (and the passes that merge them) keep the sorted keys for every hit
+    oracle_vs_gpu(fs, oracle, synthprot.synthprot(700, seed=93, lengths="lognormal"), kw, tmp_path)
+
+
 def test_synth_2000_vs_oracle(fs, oracle, tmp_path):
     from swiftortho_amd import synthprot
     kw = dict(ssd="111111", nr=oracle.AA9, ht=120000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
