@@ -180,9 +180,9 @@ int so_reset_counters(so_ctx *ctx);
 int64_t so_timing_report(const so_ctx *ctx, char *buf, int64_t cap);
 int64_t so_chunk_threshold(const so_ctx *ctx, int64_t chunk);
 int64_t so_chunk_entries(const so_ctx *ctx, int64_t chunk);
-/* copies start[0..NC] (uint32, NC+1 values) / entries (uint64) of one chunk's index to host.  A BUILT index keeps a bucket's members
- * in no particular order (the grouping kernels place them with atomics: the order differs from run to run; the last slot alone is fixed --
- * the last bucket's smallest member, the one the reference never reads); a LOADED one (so_load_index) keeps the file's slot order. */
+/* copies start[0..NC] (uint32, NC+1 values) / entries (uint64) of one chunk's index to host, every bucket's members in descending entry
+ * order -- the slot order of the reference's CSR (fsearch.py:2240-2266) and of its index files.  (The build's grouping kernels place a
+ * bucket's members with atomics; they are put in order by the chunk's first dense seed pass or by this call, whichever comes first.) */
 int so_chunk_download(so_ctx *ctx, int64_t chunk, uint32_t *start, uint64_t *entries);
 /* masked (SEG-filtered, upper-cased) bytes of query qidx as used for seeding and alignment */
 int64_t so_masked_query(so_ctx *ctx, int64_t qidx, char *buf, int64_t cap);

@@ -145,6 +145,7 @@ struct ChunkIndex {
         u32 C = 0;               // diagonal offset of the one-band subjects
         DevBuf<u32> dk32, gbase; // E addends; per chunk sequence: (first band << k) + (C or, for a multi-band subject, its length)
         DevBuf<u64> btab;        // nband x (chunk sequence | gbase << 32)
+        std::vector<std::pair<u32, u32>> spans;   // (first band, bands) of the subjects that own several (host copy: range_table checks them)
         u64 used = 0;
         // the index was rebuilt (so_drop_index + so_build_index) over the same sequences: layout, gbase and btab -- functions of the sequence
         // lengths alone -- still hold, only the entries' addends are encoded again
@@ -154,6 +155,20 @@ struct ChunkIndex {
     };
     std::vector<std::unique_ptr<BandEnc>> encs;
     u64 enc_clock = 0;
+    // The count pass of the bucketed binning without the index entries (k_bkt_count_tab): every bucket's members in descending entry
+    // order (order_chunk: the reference's own CSR order; lazily, at the chunk's first dense pass -- a sparse search never pays for it) and,
+    // per (key layout, range width), the boundaries of the band ranges inside every occupied bucket.
+    bool ordered = false;
+    DevBuf<u32> row_of_slot;    // E: occupied-bucket ordinal at every bucket's first slot
+    struct RangeTab {
+        int ba = -1, bp = -1, k = -1, wb = -1;   // the band encoding it belongs to, the range width
+        bool multi_ok = false;
+        u32 R = 0;
+        bool ok = false;        // false: a multi-band subject straddles a range boundary, a bucket above 65535 entries, ... -- the counting pass stays
+        DevBuf<u16> tab;        // U x (R + 1)
+        u64 used = 0;
+    };
+    std::vector<std::unique_ptr<RangeTab>> rtabs;
 };
 
 
@@ -215,6 +230,7 @@ struct so_ctx {
     hipStream_t st_ug = nullptr;       // k_ungap beside k_ungap1 (Tune::ug1_overlap)
     hipEvent_t ev_ug_go = nullptr, ev_ug_done = nullptr;
     bool rows_in_flight = false;
+    bool count_tab_now = false;   // this (batch, chunk)'s bucketed passes count from the range boundaries (seed_stage decides: SOHIT_COUNT_TAB)
     size_t max_hits_per_pass = (size_t)1 << 30;
     u32 max_batch = 131072;  // queries per device batch.  Round 3, config 3 (100k queries), same box: 25000 64.1 ms, 33334 63.0, 2 x 50000 63.0,
                              // 65536 + 34464 62.1, one batch of 100000 59.1 -- larger launches beat overlapping one batch's row download with
@@ -504,6 +520,8 @@ void build_index(so_ctx* c);
 void load_index(so_ctx* c, const char* prefix);
 void band_plan(so_ctx* c, ChunkIndex& ch, int bp, bool multi_ok, int* k_out, u64* nband_out);
 ChunkIndex::BandEnc* band_encoding(so_ctx* c, ChunkIndex& ch, int ba, int bp, bool multi_ok);
+void order_chunk(so_ctx* c, ChunkIndex& ch);
+const ChunkIndex::RangeTab* range_table(so_ctx* c, ChunkIndex& ch, const ChunkIndex::BandEnc& e, int wb, u32 R);
 // host_seed.hip: batch preparation and the seed stage
 void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi);
 void* small_host(so_ctx* c);

@@ -486,6 +486,7 @@ int so_chunk_download(so_ctx* c, int64_t k, uint32_t* start, uint64_t* entries) 
     return guarded(c, [&] {
         if (k < 0 || k >= (int64_t)c->chunks.size()) throw SoError("so_chunk_download: no such chunk");
         ChunkIndex& ch = *c->chunks[k];
+        order_chunk(c, ch);   // (members of every bucket in the reference's CSR order, if no dense pass has asked for that yet)
         if (start) {  // the reference's direct-addressed start[NC + 1], rebuilt from the occupied-bucket list
             std::vector<u32> ub(ch.U), ubeg((size_t)ch.U + 1);
             if (ch.U) {
@@ -498,7 +499,10 @@ int so_chunk_download(so_ctx* c, int64_t k, uint32_t* start, uint64_t* entries) 
                 start[bk] = k < ch.U ? ubeg[k] : ch.E;
             }
         }
-        if (entries && ch.E) HIP_CHECK(hipMemcpy(entries, ch.entries.p, (size_t)ch.E * sizeof(u64), hipMemcpyDeviceToHost));
+        if (entries && ch.E) {
+            HIP_CHECK(hipStreamSynchronize(c->st));
+            HIP_CHECK(hipMemcpy(entries, ch.entries.p, (size_t)ch.E * sizeof(u64), hipMemcpyDeviceToHost));
+        }
     });
 }
 

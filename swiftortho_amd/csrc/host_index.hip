@@ -86,6 +86,8 @@ void build_index(so_ctx* c) {
             c->spare_chunks.erase(c->spare_chunks.begin());
             ch->d_sh_subj = ch->d_sh_diag = -1;  // key addends belong to the old entries
             for (auto& e : ch->encs) e->stale = true;   // (band_encoding re-encodes the entries; the layout survives when the sequences are the same)
+            ch->ordered = false;
+            for (auto& t : ch->rtabs) t->k = -1;       // (range boundaries belong to the old entries; the buffers are kept)
         } else {
             ch = std::make_unique<ChunkIndex>();
         }
@@ -451,10 +453,12 @@ ChunkIndex::BandEnc* band_encoding(so_ctx* c, ChunkIndex& ch, int ba, int bp, bo
     std::vector<u64> btab;
     if (e->multi) btab.resize((size_t)nband);
     u32 band = 0;
+    e->spans.clear();
     for (u32 j = 0; j < nseq; ++j) {
         const u32 sl = c->ref.len(ch.seq_lo + j);
         const bool one = sl <= e->C;
         const u32 nb = one ? 1u : (u32)(((u64)sl + qcap + (1ull << k) - 1) >> k);
+        if (nb > 1) e->spans.emplace_back(band, nb);
         gbase[j] = (band << k) + (one ? e->C : sl);
         if (e->multi)
             for (u32 t = 0; t < nb; ++t) btab[(size_t)band + t] = (u64)j | ((u64)gbase[j] << 32);
@@ -470,4 +474,67 @@ ChunkIndex::BandEnc* band_encoding(so_ctx* c, ChunkIndex& ch, int ba, int bp, bo
     launch_encode_band32(ch.entries.p, ch.E, ba, e->gbase.p, c->ref.d_off.p + ch.seq_lo, e->dk32.p, c->st);
     HIP_CHECK(hipStreamSynchronize(c->st));   // the host vectors must outlive the copies
     return e;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The count pass without the index entries (k_bucket.hip: k_rtab_build, k_bkt_count_tab)
+// ---------------------------------------------------------------------------------------------
+// Members of every bucket in descending entry order = subject descending (the order the reference's CSR has, which the hand-written
+// grouping of the build gave up): the entries of one band range become one run of the bucket.  Done at the chunk's first dense pass;
+// every band encoding's addends follow the slots, so they are encoded again when next used (`stale`).  The smallest member of the last
+// bucket ends up in the slot the reference never reads, where k_index_fixlast had put it.
+void order_chunk(so_ctx* c, ChunkIndex& ch) {
+    if (ch.ordered) return;
+    if (ch.E && ch.U) {
+        const u32 nseq = (u32)std::max<i64>(1, ch.seq_hi - ch.seq_lo);
+        const int end_bit = std::min(63, 32 + ceil_log2((u64)nseq + 1));
+        c->ix_ent.ensure((size_t)ch.E + 4);
+        ensure_sort_tmp(c, sort_keys_u64_seg_desc_temp_bytes(ch.E, ch.U, 0, end_bit));
+        sort_keys_u64_seg_desc(c->d_sort_tmp.p, c->d_sort_tmp.cap, ch.entries.p, c->ix_ent.p, ch.E, ch.U, ch.ubeg.p, 0, end_bit, c->st);
+        HIP_CHECK(hipMemcpyAsync(ch.entries.p, c->ix_ent.p, (size_t)ch.E * sizeof(u64), hipMemcpyDeviceToDevice, c->st));
+        for (auto& e : ch.encs) e->stale = true;
+        ch.d_sh_subj = ch.d_sh_diag = -1;
+        for (auto& t : ch.rtabs) t->k = -1;
+    }
+    ch.ordered = true;
+}
+
+// Range boundaries of every occupied bucket for band encoding `e` and ranges of 2^wb bands; nullptr-like (ok == false) when the table
+// cannot stand in for the counting pass: a subject whose bands straddle a range boundary (its hits' range would depend on the query
+// position), a bucket above 65535 entries, a table above 1 GiB.  Up to four tables per chunk are kept (least recently used first out).
+const ChunkIndex::RangeTab* range_table(so_ctx* c, ChunkIndex& ch, const ChunkIndex::BandEnc& e, int wb, u32 R) {
+    ++ch.enc_clock;
+    for (auto& t : ch.rtabs)
+        if (t->k == e.k && t->ba == e.ba && t->bp == e.bp && t->multi_ok == e.multi_ok && t->wb == wb && t->R == R) {
+            t->used = ch.enc_clock;
+            return t.get();
+        }
+    ChunkIndex::RangeTab* t = nullptr;
+    for (auto& x : ch.rtabs)
+        if (x->k < 0) t = x.get();
+    if (!t && ch.rtabs.size() < 4) {
+        ch.rtabs.push_back(std::make_unique<ChunkIndex::RangeTab>());
+        t = ch.rtabs.back().get();
+    }
+    if (!t) {
+        t = ch.rtabs[0].get();
+        for (auto& x : ch.rtabs)
+            if (x->used < t->used) t = x.get();
+    }
+    t->ba = e.ba, t->bp = e.bp, t->k = e.k, t->multi_ok = e.multi_ok, t->wb = wb, t->R = R, t->used = ch.enc_clock, t->ok = false;
+    if (!ch.ordered || !ch.E || !ch.U || e.ba != 0) return t;
+    for (const auto& sp : e.spans)
+        if ((sp.first >> wb) != ((sp.first + sp.second - 1) >> wb)) return t;   // a subject's bands in two ranges
+    const size_t cells = (size_t)ch.U * ((size_t)R + 1);
+    if (cells * sizeof(u16) > ((size_t)1 << 30)) return t;
+    t->tab.ensure(cells + 8);
+    ch.row_of_slot.ensure((size_t)ch.E + 4);
+    c->d_small.ensure(16);
+    HIP_CHECK(hipMemsetAsync(c->d_small.p + 14, 0, sizeof(u32), c->st));
+    launch_rtab_build(e.dk32.p, ch.E, ch.ubeg.p, ch.U, wb + e.k, R, t->tab.p, ch.row_of_slot.p, c->d_small.p + 14, c->st);
+    const u32 flag = d2h_u32(c, c->d_small.p + 14);
+    if (flag && tune().debug) fprintf(stderr, "[sohit] range table refused (flag %u): counting pass\n", flag);
+    t->ok = flag == 0;
+    return t;
 }

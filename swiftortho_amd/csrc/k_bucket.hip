@@ -329,6 +329,160 @@ __global__ __launch_bounds__(64 * BK_WAVES, WPE) void k_bkt_pass(const uint4* __
 }
 
 // ================================================================================================================
+// the count pass WITHOUT the index entries: range boundaries per index bucket (round 6)
+// ================================================================================================================
+// k_bkt_pass<count> reads every visited index entry a second time (4 B per hit: 3.3 GB per 928 M-hit launch) only to learn how many of a
+// tile's hits fall into each band range.  The band range of a hit is a function of its SUBJECT alone (a subject's bands lie inside one
+// range: the host checks that for the few multi-band subjects and keeps the counting pass otherwise), so with the members of every index
+// bucket in descending entry order (order_chunk: subject descending -- the reference's own CSR order) the entries of one range are one
+// run of the bucket, and a table of the runs' boundaries, built once per (chunk, key layout, range width), turns the count into
+// arithmetic: tile x seed x range -> overlap of two intervals.
+//   rtab[u * (R + 1) + r] = entries of occupied bucket u whose range is >= r  (r = 0 ... R; the one entry per chunk the reference drops,
+//   offset 0 of the first sequence, has the smallest value, sits last and is in no range): range r's run is [rtab[u][r + 1], rtab[u][r]).
+__global__ __launch_bounds__(256) void k_rtab_build(const u32* __restrict__ dk32, u32 E, const u32* __restrict__ ubeg /*U + 1*/, u32 U, int gb, u32 R,
+                                                    u16* __restrict__ rtab, u32* __restrict__ row_of_slot, u32* __restrict__ flag) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= E) return;
+    u32 lo = 0, hi = U;   // the bucket of slot i: largest u with ubeg[u] <= i
+    while (hi - lo > 1) {
+        const u32 m = (lo + hi) >> 1;
+        if (ubeg[m] <= i) lo = m;
+        else hi = m;
+    }
+    const u32 u = lo, beg = ubeg[u], cnt = ubeg[u + 1] - beg, li = i - beg;
+    if (li == 0) row_of_slot[i] = u;
+    if (cnt > 0xFFFFu) {   // (16-bit boundaries: such a bucket is far above every frequency threshold; the host keeps the counting pass)
+        if (li == 0) atomicOr(flag, 2u);
+        return;
+    }
+    const u32 c = dk32[i];
+    const int ri = (int)c >= 0 ? (int)min(c >> gb, R - 1u) : -1;
+    int rp = (int)R;
+    if (li) {
+        const u32 cp = dk32[i - 1];
+        rp = (int)cp >= 0 ? (int)min(cp >> gb, R - 1u) : -1;
+    }
+    if (ri > rp) atomicOr(flag, 1u);   // not in descending order
+    u16* row = rtab + (size_t)u * (R + 1u);
+    for (int r = ri + 1; r <= rp; ++r) row[r] = (u16)li;
+    if (li == cnt - 1u)
+        for (int r = 0; r <= ri; ++r) row[r] = (u16)cnt;
+}
+
+// mat[tile * R + range] = hits of the tile in the range, as k_bkt_pass<count> writes them.  A wave per tile.  The loads form a chain -- tile
+// descriptor -> seed (hit offset, slot base) -> bucket ordinal -> its row of boundaries -- so the tile's seeds (a handful in a dense pass) are
+// first read side by side, lane = seed, and then taken one after the other with lane = range: four memory round trips per tile, not four per
+// seed (0.51 -> 0.2 ms per 906 k tiles).
+__global__ __launch_bounds__(64 * BK_WAVES) void k_bkt_count_tab(const uint4* __restrict__ td, const u32* __restrict__ qseg, u32 NT, const u32* __restrict__ cs_hoff,
+                                                                  const u32* __restrict__ cs_base, const u32* __restrict__ row_of_slot, const u16* __restrict__ rtab, u32 R,
+                                                                  u32* __restrict__ mat) {
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 t = __builtin_amdgcn_readfirstlane(blockIdx.x * BK_WAVES + w);
+    if (t >= NT) return;
+    const uint4 d = td[t];
+    const u32 q = __builtin_amdgcn_readfirstlane(d.x), first = __builtin_amdgcn_readfirstlane(d.y);
+    const u32 k0 = __builtin_amdgcn_readfirstlane(d.z), k1 = __builtin_amdgcn_readfirstlane(d.w);
+    const u32 last = first + min((u32)BK_HITS, __builtin_amdgcn_readfirstlane(qseg[q + 1]) - first);   // one past the tile's last ordinal
+    for (u32 r0 = 0; r0 < R; r0 += 64) {   // (one round unless a chunk has more than 64 ranges)
+        const u32 r = min(r0 + lane, R - 1u);
+        u32 n = 0;
+        for (u32 a0 = k0; a0 <= k1; a0 += 64) {
+            // lane = seed: the part of its bucket that lies inside the tile, relative to the bucket's first slot
+            const u32 a = min(a0 + lane, k1);
+            const u32 h0 = cs_hoff[a];
+            const u32 o_lo = max(first, h0), o_hi = a == k1 ? last : min(last, cs_hoff[a + 1]);
+            const bool live = a0 + lane <= k1 && o_hi > o_lo;
+            const u32 row = live ? row_of_slot[cs_base[a] + h0] : 0u;
+            const u32 x0 = o_lo - h0, x1 = o_hi - h0;
+            const u32 ns = min(64u, k1 - a0 + 1u);
+            // lane = range: overlap of the range's run [row[r + 1], row[r]) with the seed's part
+            // (four seeds' rows requested before the first is used; a seed outside the tile reads row 0 and counts nothing)
+            for (u32 j = 0; j < ns; j += 4) {
+                u32 lo[4], hi[4];
+#pragma unroll
+                for (u32 k = 0; k < 4; ++k) {
+                    const int jj = (int)min(j + k, ns - 1u);
+                    const bool lv = j + k < ns && __builtin_amdgcn_readlane((int)live, jj) != 0;
+                    const u16* rw = rtab + (size_t)(u32)__builtin_amdgcn_readlane((int)row, jj) * (R + 1u);
+                    lo[k] = max((u32)rw[r + 1], (u32)__builtin_amdgcn_readlane((int)x0, jj));
+                    hi[k] = lv ? min((u32)rw[r], (u32)__builtin_amdgcn_readlane((int)x1, jj)) : 0u;
+                }
+#pragma unroll
+                for (u32 k = 0; k < 4; ++k) n += hi[k] > lo[k] ? hi[k] - lo[k] : 0u;
+            }
+        }
+        if (r0 + lane < R) mat[(size_t)t * R + r] = n;
+    }
+}
+
+// The same with a wave per QUERY (R <= 64): the query's seeds are walked once, in order, the current tile's counts in the lanes; a tile is
+// written when the seed that reaches its end has been added.  A wave per tile paid its chain of four dependent memory round trips for
+// three or four seeds (0.42 ms per 906 k tiles: latency); here the chain is paid once per 64 seeds.
+__global__ __launch_bounds__(64 * BK_WAVES) void k_bkt_count_tabq(const uint4* __restrict__ td, const u32* __restrict__ qseg, const u32* __restrict__ t0 /*nqp + 1*/, u32 nqp,
+                                                                   const u32* __restrict__ cs_hoff, const u32* __restrict__ cs_base, const u32* __restrict__ row_of_slot,
+                                                                   const u16* __restrict__ rtab, u32 R, u32* __restrict__ mat) {
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 q = __builtin_amdgcn_readfirstlane(blockIdx.x * BK_WAVES + w);
+    if (q >= nqp) return;
+    const u32 tf = __builtin_amdgcn_readfirstlane(t0[q]), te = __builtin_amdgcn_readfirstlane(t0[q + 1]);
+    if (te <= tf) return;   // no hits: no tile
+    const u32 qe = __builtin_amdgcn_readfirstlane(qseg[q + 1]);
+    const u32 ka = __builtin_amdgcn_readfirstlane(td[tf].z), kb = __builtin_amdgcn_readfirstlane(td[te - 1u].w);
+    const u32 r = min(lane, R - 1u);
+    u32 acc = 0, tcur = tf;
+    u32 tile_lo = __builtin_amdgcn_readfirstlane(qseg[q]), tile_hi = min(tile_lo + (u32)BK_HITS, qe);
+    for (u32 a0 = ka; a0 <= kb; a0 += 64) {
+        const u32 a = min(a0 + lane, kb);
+        const u32 h0 = cs_hoff[a], h1 = a < kb ? cs_hoff[a + 1] : qe;   // the seed's hit ordinals
+        const u32 row = row_of_slot[cs_base[a] + h0];
+        const u32 ns = min(64u, kb - a0 + 1u);
+        for (u32 j0 = 0; j0 < ns; j0 += 4) {
+            u32 lo[4], hi[4];
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) {   // four seeds' rows requested before the first is used
+                const u16* rw = rtab + (size_t)(u32)__builtin_amdgcn_readlane((int)row, (int)min(j0 + k, ns - 1u)) * (R + 1u);
+                lo[k] = rw[r + 1], hi[k] = rw[r];
+            }
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) {
+                if (j0 + k >= ns) break;   // (wave-uniform)
+                const u32 s0 = (u32)__builtin_amdgcn_readlane((int)h0, (int)(j0 + k)), s1 = (u32)__builtin_amdgcn_readlane((int)h1, (int)(j0 + k));
+                for (;;) {   // the tiles the seed's ordinals [s0, s1) reach into
+                    const u32 x0 = max(lo[k], max(s0, tile_lo) - s0), x1 = min(hi[k], min(s1, tile_hi) - s0);
+                    acc += x1 > x0 ? x1 - x0 : 0u;
+                    if (s1 < tile_hi) break;
+                    if (lane < R) mat[(size_t)tcur * R + r] = acc;   // the tile is complete
+                    acc = 0, ++tcur, tile_lo = tile_hi, tile_hi = min(tile_hi + (u32)BK_HITS, qe);
+                    if (s1 <= tile_lo) break;
+                }
+            }
+        }
+    }
+}
+
+// SOHIT_COUNT_TAB=2 (tests): the table's counts against the counting pass's
+__global__ __launch_bounds__(256) void k_u32_differ(const u32* __restrict__ a, const u32* __restrict__ b, size_t n, u32* __restrict__ flag) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n && a[i] != b[i]) atomicAdd(flag, 1u);
+}
+void launch_u32_differ(const u32* a, const u32* b, size_t n, u32* flag, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_u32_differ, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, n, flag);
+}
+void launch_rtab_build(const u32* dk32, u32 E, const u32* ubeg, u32 U, int gb, u32 R, u16* rtab, u32* row_of_slot, u32* flag, hipStream_t st) {
+    if (E && U) hipLaunchKernelGGL(k_rtab_build, dim3((E + 255) / 256), dim3(256), 0, st, dk32, E, ubeg, U, gb, R, rtab, row_of_slot, flag);
+}
+void launch_bkt_count_tab(const void* td, const u32* qseg, const u32* t0, u32 nqp, u32 NT, const u32* cs_hoff, const u32* cs_base, const u32* row_of_slot, const u16* rtab,
+                          u32 R, u32* mat, hipStream_t st) {
+    if (NT && R <= 64) {
+        hipLaunchKernelGGL(k_bkt_count_tabq, dim3((nqp + BK_WAVES - 1) / BK_WAVES), dim3(64 * BK_WAVES), 0, st, (const uint4*)td, qseg, t0, nqp, cs_hoff, cs_base, row_of_slot,
+                           rtab, R, mat);
+        return;
+    }
+    if (NT) hipLaunchKernelGGL(k_bkt_count_tab, dim3((NT + BK_WAVES - 1) / BK_WAVES), dim3(64 * BK_WAVES), 0, st, (const uint4*)td, qseg, NT, cs_hoff, cs_base, row_of_slot,
+                               rtab, R, mat);
+}
+
+// ================================================================================================================
 // grouping kernel: hits of a bucket -> 64-bit keys in (subject, diagonal, qpos) order
 // ================================================================================================================
 // One workgroup per bucket (1-2 k hits over a few hundred subjects).  An exact sort, but shaped for the data: an LDS

@@ -86,3 +86,18 @@ void sort_cand_keys_seg(void* temp, size_t temp_bytes, const u64* in, u64* out, 
     HIP_CHECK(cand_keys_dispatch(temp, temp_bytes, in, out, n, nseg, seg, seg + 1, begin_bit, end_bit, st));
 }
 
+
+// ---- members of every index bucket in DESCENDING entry order (order_chunk, host_index.hip): one segment per occupied bucket (tens of entries:
+// the library's warp-sort size classes), once per index build and only for chunks whose passes are dense enough for the bucketed binning ----
+size_t sort_keys_u64_seg_desc_temp_bytes(size_t n, u32 nseg, int begin_bit, int end_bit) {
+    size_t bytes = 0;
+    (void)rocprim::segmented_radix_sort_keys_desc<rocprim::default_config>(nullptr, bytes, (const u64*)nullptr, (u64*)nullptr, (unsigned)n, nseg, (const u32*)nullptr,
+                                                                           (const u32*)nullptr, (unsigned)begin_bit, (unsigned)end_bit, (hipStream_t)0, false);
+    return bytes;
+}
+void sort_keys_u64_seg_desc(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* seg, int begin_bit, int end_bit, hipStream_t st) {
+    if (n == 0 || nseg == 0) return;
+    if (end_bit >= 64) throw SoError("sort_keys_u64_seg_desc: end_bit must be below 64");
+    HIP_CHECK(rocprim::segmented_radix_sort_keys_desc<rocprim::default_config>(temp, temp_bytes, in, out, (unsigned)n, nseg, seg, seg + 1, (unsigned)begin_bit,
+                                                                               (unsigned)end_bit, st, false));
+}

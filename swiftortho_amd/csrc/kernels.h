@@ -210,6 +210,14 @@ void launch_scatter_u32(const u32* src, const u32* idx, u32 n, u32* dst, hipStre
 // k_bucket.hip: diagonal binning without a sort (query-aligned tiles, count -> scan -> scatter, LDS hash grouping)
 u32 bkt_tile_hits();
 void launch_bkt_ntiles(const u32* qseg, u32 nqp, u32* ntile, hipStream_t st);
+// the count pass from per-bucket range boundaries (k_bucket.hip; order_chunk / range_table in host_index.hip)
+void launch_rtab_build(const u32* dk32, u32 E, const u32* ubeg, u32 U, int gb, u32 R, u16* rtab, u32* row_of_slot, u32* flag, hipStream_t st);
+void launch_bkt_count_tab(const void* td, const u32* qseg, const u32* t0 /*first tile of every pass query, + NT*/, u32 nqp, u32 NT, const u32* cs_hoff, const u32* cs_base,
+                          const u32* row_of_slot, const u16* rtab, u32 R, u32* mat, hipStream_t st);
+void launch_u32_differ(const u32* a, const u32* b, size_t n, u32* flag, hipStream_t st);
+size_t sort_keys_u64_seg_desc_temp_bytes(size_t n, u32 nseg, int begin_bit, int end_bit);
+void sort_keys_u64_seg_desc(void* temp, size_t temp_bytes, const u64* in, u64* out, size_t n, u32 nseg, const u32* seg /*nseg + 1*/, int begin_bit, int end_bit,
+                            hipStream_t st);
 void launch_bkt_tiledesc(const u32* qseg, const u32* t0, u32 nqp, u32 NT, const u32* cs_hoff, u32 K, void* td /*uint4 x NT*/, hipStream_t st);
 void launch_bkt_pass(bool scatter, const void* td, const u32* qseg, u32 NT, const u32* cs_hoff, const u32* cs_base, const u64* cs_kbase,
                      const u32* dk32, const u32* roff, const BktLayout& L, u32* mat, u32* out, hipStream_t st);

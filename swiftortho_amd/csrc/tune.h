@@ -17,6 +17,7 @@
     X(B, bucket, "SOHIT_BUCKET", 1, "bucketed diagonal binning (0: every pass on the sorted path)")                                                            \
     X(I, bucket_min, "SOHIT_BUCKET_MIN", 192, "hits per bucket below which a pass takes the sorted path (0: bucketed whenever possible)")                      \
     X(I, bucket_avg, "SOHIT_BUCKET_AVG", 2560, "average bucket size the band-range width is chosen for")                                                       \
+    X(I, count_tab, "SOHIT_COUNT_TAB", 1, "bucketed passes: hits per (tile, range) from the range boundaries of the ordered index buckets when a batch brings a chunk two passes and more (0: always the counting pass over the entries; 2: always both, compared -- tests; 3: always)") \
     X(B, bucket_best, "SOHIT_BUCKET_BEST", 1, "best diagonal per subject by the per-bucket reduction (0: sort of the pass records)")                           \
     X(B, bands, "SOHIT_BANDS", 1, "diagonal bands follow the subjects' lengths (0: one band per subject)")                                                     \
     X(B, lk_wide, "SOHIT_LK_WIDE", 0, "8-byte index addends whatever the field widths")                                                                        \

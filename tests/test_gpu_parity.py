@@ -79,8 +79,8 @@ def test_index_and_candidates_vs_golden(fs, oracle, name):
 
 
 def check_index(s, ix, NC, A, S):
-    """GPU chunk index == oracle CSR: same bucket boundaries; each bucket holds the same members
-    (the GPU keeps them unordered except that slot E-1 is the last bucket's smallest member)."""
+    """GPU chunk index == oracle CSR: same bucket boundaries, and the downloaded entries in the reference's slot order (descending entry
+    value inside a bucket: so_chunk_download puts a built chunk in that order, as the first dense pass would)."""
     o_start, o_locus, soas = ix.start(), ix.locus(), ix.soas()
     g_start, ent = s.chunk_index(0)
     E = len(o_locus)
@@ -96,6 +96,7 @@ def check_index(s, ix, NC, A, S):
     # reference order inside a bucket = descending entry value (subject, tag, pos)
     order = np.lexsort(((~ent), bucket))
     assert np.array_equal(x[order], o_locus.astype(np.int64))
+    assert np.array_equal(order, np.arange(E)), "entries are not in the reference's slot order"
     # the slot the reference never reads
     last_b = bucket[-1]
     lo = int(g_start[last_b])
@@ -624,6 +625,35 @@ def test_makedb_then_load_equals_a_fresh_build(fs, tmp_path, space, ht):
     for k in range(3):
         for suf in (".idx", ".soas", ".bin"):
             os.remove("%s.%d%s" % (ref, k, suf))
+
+
+@pytest.mark.parametrize("name", ["families_narrow_ranges", "multichunk", "uniform"])
+@pytest.mark.parametrize("mode", ["2", "0"], ids=["boundaries_checked_against_the_counting_pass", "counting_pass"])
+def test_bucket_counts_from_range_boundaries(fs, oracle, tmp_path, monkeypatch, name, mode):
+    """The count pass of the bucketed binning reads the range boundaries of the ordered index buckets instead of the entries (order_chunk /
+    range_table / k_bkt_count_tab; default).  SOHIT_COUNT_TAB=2 runs the counting pass beside it and fails the search if one cell of the
+    (tile, range) matrix differs; 0 is the counting pass alone.  Rows, candidates and counters are the oracle's both ways, and the profile says
+    which one ran."""
+    from swiftortho_amd import synthprot
+    n, ln, seed, over, avg = BUCKET_CASES[name]
+    over = dict(over)
+    fa = (synthprot.uniform_proteins if over.pop("uniform", False) else synthprot.synthprot)(n, ln, seed)
+    kw = dict(ssd="111111", nr=oracle.AA9, ht=120000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
+    kw.update(over)
+    monkeypatch.setenv("SOHIT_BUCKET_MIN", "0")
+    monkeypatch.setenv("SOHIT_BUCKET_AVG", avg)
+    monkeypatch.setenv("SOHIT_COUNT_TAB", mode)
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+    s = fs.Searcher(profile=True, **kw)
+    s.load_ref_bytes(fa)
+    s.load_queries_bytes(fa)
+    for _ in range(2):   # (the second search finds the chunks ordered and the tables built)
+        h = s.search()
+        rows = b"".join(h.rows())
+        h.close()
+        assert rows == open(str(tmp_path / "o.sc"), "rb").read()
+    assert ("seed.bucket_count_tab_launches" in s.timing()) == (mode == "2")
+    s.close()
 
 
 @pytest.mark.parametrize("n,ln,avg", [(40, 4300, "100000"), (24, 5200, "64"), (300, 900, "100000")])

@@ -55,7 +55,7 @@ if one("fetch/*/*_counter_collection.csv") and one("write/*/*_counter_collection
     def pick(prefix):   # kernel names carry their template arguments: k_bkt_pass<true, true, 5> ...
         c = [k for k in sorted(set(fetch) | set(write)) if k.startswith(prefix)]
         return c[0] if c else None
-    for name, key in ((pick("k_bkt_pass<true"), "scatter"), (pick("k_bkt_pass<false"), "count"), (pick("k_bkt_group"), "group"), (pick("k_lookup<16"), "k_lookup")):
+    for name, key in ((pick("k_bkt_pass<true"), "scatter"), (pick("k_bkt_count_tab") or pick("k_bkt_pass<false"), "count"), (pick("k_bkt_group"), "group"), (pick("k_lookup<16"), "k_lookup")):
         if name and (name in fetch or name in write):
             rd, wr = int(2 * fetch.get(name, 0) * 1024), int(write.get(name, 0) * 1024)
             out[key] = {"kernel": name, "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr,
