@@ -229,6 +229,7 @@ struct so_ctx {
     hipEvent_t ev_side_go = nullptr, ev_korder = nullptr;
     hipStream_t st_ug = nullptr;       // k_ungap beside k_ungap1 (Tune::ug1_overlap)
     hipEvent_t ev_ug_go = nullptr, ev_ug_done = nullptr;
+    hipEvent_t ev_bnd_go = nullptr, ev_bnd_done = nullptr;   // the next chunk's k_bounds on st_side (chunk_qhits)
     bool rows_in_flight = false;
     bool count_tab_now = false;   // this (batch, chunk)'s bucketed passes count from the range boundaries (seed_stage decides: SOHIT_COUNT_TAB)
     size_t max_hits_per_pass = (size_t)1 << 30;
@@ -337,6 +338,10 @@ struct Batch {
     DevBuf<u32> d_qid, d_ocnt, d_ostart;
     SeqSet dev;              // device arrays only (d_res = masked raw, d_scls, d_off, d_words, d_pseq)
     DevBuf<u32> qbucket, korder, sbeg, scnt, pcnt, eff, nz, hoff, cidx;
+    // k_bounds of the NEXT chunk runs on the side stream beside this chunk's seed stage (one random directory line per window: memory
+    // latency, no LDS), into a second set of arrays that chunk_qhits swaps in (SOHIT_BOUNDS_AHEAD)
+    DevBuf<u32> sbeg2, scnt2, pcnt2;
+    int bnd_ci = -1;         // chunk whose bounds the second set holds (or is being filled with): -1 none
     DevBuf<int> ksc;
     DevBuf<u8> mark;
     DevBuf<u32> cs_hoff, cs_beg, blk_first, qseg, sel_idx;

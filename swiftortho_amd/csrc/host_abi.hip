@@ -167,6 +167,8 @@ so_ctx* so_create(int device, const so_params* params) {
         HIP_CHECK(hipStreamCreateWithFlags(&c->st_ug, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_ug_go, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&c->ev_ug_done, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&c->ev_bnd_go, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&c->ev_bnd_done, hipEventDisableTiming));
         upload_constants(c);
         c->warm = std::thread(warm_sort_modules, device);
         g_create_err.clear();
@@ -198,6 +200,8 @@ void so_destroy(so_ctx* c) {
     if (c->st_side) (void)hipStreamDestroy(c->st_side);
     if (c->ev_ug_go) (void)hipEventDestroy(c->ev_ug_go);
     if (c->ev_ug_done) (void)hipEventDestroy(c->ev_ug_done);
+    if (c->ev_bnd_go) (void)hipEventDestroy(c->ev_bnd_go);
+    if (c->ev_bnd_done) (void)hipEventDestroy(c->ev_bnd_done);
     if (c->st_ug) (void)hipStreamDestroy(c->st_ug);
     if (c->st) (void)hipStreamDestroy(c->st);
     if (&c->tune == &tune()) set_tune(nullptr);

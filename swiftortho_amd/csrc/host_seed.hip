@@ -2,8 +2,9 @@
 #include "host.h"
 
 void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
-    if (b.korder_async) HIP_CHECK(hipStreamSynchronize(c->st_side));   // (a batch that never reached its long queries' passes)
+    if (b.korder_async || b.bnd_ci >= 0) HIP_CHECK(hipStreamSynchronize(c->st_side));   // (a batch that never reached its long queries' passes / its last chunks)
     b.korder_async = false;
+    b.bnd_ci = -1;
     b.q_lo = q_lo, b.q_hi = q_hi, b.nq = (u32)(q_hi - q_lo);
     const SeqSet& Q = c->qry;
     const bool classes_on = tune().qclass;   // SOHIT_QCLASS=0: file order
@@ -160,12 +161,34 @@ const unsigned long long* chunk_qhits(so_ctx* c, Batch& b, int ci) {
     ChunkIndex& ch = *c->chunks[ci];
     const int AS = c->cfg.A * c->cfg.S;
     const u32 Ppad = b.dev.Ppad, NC = (u32)c->nc;
-    {
+    if (b.bnd_ci == ci) {   // computed on the side stream beside the previous chunk's seed stage: take the second set of arrays
+        HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_bnd_done, 0));
+        std::swap(b.sbeg.p, b.sbeg2.p), std::swap(b.sbeg.cap, b.sbeg2.cap);
+        std::swap(b.scnt.p, b.scnt2.p), std::swap(b.scnt.cap, b.scnt2.cap);
+        std::swap(b.pcnt.p, b.pcnt2.p), std::swap(b.pcnt.cap, b.pcnt2.cap);
+    } else {
+        if (b.bnd_ci >= 0) HIP_CHECK(hipStreamWaitEvent(c->st, c->ev_bnd_done, 0));   // (another chunk's: its arrays are simply not used)
         ProfTimer pt(c, &c->cnt.bounds_ms, &c->cnt.bounds_launches);
         launch_bounds(b.qbucket.p, Ppad, AS, ch.hkey.p, ch.hval.p, ch.hshift, ch.hmask, ch.use_dir ? ch.dir.p : nullptr, ch.ubeg.p, NC, ch.E, b.sbeg.p,
                       b.scnt.p, b.pcnt.p, c->st);
         pt.stop();
         if (c->profile) c->cnt.bounds_bytes += (i64)8 * AS * (i64)b.h_off[b.nq];
+    }
+    b.bnd_ci = -1;
+    if (tune().bounds_ahead && !c->profile) {   // (the stage clocks want every kernel on the batch's stream)
+        int nx = ci + 1;
+        while (nx < (int)c->chunks.size() && (c->chunks[nx]->seq_hi == c->chunks[nx]->seq_lo || c->chunks[nx]->E == 0)) ++nx;
+        if (nx < (int)c->chunks.size()) {
+            ChunkIndex& cn = *c->chunks[nx];
+            const size_t T = (size_t)AS * Ppad;
+            b.sbeg2.ensure(T), b.scnt2.ensure(T), b.pcnt2.ensure(Ppad);
+            HIP_CHECK(hipEventRecord(c->ev_bnd_go, c->st));   // (what was queued so far may still read the second set: it held the previous chunk's bounds)
+            HIP_CHECK(hipStreamWaitEvent(c->st_side, c->ev_bnd_go, 0));
+            launch_bounds(b.qbucket.p, Ppad, AS, cn.hkey.p, cn.hval.p, cn.hshift, cn.hmask, cn.use_dir ? cn.dir.p : nullptr, cn.ubeg.p, NC, cn.E, b.sbeg2.p, b.scnt2.p,
+                          b.pcnt2.p, c->st_side);
+            HIP_CHECK(hipEventRecord(c->ev_bnd_done, c->st_side));
+            b.bnd_ci = nx;
+        }
     }
     HIP_CHECK(hipMemsetAsync(b.mark.p, 0, Ppad, c->st));
     i64 threshold = ch.threshold;

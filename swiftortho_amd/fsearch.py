@@ -313,12 +313,10 @@ def makedb(ref, space='11111111', nr=AA9, step=1, ht=-1, chk=500000, device=0):
             st, ed = i, min(i + chk, N)
             start, ent = s.chunk_index(k)
             soas = np.concatenate([[0], np.cumsum(lens[st:ed])]).astype(np.int64)
-            E = len(ent)
-            bucket = np.repeat(np.arange(NC, dtype=np.int64), np.diff(start.astype(np.int64)))
-            order = np.lexsort((np.iinfo(np.uint64).max - ent, bucket))   # bucket ascending, entry descending inside a bucket
-            e = ent[order]
-            locus = soas[(e >> np.uint64(32)).astype(np.int64)] + (e & np.uint64(0xFFFFFF)).astype(np.int64)
-            assert len(bucket) == E
+            # (so_chunk_download hands the entries over in the reference's slot order: bucket ascending, entry descending inside a bucket --
+            # the device puts them in that order, order_chunk in host_index.hip; until round 6 a host lexsort of the chunk did)
+            assert int(start[NC]) == len(ent)
+            locus = soas[(ent >> np.uint64(32)).astype(np.int64)] + (ent & np.uint64(0xFFFFFF)).astype(np.int64)
             name = '%s.%d' % (ref, i // chk)
             locus.astype('<i4').tofile(name + '.idx')
             soas.astype('<i4').tofile(name + '.soas')
