@@ -530,7 +530,7 @@ const ChunkIndex::RangeTab* range_table(so_ctx* c, ChunkIndex& ch, const ChunkIn
     if (cells * sizeof(u16) > ((size_t)1 << 30)) return t;
     t->tab.ensure(cells + 8);
     ch.row_of_slot.ensure((size_t)ch.E + 4);
-    c->d_small.ensure(16);
+    c->d_small.ensure(32);
     HIP_CHECK(hipMemsetAsync(c->d_small.p + 14, 0, sizeof(u32), c->st));
     launch_rtab_build(e.dk32.p, ch.E, ch.ubeg.p, ch.U, wb + e.k, R, t->tab.p, ch.row_of_slot.p, c->d_small.p + 14, c->st);
     const u32 flag = d2h_u32(c, c->d_small.p + 14);

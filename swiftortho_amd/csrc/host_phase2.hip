@@ -136,7 +136,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(n, 64));
         // (ordering inside blocks of 2^k queries instead of globally -- key = query block << 13 | rows -- was measured: 24.9-25.2 ms of
         // align rounds for k = 7 ... 13 against 24.8-25.2)
-        c->d_small.ensure(16);
+        c->d_small.ensure(32);
         if (split) HIP_CHECK(hipMemsetAsync(c->d_small.p + 12, 0, sizeof(u32), c->st));
         launch_task_rows(b.tasks.p, list, n, b.dev.d_off.p, c->ref.d_off.p, b.dev.d_bound.p, c->ref.d_bound.p, align_pk_max_len(), align_pk_max_score(),
                          split ? c->d_small.p + 12 : nullptr, b.ucount.p + 2, b.tmp64.p, c->st);
@@ -191,7 +191,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         first_round = false;
         if (spec_round) {
             b.spcnt.ensure((size_t)nq + 4), b.spoff.ensure((size_t)nq + 4), b.sidx.ensure((size_t)NT + 4);
-            c->d_small.ensure(16);
+            c->d_small.ensure(32);
             HIP_CHECK(hipMemsetAsync(c->d_small.p + 3, 0, sizeof(u32), c->st));
             launch_round_counts_spec(b.ntask.p, b.ntile.p, b.roffc.p, b.rk_slot.p, b.qcoff.p, b.st_state.p, nq, c->max_miss, minr, b.tasks.p, b.toff.p,
                                      b.dev.d_off.p, c->ref.d_off.p, c->d_bittab.p, so_ctx::BITTAB_N, c->ref.N, c->expect * spec_slack, b.rcnt.p, b.tcnt.p, b.spcnt.p,
@@ -262,7 +262,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
                 // (a lane walks a whole alignment alone: a launch lasts at least one alignment's ~0.4 ms however few tasks it holds -- the last
                 // rounds of config 3, 6.6 k and 64 tasks, took 0.63 and 0.40 ms; sixteen lanes per pair finish those in 0.1)
                 if (lane_on && NR - n_wide >= (1u << 18)) {
-                    c->d_small.ensure(16);
+                    c->d_small.ensure(32);
                     launch_align_lane(b.tasks.p, rlist + n_wide, NR - n_wide, pkc, b.dev.d_off.p, c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->d_small.p + 13, c->ncu, c->st);
                 } else {
                     launch_align_pk(b.tasks.p, rlist + n_wide, NR - n_wide, pkc, b.dev.d_off.p, c->ref.d_off.p, c->d_b62c.p, b.ares.p, c->st);
@@ -295,7 +295,7 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     const u32 emit_min_rows = (u32)std::max(1ll, tune().emit_min_rows);
     // (config 3, one batch: 1 part 57.0 ms per step, 4 parts 56.0)
     const u32 qstep = (nq + EMIT_PARTS - 1) / EMIT_PARTS;
-    c->d_small.ensure(16);
+    c->d_small.ensure(32);
     launch_stride_gather(b.ooff.p, qstep, (nq + qstep - 1) / qstep, c->d_small.p + 4, c->st);   // d_small[4 + p] = first row of range p
     stash_u32(c, dNO, 0);
     u32 NO, part_row[EMIT_PARTS_MAX + 1];
@@ -371,30 +371,37 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
         // not ordered keeps the 32-bit kernel for all of them
         u32 nwide_part[EMIT_PARTS_MAX] = {0};
         if (order_rows) {
-            // [t0, t1) of `in`, longest band first, to the same range of `out`; split: the wide tasks first, returns their number
-            auto order_list = [&](const u32* in, u32 t0, u32 t1, u32* out, bool split) -> u32 {
+            // [t0, t1) of `in`, longest band first, to the same range of `out`; wide (non-null): the wide tasks first, their number counted there
+            // (the ranges' counts come back in ONE copy behind the loop: a synchronisation per range stalled the range-by-range overlap)
+            c->d_small.ensure(32);
+            const bool split = traced_pk && pk_mixed;
+            if (split) HIP_CHECK(hipMemsetAsync(c->d_small.p + 16, 0, EMIT_PARTS_MAX * sizeof(u32), c->st));
+            auto order_list = [&](const u32* in, u32 t0, u32 t1, u32* out, u32* wide) {
                 const u32 n = t1 - t0;
-                if (!n) return 0u;
+                if (!n) return;
                 b.tmp64.ensure((size_t)n + 2), b.c_ft2.ensure((size_t)n + 2);
                 ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(n, 64));
-                c->d_small.ensure(16);
-                if (split) HIP_CHECK(hipMemsetAsync(c->d_small.p + 12, 0, sizeof(u32), c->st));
-                launch_task_rows(b.tasks.p, in + t0, n, b.dev.d_off.p, c->ref.d_off.p, b.dev.d_bound.p, c->ref.d_bound.p, split ? align_pk_max_len() : 0,
-                                 split ? align_pk_max_score() : 0u, split ? c->d_small.p + 12 : nullptr, nullptr, b.tmp64.p, c->st);
-                sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, in + t0, out + t0, n, split ? 14 : 13, c->st);
-                return split ? d2h_u32(c, c->d_small.p + 12) : 0u;
+                launch_task_rows(b.tasks.p, in + t0, n, b.dev.d_off.p, c->ref.d_off.p, b.dev.d_bound.p, c->ref.d_bound.p, wide ? align_pk_max_len() : 0,
+                                 wide ? align_pk_max_score() : 0u, wide, nullptr, b.tmp64.p, c->st);
+                sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, b.tmp64.p, b.c_ft2.p, in + t0, out + t0, n, wide ? 14 : 13, c->st);
             };
             b.tl_sorted.ensure((size_t)tn + 4);
             if (nspec) b.al_sorted.ensure((size_t)(NO - tn) + 4);
             for (int p = 0; p < parts; ++p) {
                 const u32 r0 = parts > 1 ? part_row[p] : 0u, r1 = parts > 1 ? part_row[p + 1] : NO;
-                const bool split = traced_pk && pk_mixed;
+                u32* wide = split ? c->d_small.p + 16 + p : nullptr;
                 if (nspec) {
-                    nwide_part[p] = order_list(tlist, pb[p], pb[p + 1], b.tl_sorted.p, split);
-                    (void)order_list(alist, r0 - pb[p], r1 - pb[p + 1], b.al_sorted.p, false);
+                    order_list(tlist, pb[p], pb[p + 1], b.tl_sorted.p, wide);
+                    order_list(alist, r0 - pb[p], r1 - pb[p + 1], b.al_sorted.p, nullptr);
                 } else {
-                    nwide_part[p] = order_list(tlist, r0, r1, b.tl_sorted.p, split);
+                    order_list(tlist, r0, r1, b.tl_sorted.p, wide);
                 }
+            }
+            if (split) {
+                u32* v = (u32*)small_host(c);
+                HIP_CHECK(hipMemcpyAsync(v, c->d_small.p + 16, EMIT_PARTS_MAX * sizeof(u32), hipMemcpyDeviceToHost, c->st));
+                HIP_CHECK(hipStreamSynchronize(c->st));
+                for (int p = 0; p < parts; ++p) nwide_part[p] = v[p];
             }
             tlist = b.tl_sorted.p;
             if (nspec) alist = b.al_sorted.p;

@@ -142,7 +142,7 @@ u32 d2h_u32(so_ctx* c, const u32* p) {
 // Totals of two scans that share d_scan_tmp, fetched with ONE synchronisation: the first total is parked in a
 // device word while the second scan runs.
 void stash_u32(so_ctx* c, const u32* p, int slot) {
-    c->d_small.ensure(16);
+    c->d_small.ensure(32);
     HIP_CHECK(hipMemcpyAsync(c->d_small.p + slot, p, sizeof(u32), hipMemcpyDeviceToDevice, c->st));
 }
 void d2h_pair(so_ctx* c, const u32* second, u32& a, u32& b) {
@@ -444,7 +444,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
             if (tab && tune().count_tab == 2) {   // tests: the counting pass must give the same matrix
                 b.bpart.ensure(nm + 4);
                 launch_bkt_pass(false, b.btd.p, qseg, NT, b.cs_hoff.p, b.cs_beg.p, b.cs_kbase.p, dk32, c->ref.d_off.p + ch.seq_lo, L, b.bpart.p, nullptr, c->st);
-                c->d_small.ensure(16);
+                c->d_small.ensure(32);
                 HIP_CHECK(hipMemsetAsync(c->d_small.p + 14, 0, sizeof(u32), c->st));
                 launch_u32_differ(b.bmat.p, b.bpart.p, nm, c->d_small.p + 14, c->st);
                 const u32 nd = d2h_u32(c, c->d_small.p + 14);
@@ -706,7 +706,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
         ensure_sort_tmp(c, sort_pairs_u64_u32_temp_bytes(NP, 64));
         sort_pairs_u64_u32(c->d_sort_tmp.p, c->d_sort_tmp.cap, q_qs, b.p_qs2.p, b.pidx.p, b.pidx2.p, NP, klr.bs + kl.bq, c->st);
         b.flags.ensure((size_t)NP + 4), b.gidx.ensure((size_t)NP + 4);
-        c->d_small.ensure(16);
+        c->d_small.ensure(32);
         launch_seg_flags(b.p_qs2.p, NP, b.flags.p, c->d_small.p, c->st);
         const u32* dS = scan_u32(b.flags.p, b.gidx.p, NP, false, c->d_scan_tmp.p, c->st);
         // per-query candidate segments and the longest one (d_small[0]), fetched with the candidate total
