@@ -509,6 +509,15 @@ void launch_align_traced(const AlnTask* tasks, const u32* ridx, u32 ntasks, cons
     launch_align_pk_traced(tasks, ridx, n_wide, ntasks, pk, qoff, roff, b62g, trace, trace_stride, tofs, out, tpos_out, tpos_base, st);
 }
 
+// the walks alone over list positions whose traces sit at tofs[position] (the alignments were made by an earlier launch_align_traced)
+void launch_traceback_tofs(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u32* qoff, const u8* r_res, const u32* roff,
+                           const u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out, hipStream_t st) {
+    if (!ntasks) return;
+    const u32 nw = traceback_waves(ntasks);
+    hipLaunchKernelGGL(k_traceback, dim3(nw + (ntasks + 63) / 64), dim3(64), 0, st, tasks, ridx, ntasks, q_res, qoff, r_res, roff, trace, trace_stride,
+                       (const u32*)nullptr, tofs, out, nw, (int)tune().trace_wave_rows);
+}
+
 void launch_traceback(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u32* qoff, const u8* r_res, const u32* roff,
                       const u32* trace, u32 trace_stride, const u32* tpos, AlnRes* out, hipStream_t st) {
     if (!ntasks) return;

@@ -264,6 +264,8 @@ void launch_align_pk_traced(const AlnTask* tasks, const u32* ridx, u32 t0, u32 t
                             u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out, u32* tpos_out, u32 tpos_base, hipStream_t st);
 void launch_traceback(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u32* qoff, const u8* r_res, const u32* roff,
                       const u32* trace, u32 trace_stride, const u32* tpos, AlnRes* out, hipStream_t st);
+void launch_traceback_tofs(const AlnTask* tasks, const u32* ridx, u32 ntasks, const u8* q_res, const u32* qoff, const u8* r_res, const u32* roff,
+                           const u32* trace, u32 trace_stride, const u32* tofs, AlnRes* out, hipStream_t st);
 void launch_stop_round_w(const AlnTask* tasks, const AlnRes* res, const u32* qcoff, const u32* ntask, const u32* ntile, const u32* roffc,
                          const u32* rk_slot, const u32* toff, const u32* rcnt, u32 nq, const u32* qoff, const u32* roff, const int* bittab,
                          int bittab_n, i64 D, double expect, double max_miss, i64 v, u32* sel, u32* st_state, int* bits,
