@@ -172,7 +172,9 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     // Speculative traces (k_round_counts_spec): in the FIRST round, the leading tasks of every query whose ungapped score alone would pass
     // the e-value test are aligned with traces at once; reported rows that have one skip the second alignment.  SOHIT_SPEC=0: off.
     // SOHIT_SPEC=0 / 1: off / on whatever the size (default: on from 2^21 tasks; below that the extra launches cost more than they save:
-    // config 2, 0.55 M tasks, 16.7 -> 17.1 ms).  SOHIT_SPEC_SLACK: the guess tests the ungapped score against expect x this (default 1e3:
+    // config 2, 0.55 M tasks, 16.7 -> 17.1 ms).  SOHIT_SPEC_SLACK: the guess tests the ungapped score against expect x this (default 1e6 since the end of
+    // round 6 -- with the cheaper walk and the one-launch alignment of the rows left over, config 3 interleaved: 1e2 47.70 ms, 1e3 47.56, 1e4 47.51, 1e5 47.38,
+    // 1e6 47.21, 1e7 47.17, 1e8 47.28, 1e10 53.2 (the first round's traces no longer fit); the weight-6 and mixed-length sets do not care.  Round 5, 1e3:
     // config 3 keeps 1.44 M traces, all of them of reported rows, 175 k rows are left for the second pass; 1: 1.30 M / 315 k; 1e6: 1.56 M /
     // 57 k with 1.3 k traces unused -- a wrong guess costs about as much as a right one saves).
     const bool spec_on = tune().spec >= 0 ? tune().spec != 0 : NT >= (1u << 21);

@@ -35,7 +35,7 @@
     X(I, trace_wave_rows, "SOHIT_TRACE_WAVE_ROWS", 1024, "traceback: bands of this many rows and more are walked by a wave of their own (0: never)")         \
     X(I, trace_wave_max, "SOHIT_TRACE_WAVE_MAX", 32768, "... among the first this many positions of a launch list")                                            \
     X(I, spec, "SOHIT_SPEC", -1, "speculative traces in the first round: 0 off, 1 on, -1 from 2^21 tasks on")                                                  \
-    X(D, spec_slack, "SOHIT_SPEC_SLACK", 1e3, "... the guess tests the ungapped score against expect x this (tests: 1e30 = every first-round task traced, 1e-30 = none)")          \
+    X(D, spec_slack, "SOHIT_SPEC_SLACK", 1e6, "... the guess tests the ungapped score against expect x this (tests: 1e30 = every first-round task traced, 1e-30 = none)")          \
     X(I, spec_cap, "SOHIT_SPEC_CAP", -1, "tests: most speculative traces kept (-1: all)")                                                                      \
     X(I, emit_parts, "SOHIT_EMIT_PARTS", 4, "... and otherwise")                                                                                               \
     X(I, emit_min_rows, "SOHIT_EMIT_MIN_ROWS", 1 << 18, "rows below which the emission is one part")                                                           \
