@@ -292,8 +292,10 @@ void phase2(so_ctx* c, Batch& b, HitBuf& out) {
     // back with the row total: ooff at every (nq / parts)-th query.
     enum { EMIT_PARTS_MAX = 8 };
     // SOHIT_EMIT_PARTS (1-8, default 4) / SOHIT_EMIT_MIN_ROWS (default 2^18: smaller results leave in one piece): tuning and test switches
-    // (with kept traces -- nspec -- the last stage is short: fewer ranges, SOHIT_SPEC_PARTS, default 2)
-    const int EMIT_PARTS = std::min<int>(EMIT_PARTS_MAX, std::max(1, nspec ? 2 : (int)tune().emit_parts));
+    // (with kept traces -- nspec -- on a batch of mixed lengths the last stage orders and launches per range: two ranges, 66.0 against 66.9 ms with
+    // four on the log-normal set; a uniform batch takes four since its left-over rows are aligned in one launch: config 3 1 range 48.26 ms, 2 47.19, 3 46.98,
+    // 4 46.91, 5 47.06, 6 47.16, 8 47.47)
+    const int EMIT_PARTS = std::min<int>(EMIT_PARTS_MAX, std::max(1, (nspec && (b.permuted || pk_mixed)) ? 2 : (int)tune().emit_parts));
     const u32 emit_min_rows = (u32)std::max(1ll, tune().emit_min_rows);
     // (config 3, one batch: 1 part 57.0 ms per step, 4 parts 56.0)
     const u32 qstep = (nq + EMIT_PARTS - 1) / EMIT_PARTS;
