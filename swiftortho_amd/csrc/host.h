@@ -215,7 +215,7 @@ struct so_ctx {
     DevBuf<u32> d_scan_tmp, d_tmp32a, d_tmp32b;
     DevBuf<u64> d_stats;
     DevBuf<u32> d_small;  // parked scan totals (stash_u32)
-    DevBuf<u32> ix_pcount, ix_bkt, ix_bkt2, ix_flags, ix_ridx, ix_plan, ix_tk;  // index build scratch
+    DevBuf<u32> ix_bkt, ix_bkt2, ix_flags, ix_ridx, ix_plan, ix_tk;  // index build scratch
     DevBuf<u64> ix_ent, ix_tv;
     DevBuf<u8> d_pcls;
     DevBuf<u8> d_sort_tmp;

@@ -103,35 +103,35 @@ void build_index(so_ctx* c) {
             // SOHIT_DIR_MAX: largest -M served by the bitmap + rank directory (NC / 4 bytes per chunk)
             ch->use_dir = (u64)NC <= (tune().dir_max >= 0 ? (u64)tune().dir_max : (1ull << 28));
         }
-        // 1. windows per position -> exclusive scan -> (bucket, entry) pairs in position order
+        // 1. (bucket, entry) pairs, ONE pass: position p's A x S windows at the fixed slots (p - p_lo) * AS + tag, an invalid window as bucket ~0
+        //    (until round 6: windows counted per position, scanned, emitted densely -- a counting pass, a scan and a host round trip more)
         const u32 npos = ch->p_hi - ch->p_lo;
-        c->ix_pcount.ensure((size_t)npos + 4);
-        c->d_scan_tmp.ensure(scan_u32_temp_elems((size_t)npos + 1) + 8);
-        dlap("alloc pcount / scan tmp");
-        launch_index_windows(false, c->ref.d_words.p, c->ref.d_pseq.p, c->ref.d_off.p, ch->p_lo, ch->p_hi, c->ref.Ppad, (u32)ch->seq_lo, c->cfg,
-                             c->ref.lut, (u32)c->step, c->ix_pcount.p, nullptr, nullptr, c->st);
+        const int AS = c->cfg.A * c->cfg.S;
+        const u64 nslots64 = (u64)npos * (u64)AS;
+        if (nslots64 >= (1ull << 31)) throw SoError("chunk holds 2^31 seed-window slots or more; lower -c");
+        const u32 nslots = (u32)nslots64;
         u32 E = 0;
-        if (npos) E = d2h_u32(c, scan_u32(c->ix_pcount.p, c->ix_pcount.p, npos, false, c->d_scan_tmp.p, c->st));
-        dlap("windows (count) + scan");
+        ch->U = 0;
+        u64 s2 = 0;
+        if (nslots) {
+            c->ix_bkt.ensure((size_t)nslots + 4), c->ix_ent.ensure((size_t)nslots + 4);
+            c->ix_plan.ensure(ixsort_plan_elems((u32)NC) + 8);
+            c->d_scan_tmp.ensure(scan_u32_temp_elems(std::max<size_t>(ixsort_plan_elems((u32)NC), (size_t)nslots + 1)) + 8);
+            dlap("alloc pairs / plan");
+            launch_index_windows_sparse(c->ref.d_words.p, c->ref.d_pseq.p, c->ref.d_off.p, ch->p_lo, ch->p_hi, c->ref.Ppad, (u32)ch->seq_lo, c->cfg, c->ref.lut,
+                                        (u32)c->step, c->ix_bkt.p, c->ix_ent.p, c->st);
+            // 2. group by bucket id (ascending): the slot layout of the reference's CSR.  Hand-written: two counting passes, k_ixsort.hip; the
+            //    first one's scan leaves the number of entries; members of a bucket land in no particular order (order_chunk)
+            E = d2h_u32(c, ixsort_count(c->ix_bkt.p, nslots, (u32)NC, c->ix_plan.p, c->d_scan_tmp.p, c->st));
+            dlap("windows + level-1 count");
+        }
         if ((u64)E >= (1ull << 29)) throw SoError("chunk index exceeds 2^29 entries (the lookup kernel addresses 8-byte slots with 32-bit byte offsets); lower -c");
         ch->E = E;
-        ch->U = 0;
         ch->entries.ensure((size_t)E + 4);
-        u64 s2 = 0;
         if (E) {
-            c->ix_bkt.ensure((size_t)E + 4), c->ix_bkt2.ensure((size_t)E + 4), c->ix_ent.ensure((size_t)E + 4);
-            dlap("alloc entries / pairs");
-            launch_index_windows(true, c->ref.d_words.p, c->ref.d_pseq.p, c->ref.d_off.p, ch->p_lo, ch->p_hi, c->ref.Ppad, (u32)ch->seq_lo, c->cfg,
-                                 c->ref.lut, (u32)c->step, c->ix_pcount.p, c->ix_bkt.p, c->ix_ent.p, c->st);
-            // 2. group by bucket id (ascending): the slot layout of the reference's CSR
-            const int bbits = ceil_log2((u64)NC);
-            dlap("windows (emit)");
-            // (hand-written: two counting passes, k_ixsort.hip; members of a bucket land in no particular order)
-            (void)bbits;
-            c->ix_plan.ensure(ixsort_plan_elems((u32)NC) + 8), c->ix_tk.ensure((size_t)E + 4), c->ix_tv.ensure((size_t)E + 4);
-            c->d_scan_tmp.ensure(scan_u32_temp_elems(ixsort_plan_elems((u32)NC)) + 8);
-            dlap("alloc grouping scratch");
-            ixsort_pairs(c->ix_bkt.p, c->ix_ent.p, E, (u32)NC, c->ix_plan.p, c->d_scan_tmp.p, c->ix_tk.p, c->ix_tv.p, c->ix_bkt2.p, ch->entries.p, c->st);
+            c->ix_bkt2.ensure((size_t)E + 4), c->ix_tk.ensure((size_t)E + 4), c->ix_tv.ensure((size_t)E + 4);
+            dlap("alloc entries / grouping scratch");
+            ixsort_finish(c->ix_bkt.p, c->ix_ent.p, nslots, (u32)NC, c->ix_plan.p, c->ix_tk.p, c->ix_tv.p, c->ix_bkt2.p, ch->entries.p, c->st);
             dlap("pair grouping");
             // 3. runs -> occupied bucket list, first slots, sizes
             c->ix_flags.ensure((size_t)E + 4), c->ix_ridx.ensure((size_t)E + 4);

@@ -9,59 +9,52 @@
 //   ub[0..U)      u32   occupied bucket ids, ascending;   ubeg[0..U] u32   first slot of each (ubeg[U] = E)
 //   hkey / hval         hash map bucket id -> (first slot | count << 32), linear probing, load <= 1/2
 //
-// Build: count windows per position -> exclusive scan -> emit (bucket, entry) pairs in position order (no atomics)
-// -> radix sort by bucket -> run heads -> unique list, run lengths (threshold statistics) -> hash map.
+// Build: (bucket, entry) pairs at fixed slots per position, invalid windows marked (k_index_windows_sparse: one pass; until round 6 count ->
+// scan -> dense emit) -> grouping by bucket id (k_ixsort.hip: two counting passes, the first one's scan = the number of entries) -> run heads
+// -> unique list, run lengths (threshold statistics) -> directory (bitmap + rank, or the hash map for very large -M).
 // "bucket = hash % NC, no key check" -- collisions included -- is unchanged: the map is keyed by the bucket id.
 //
 // The reference stores bucket members in descending insertion order and later visits them in slot order; here
-// the slot order inside a bucket is whatever the sort leaves, because every downstream consumer re-derives the
+// the slot order inside a bucket is whatever the grouping leaves, because every downstream consumer re-derives the
 // visiting order from the entry value itself (descending (subject, tag, pos) == descending insertion order) --
-// see DESIGN.md "ordering without sorting the index".  The one order-dependent rule, "the very last locus slot
-// is never read" (fsearch.py:2277, 2539), is kept by k_index_fixlast.
+// until order_chunk (host_index.hip: the chunk's first dense pass, or so_chunk_download) puts the members in that very
+// order.  The one order-dependent rule, "the very last locus slot is never read" (fsearch.py:2277, 2539), is kept by
+// k_index_fixlast.
 #include "common.h"
 #include "kernels.h"
 #include "seedhash.h"
 
-// EMIT = false: pcount[p - p_lo] = seed windows starting at packed position p (0 .. A * S).
-// EMIT = true : pcount holds the exclusive scan of those counts; the position writes its (bucket, entry) pairs there.
-template <bool EMIT>
-__global__ __launch_bounds__(TILE_POS) void k_index_windows(const u32* __restrict__ words, const u32* __restrict__ pseq,
-                                                            const u32* __restrict__ off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
-                                                            SeedCfg cfg, HashLut lut, u32 step, u32* __restrict__ pcount,
-                                                            u32* __restrict__ bkt, u64* __restrict__ ent) {
+// ONE pass instead of count + scan + emit (round 6): position p writes its A x S (bucket, entry) pairs to the fixed slots (p - p_lo) * AS + tag,
+// an invalid window as bucket ~0 (never a bucket id: the directory kernels refuse NC - 1 and above) -- the grouping (k_ixsort.hip) skips those
+// and its own scan yields the number of entries.  Saves the counting pass (0.17 ms per 50 k-sequence chunk), a scan and a host round trip.
+__global__ __launch_bounds__(TILE_POS) void k_index_windows_sparse(const u32* __restrict__ words, const u32* __restrict__ pseq, const u32* __restrict__ off, u32 p_lo,
+                                                                   u32 p_hi, u32 Ppad, u32 seq_lo, SeedCfg cfg, HashLut lut, u32 step, u32* __restrict__ bkt,
+                                                                   u64* __restrict__ ent) {
     __shared__ u8 s_cls[TILE_POS + MAX_SEEDLEN];
     const u32 p0 = p_lo + blockIdx.x * TILE_POS;
     stage_classes(words, p0, Ppad, s_cls);
     __syncthreads();
     const u32 p = p0 + threadIdx.x;
     if (p >= p_hi) return;
-    u32 n = 0;
+    const u32 AS = (u32)(cfg.A * cfg.S);
+    const size_t base = (size_t)(p - p_lo) * AS;
     bool live = s_cls[threadIdx.x] < HCLS_SEP;  // separator or x: no window starts here
     u32 j = 0, pos = 0;
-    if (live && (EMIT || step > 1)) {
+    if (live) {
         j = pseq[p];
         pos = p - (off[j] + j);
         if (step > 1 && (pos % step) != 0) live = false;  // xrange(0, L - k + 1, step), fsearch.py:534
     }
-    if (live) {
-        u32 slot = EMIT ? pcount[p - p_lo] : 0u;
-        u32 bucket[MAX_PATTERNS];
-        for (int a = 0; a < cfg.A; ++a) {
-            const u32 mask = hash_position(s_cls + threadIdx.x, cfg, lut.v[a], bucket);
-            if (!EMIT) {
-                n += (u32)__popc(mask);
-            } else {
-                for (int s = 0; s < cfg.S; ++s) {
-                    if (!((mask >> s) & 1u)) continue;
-                    const u32 tag = (u32)(a * cfg.S + s);
-                    bkt[slot] = bucket[s];
-                    ent[slot] = ((u64)(j - seq_lo) << 32) | ((u64)tag << 24) | (u64)pos;
-                    ++slot;
-                }
-            }
+    u32 bucket[MAX_PATTERNS];
+    for (int a = 0; a < cfg.A; ++a) {
+        const u32 mask = live ? hash_position(s_cls + threadIdx.x, cfg, lut.v[a], bucket) : 0u;
+        for (int sd = 0; sd < cfg.S; ++sd) {
+            const u32 tag = (u32)(a * cfg.S + sd);
+            const bool ok = ((mask >> sd) & 1u) != 0;
+            bkt[base + tag] = ok ? bucket[sd] : 0xFFFFFFFFu;
+            if (ok) ent[base + tag] = ((u64)(j - seq_lo) << 32) | ((u64)tag << 24) | (u64)pos;
         }
     }
-    if (!EMIT) pcount[p - p_lo] = n;
 }
 
 // ---- runs of equal bucket ids in the sorted pair list ---------------------------------------------------
@@ -295,16 +288,11 @@ void launch_encode_delta(const u64* entries, u32 E, int sh_subj, int sh_diag, u3
     hipLaunchKernelGGL(k_encode_delta, dim3((E + 255) / 256), dim3(256), 0, st, entries, E, sh_subj, sh_diag, maxslen, dkeys);
 }
 
-void launch_index_windows(bool emit, const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
-                          const SeedCfg& cfg, const HashLut& lut, u32 step, u32* pcount, u32* bkt, u64* ent, hipStream_t st) {
+void launch_index_windows_sparse(const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo, const SeedCfg& cfg, const HashLut& lut, u32 step,
+                                 u32* bkt, u64* ent, hipStream_t st) {
     if (p_hi <= p_lo) return;
     const u32 nb = (p_hi - p_lo + TILE_POS - 1) / TILE_POS;
-    if (emit)
-        hipLaunchKernelGGL((k_index_windows<true>), dim3(nb), dim3(TILE_POS), 0, st, words, pseq, off, p_lo, p_hi, Ppad, seq_lo, cfg, lut, step,
-                           pcount, bkt, ent);
-    else
-        hipLaunchKernelGGL((k_index_windows<false>), dim3(nb), dim3(TILE_POS), 0, st, words, pseq, off, p_lo, p_hi, Ppad, seq_lo, cfg, lut, step,
-                           pcount, bkt, ent);
+    hipLaunchKernelGGL(k_index_windows_sparse, dim3(nb), dim3(TILE_POS), 0, st, words, pseq, off, p_lo, p_hi, Ppad, seq_lo, cfg, lut, step, bkt, ent);
 }
 
 void launch_run_heads(const u32* bkt, u32 E, u32* flags, hipStream_t st) {

@@ -47,7 +47,10 @@ __global__ __launch_bounds__(IXS_T1) void k_ixs_count(const u32* __restrict__ ke
     __syncthreads();
     u32 lo, hi;
     ixs_slice(E, lo, hi);
-    for (u32 i = lo + threadIdx.x; i < hi; i += IXS_T1) atomicAdd(&s_cnt[keys[i] >> wsh], 1u);
+    for (u32 i = lo + threadIdx.x; i < hi; i += IXS_T1) {
+        const u32 k = keys[i];
+        if (k != 0xFFFFFFFFu) atomicAdd(&s_cnt[k >> wsh], 1u);   // (~0: the slot of an invalid window, k_index_windows_sparse)
+    }
     __syncthreads();
     for (u32 i = threadIdx.x; i < nbins; i += IXS_T1) plan[(size_t)i * IXS_G + ixs_col()] = s_cnt[i];
     if (blockIdx.x == 0 && threadIdx.x == 0) plan[(size_t)nbins * IXS_G] = 0;   // (the scan leaves E there: the end of the last bin)
@@ -62,6 +65,7 @@ __global__ __launch_bounds__(IXS_T1) void k_ixs_scatter(const u32* __restrict__ 
     ixs_slice(E, lo, hi);
     for (u32 i = lo + threadIdx.x; i < hi; i += IXS_T1) {
         const u32 k = keys[i];
+        if (k == 0xFFFFFFFFu) continue;
         const u32 at = atomicAdd(&s_cur[k >> wsh], 1u);
         tk[at] = k, tv[at] = vals[i];
     }
@@ -154,13 +158,24 @@ __global__ __launch_bounds__(IXS_T2) void k_ixs_bin(const u32* __restrict__ tk, 
     }
 }
 
-// keys in [0, NC).  plan: ixsort_plan_elems(NC) u32; (tk, tv): E pairs of scratch; (kin, vin) are overwritten when NC > 2^27.
-void ixsort_pairs(u32* kin, u64* vin, u32 E, u32 NC, u32* plan, u32* scan_tmp, u32* tk, u64* tv, u32* kout, u64* vout, hipStream_t st) {
-    if (!E) return;
+// keys in [0, NC), or ~0 = no pair in this slot (n slots in all).  plan: ixsort_plan_elems(NC) u32; (tk, tv), (kout, vout): E pairs, E = the
+// number of valid slots = the plan's last word after ixsort_count; (kin, vin) are overwritten when NC > 2^27.
+const u32* ixsort_count(const u32* kin, u32 n, u32 NC, u32* plan, u32* scan_tmp, hipStream_t st) {   // -> device word holding E
     const int wsh = ixs_wsh(NC);
     const u32 nbins = ixsort_bins(NC);
-    hipLaunchKernelGGL(k_ixs_count, dim3(IXS_G), dim3(IXS_T1), 0, st, kin, E, wsh, nbins, plan);
+    hipLaunchKernelGGL(k_ixs_count, dim3(IXS_G), dim3(IXS_T1), 0, st, kin, n, wsh, nbins, plan);
     scan_u32(plan, plan, (size_t)nbins * IXS_G + 1, false, scan_tmp, st);
-    hipLaunchKernelGGL(k_ixs_scatter, dim3(IXS_G), dim3(IXS_T1), 0, st, kin, vin, E, wsh, nbins, plan, tk, tv);
+    return plan + (size_t)nbins * IXS_G;
+}
+void ixsort_finish(u32* kin, u64* vin, u32 n, u32 NC, const u32* plan, u32* tk, u64* tv, u32* kout, u64* vout, hipStream_t st) {
+    if (!n) return;
+    const int wsh = ixs_wsh(NC);
+    const u32 nbins = ixsort_bins(NC);
+    hipLaunchKernelGGL(k_ixs_scatter, dim3(IXS_G), dim3(IXS_T1), 0, st, kin, vin, n, wsh, nbins, plan, tk, tv);
     hipLaunchKernelGGL(k_ixs_bin, dim3(nbins), dim3(IXS_T2), 0, st, tk, tv, plan, wsh, kin, vin, kout, vout);
+}
+void ixsort_pairs(u32* kin, u64* vin, u32 E, u32 NC, u32* plan, u32* scan_tmp, u32* tk, u64* tv, u32* kout, u64* vout, hipStream_t st) {
+    if (!E) return;
+    (void)ixsort_count(kin, E, NC, plan, scan_tmp, st);
+    ixsort_finish(kin, vin, E, NC, plan, tk, tv, kout, vout, st);
 }

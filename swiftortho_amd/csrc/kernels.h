@@ -29,6 +29,11 @@ void sort_pairs_u64_u32(void* temp, size_t temp_bytes, const u64* kin, u64* kout
 // ixsort_plan_elems(NC) u32, scan_tmp: scan_u32_temp_elems of that, (tk, tv): E pairs of scratch; (kin, vin) are scratch too when NC > 2^27
 size_t ixsort_plan_elems(u32 NC);
 void ixsort_pairs(u32* kin, u64* vin, u32 E, u32 NC, u32* plan, u32* scan_tmp, u32* tk, u64* tv, u32* kout, u64* vout, hipStream_t st);
+// the same in two steps over n SLOTS of which some hold no pair (key ~0): the count and its scan leave the number of pairs in the returned device word
+const u32* ixsort_count(const u32* kin, u32 n, u32 NC, u32* plan, u32* scan_tmp, hipStream_t st);
+void ixsort_finish(u32* kin, u64* vin, u32 n, u32 NC, const u32* plan, u32* tk, u64* tv, u32* kout, u64* vout, hipStream_t st);
+void launch_index_windows_sparse(const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo, const SeedCfg& cfg, const HashLut& lut, u32 step,
+                                 u32* bkt, u64* ent, hipStream_t st);
 
 // k_prep.hip
 void launch_layout(const u8* res, const u32* off, u32 nseq, u32 P, u32 Ppad, const u8* hmap, u32* pseq, u8* pcls, u32* words,
@@ -54,8 +59,6 @@ void launch_copy_range(const u8* src, u8* dst, size_t n, hipStream_t st);
 
 // k_index.hip
 #define HTAB_EMPTY 0xFFFFFFFFu
-void launch_index_windows(bool emit, const u32* words, const u32* pseq, const u32* off, u32 p_lo, u32 p_hi, u32 Ppad, u32 seq_lo,
-                          const SeedCfg& cfg, const HashLut& lut, u32 step, u32* pcount, u32* bkt, u64* ent, hipStream_t st);
 void launch_run_heads(const u32* bkt, u32 E, u32* flags, hipStream_t st);
 void launch_run_list(const u32* bkt, const u32* flags, const u32* ridx, u32 E, u32 U, u32* ub, u32* ubeg, u32* cnt, hipStream_t st);
 void launch_dir_build(const u32* ub, u32 U, u64* dir /*zeroed, NC / 32 + 1 words*/, hipStream_t st);
