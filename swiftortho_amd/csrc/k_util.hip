@@ -168,7 +168,8 @@ __global__ __launch_bounds__(SS_THREADS) void k_scan_small(const u32* __restrict
     }
     if (threadIdx.x == 0) *total = carry;
 }
-#define SCAN_SMALL_TILES 17  // up to 136 k values: a full batch of 131072 queries (+ 1) stays in the one-launch path
+#define SCAN_SMALL_TILES 4   // up to 32 k values in ONE launch (config 2's 10 k queries: 14.2 against 14.5 ms); above that the three kernels are faster -- a 100 k-value scan
+                            // takes 26 us in one workgroup and 5 + 5 + 7 in three launches, and a config-3 step holds 21 of them (46.5 -> 46.15 ms)
 
 size_t scan_u32_temp_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 2; }
 
