@@ -312,6 +312,7 @@ void parallel_for(i64 n, F f) {
 // ---------------------------------------------------------------------------------------------
 // Search
 // ---------------------------------------------------------------------------------------------
+#define QCLASSES_MAX 5
 struct Batch {
     i64 q_lo = 0, q_hi = 0;  // absolute query ordinals
     u32 nq = 0;
@@ -331,6 +332,13 @@ struct Batch {
     i64 lay_lo = -1, lay_hi = -1;
     bool lay_classes = false;
     bool permuted = false;
+    // functions of the slot layout, made with it (the host loops over a 100 k-query batch that found them again for every search and every
+    // chunk were ~0.1 ms of GPU idle per chunk): are the classes in order; first slot of every class (+ nq); longest query of every class and
+    // of every block of 256 slots
+    bool cls_sorted = true;
+    u32 cls_start[QCLASSES_MAX + 1] = {0};
+    u32 cls_maxq[QCLASSES_MAX] = {0};
+    std::vector<u32> blkmax;
     // slots [q_defer, nq): the length class whose longest members' k-mer order is still being computed on the side stream; their
     // frequency cap (and everything after it) waits for ev_korder, the classes before them do not
     u32 q_defer = 0;
@@ -381,6 +389,7 @@ struct Batch {
 // bucket ranges follow its longest query, and the seed hits a query brings to a bucket grow with its length: inside a class
 // they differ by a factor of two (eight in the first), so the grouping kernel's buckets stay near their target size.
 #define QCLASSES 5
+static_assert(QCLASSES <= QCLASSES_MAX, "Batch::cls_start");
 inline u8 query_class(u32 len) { return len < 512 ? 0 : len < 1024 ? 1 : len < 2048 ? 2 : len < 4096 ? 3 : 4; }
 
 // wall-clock stage laps (stream-synchronising, so only when profiling)

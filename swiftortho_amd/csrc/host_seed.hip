@@ -26,10 +26,24 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
             b.qid[at[k]++] = i;
         }
     }
+    b.blkmax.assign(((size_t)b.nq + 255) / 256, 0u);
+    for (int k = 0; k < QCLASSES; ++k) b.cls_maxq[k] = 0;
+    b.cls_sorted = true;
     for (u32 i = 0; i < b.nq; ++i) {
         u32 ln = Q.len(q_lo + b.qid[i]);
         b.h_off[i + 1] = b.h_off[i] + ln;
         b.maxqlen = std::max(b.maxqlen, ln);
+        b.blkmax[i >> 8] = std::max(b.blkmax[i >> 8], ln);
+        b.cls_maxq[b.qcls[i]] = std::max(b.cls_maxq[b.qcls[i]], ln);
+        if (i && b.qcls[i] < b.qcls[i - 1]) b.cls_sorted = false;
+    }
+    {
+        u32 at = 0;
+        for (int k = 0; k < QCLASSES; ++k) {
+            b.cls_start[k] = at;
+            while (b.cls_sorted && at < b.nq && b.qcls[at] == k) ++at;
+        }
+        b.cls_start[QCLASSES] = b.nq;
     }
     }
     const u32* d_qid = nullptr;
@@ -51,12 +65,10 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
             // a class-ordered batch keeps its long queries at the end: the instances for them start there, and the one for the queries
             // above 4096 residues (one wave per query: 0.4 ms for a 30 000-residue giant) runs on the side stream beside the others
             u32 q_mid = 0, q_long = 0;
-            bool ordered = true;
-            for (u32 i = 1; i < b.nq && ordered; ++i) ordered = b.qcls[i] >= b.qcls[i - 1];
+            const bool ordered = b.cls_sorted;
             if (ordered && tune().qclass) {
-                while (q_mid < b.nq && b.qcls[q_mid] < 2) ++q_mid;      // classes 0, 1: below 1024 residues
-                q_long = q_mid;
-                while (q_long < b.nq && b.qcls[q_long] < 4) ++q_long;   // class 4: 4096 and more
+                q_mid = b.cls_start[2];      // classes 0, 1: below 1024 residues
+                q_long = b.cls_start[4];     // class 4: 4096 and more
             }
             const bool seg_aside = b.maxqlen > 4096;
             if (seg_aside) {
@@ -93,17 +105,19 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
     {
         // queries with more windows than the LDS sort holds use global scratch; in a class-ordered batch they are the tail
         u32 q_long = b.nq;
-        for (u32 i = 0; i < b.nq; ++i)
-            if ((i64)(b.h_off[i + 1] - b.h_off[i]) - c->cfg.mink + 1 > (i64)ksc_lds_max()) {
-                q_long = i;
-                break;
-            }
+        for (u32 blk = 0; blk < (u32)b.blkmax.size() && q_long == b.nq; ++blk) {   // (the first slot whose query is too long: block maxima first)
+            if ((i64)b.blkmax[blk] - c->cfg.mink + 1 <= (i64)ksc_lds_max()) continue;
+            for (u32 i = blk << 8; i < std::min<u32>(b.nq, (blk + 1) << 8); ++i)
+                if ((i64)(b.h_off[i + 1] - b.h_off[i]) - c->cfg.mink + 1 > (i64)ksc_lds_max()) {
+                    q_long = i;
+                    break;
+                }
+        }
         if (q_long < b.nq) b.gx.ensure(nres + 4), b.gL.ensure(nres + 4), b.gR.ensure(nres + 4);
         // in a class-ordered batch the long ones are the tail of the last class: their order is computed on the side stream
         // (SOHIT_KSC_ASYNC=0: on the batch's stream)
         const bool async_on = true;
-        bool ordered = true;
-        for (u32 i = 1; i < b.nq && ordered; ++i) ordered = b.qcls[i] >= b.qcls[i - 1];
+        const bool ordered = b.cls_sorted;
         b.korder_async = async_on && q_long < b.nq && ordered && b.qcls[q_long] != b.qcls[0];
         if (b.korder_async) {
             b.q_defer = q_long;
@@ -257,15 +271,28 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
     // neighbouring sparse classes are searched as ONE pass (heterogeneous 100 k set, headline seed: ten passes per step -> four).
     // The class still waiting for its k-mer orders (korder_async) is never merged into an earlier pass.
     int grp[QCLASSES];
+    unsigned long long cls_hits[QCLASSES] = {0};
+    bool whole_classes = false;
     {
         const bool merge_on = tune().pass_merge;
         unsigned long long hits[QCLASSES] = {0}, cnt[QCLASSES] = {0};
         u32 maxq[QCLASSES] = {0};
         const u32 known = b.korder_async ? b.q_defer : b.nq;   // (the deferred class's counts arrive later)
-        for (u32 q = 0; q < known; ++q) {
-            const int k = b.qcls[q];
-            hits[k] += qh[q], cnt[k]++, maxq[k] = std::max(maxq[k], b.h_off[q + 1] - b.h_off[q]);
+        if (b.cls_sorted && known == b.nq) {   // the classes are slot ranges: their sizes and longest queries came with the layout
+            for (int k = 0; k < QCLASSES; ++k) {
+                cnt[k] = b.cls_start[k + 1] - b.cls_start[k], maxq[k] = b.cls_maxq[k];
+                unsigned long long h = 0;
+                for (u32 q = b.cls_start[k]; q < b.cls_start[k + 1]; ++q) h += qh[q];
+                hits[k] = h;
+            }
+        } else {
+            for (u32 q = 0; q < known; ++q) {
+                const int k = b.qcls[q];
+                hits[k] += qh[q], cnt[k]++, maxq[k] = std::max(maxq[k], b.h_off[q + 1] - b.h_off[q]);
+            }
         }
+        whole_classes = b.cls_sorted && known == b.nq;   // a pass may take a class in one step when all of it fits
+        for (int k = 0; k < QCLASSES; ++k) cls_hits[k] = hits[k];
         {   // Ordering the chunk's buckets and building a table of range boundaries costs ~1.2 ms per 50 k-sequence chunk (once per index build)
             // and saves 0.58 ms per 10^9-hit pass: worth it when this batch alone brings the chunk two passes (the 10 k-protein config 2 has
             // one pass in all: 14.3 -> 14.7 ms with it)
@@ -290,6 +317,8 @@ void seed_stage(so_ctx* c, Batch& b, int ci) {
         if (b.korder_async && qa >= b.q_defer) chunk_qhits_deferred(c, b, ci);
         unsigned long long acc = 0;
         u32 qb = qa;
+        while (whole_classes && qb < b.nq && qb == b.cls_start[b.qcls[qb]] && acc + cls_hits[b.qcls[qb]] <= budget && grp[b.qcls[qb]] == grp[b.qcls[qa]])
+            acc += cls_hits[b.qcls[qb]], qb = b.cls_start[b.qcls[qb] + 1];   // (what the query-by-query loop below would do, without the 100 k steps)
         while (qb < b.nq && (qb == qa || (acc + qh[qb] <= budget && grp[b.qcls[qb]] == grp[b.qcls[qa]]))) acc += qh[qb++];
         if (acc >= 0xFFFFFFF0ull) throw SoError("a single query visits >= 2^32 index entries in one chunk: lower -c");
         if (acc) seed_pass(c, b, ci, qa, qb, wall(), sc), ++c->cnt.seed_passes;
@@ -322,7 +351,10 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     // key layout.  Query-position bits follow the PASS's longest query (passes hold one length class, seed_stage); subject and
     // diagonal bits come from the compact banded addends when they fit (band_encoding), else from the chunk's longest sequence.
     u32 pmaxq = 0;
-    for (u32 q = qa; q < qb; ++q) pmaxq = std::max(pmaxq, b.h_off[q + 1] - b.h_off[q]);
+    for (u32 q = qa; q < qb;) {   // (whole blocks of 256 slots through their maxima)
+        if ((q & 255u) == 0 && q + 256u <= qb) pmaxq = std::max(pmaxq, b.blkmax[q >> 8]), q += 256u;
+        else pmaxq = std::max(pmaxq, b.h_off[q + 1] - b.h_off[q]), ++q;
+    }
     KeyLayout kl;
     kl.bq = ceil_log2((u64)b.nq + 1);
     kl.bp = ceil_log2(std::max<u32>(pmaxq, 2));
