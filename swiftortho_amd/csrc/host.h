@@ -343,6 +343,10 @@ struct Batch {
     // frequency cap (and everything after it) waits for ev_korder, the classes before them do not
     u32 q_defer = 0;
     bool korder_async = false;
+    // the k-mer orders are computed by the first chunk in which a query reaches its frequency cap (chunk_qhits -> order_queries);
+    // ksc_long = first batch slot whose order needs global scratch
+    bool korder_ready = false;
+    u32 ksc_long = 0;
     DevBuf<u32> d_qid, d_ocnt, d_ostart;
     SeqSet dev;              // device arrays only (d_res = masked raw, d_scls, d_off, d_words, d_pseq)
     DevBuf<u32> qbucket, korder, sbeg, scnt, pcnt, eff, nz, hoff, cidx;
@@ -538,6 +542,7 @@ void order_chunk(so_ctx* c, ChunkIndex& ch);
 const ChunkIndex::RangeTab* range_table(so_ctx* c, ChunkIndex& ch, const ChunkIndex::BandEnc& e, int wb, u32 R);
 // host_seed.hip: batch preparation and the seed stage
 void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi);
+void order_queries(so_ctx* c, Batch& b);
 void* small_host(so_ctx* c);
 u32 d2h_u32(so_ctx* c, const u32* p);
 void stash_u32(so_ctx* c, const u32* p, int slot);

@@ -1,6 +1,28 @@
 // host_seed.hip -- libsohit.so host side: batch preparation and the seed stage -- bucket bounds, frequency cap, lookup + diagonal binning, ungapped extension, best diagonal, candidate order (see host.h).
 #include "host.h"
 
+// The k-mer orders of the batch's queries (fsearch.py:2660-2666: windows by self score, the reference's own quicksort replayed: 1.3 ms
+// for 100 k queries).  Only the frequency cap reads them, and only for a query whose windows together exceed its limit in the chunk at
+// hand: the batch's first chunk with such a query asks for them (chunk_qhits; SOHIT_KSC_LAZY=0: prepare_batch does), a batch without
+// one never does -- the long seeds.  In a class-ordered batch the queries that need global scratch are the tail of the last class: their
+// order is computed on the side stream while the classes before them are searched.
+void order_queries(so_ctx* c, Batch& b) {
+    const u32 q_long = b.ksc_long;
+    const size_t nres = b.h_off[b.nq];
+    if (q_long < b.nq) b.gx.ensure(nres + 4), b.gL.ensure(nres + 4), b.gR.ensure(nres + 4);
+    b.korder_async = q_long < b.nq && b.cls_sorted && b.qcls[q_long] != b.qcls[0];
+    if (b.korder_async) {
+        b.q_defer = q_long;
+        while (b.q_defer > 0 && b.qcls[b.q_defer - 1] == b.qcls[q_long]) --b.q_defer;
+        HIP_CHECK(hipEventRecord(c->ev_side_go, c->st));   // the batch's class arrays are on the device
+        HIP_CHECK(hipStreamWaitEvent(c->st_side, c->ev_side_go, 0));
+    }
+    launch_ksc_order(b.dev.d_scls.p, b.dev.d_off.p, b.nq, q_long, c->cfg.mink, c->d_b62c.p, b.gx.p, b.gL.p, b.gR.p, b.korder.p, c->st,
+                     b.korder_async ? c->st_side : c->st);
+    if (b.korder_async) HIP_CHECK(hipEventRecord(c->ev_korder, c->st_side));
+    b.korder_ready = true;
+}
+
 void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
     if (b.korder_async || b.bnd_ci >= 0) HIP_CHECK(hipStreamSynchronize(c->st_side));   // (a batch that never reached its long queries' passes / its last chunks)
     b.korder_async = false;
@@ -113,21 +135,9 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
                     break;
                 }
         }
-        if (q_long < b.nq) b.gx.ensure(nres + 4), b.gL.ensure(nres + 4), b.gR.ensure(nres + 4);
-        // in a class-ordered batch the long ones are the tail of the last class: their order is computed on the side stream
-        // (SOHIT_KSC_ASYNC=0: on the batch's stream)
-        const bool async_on = true;
-        const bool ordered = b.cls_sorted;
-        b.korder_async = async_on && q_long < b.nq && ordered && b.qcls[q_long] != b.qcls[0];
-        if (b.korder_async) {
-            b.q_defer = q_long;
-            while (b.q_defer > 0 && b.qcls[b.q_defer - 1] == b.qcls[q_long]) --b.q_defer;
-            HIP_CHECK(hipEventRecord(c->ev_side_go, c->st));   // the batch's class arrays are on the device
-            HIP_CHECK(hipStreamWaitEvent(c->st_side, c->ev_side_go, 0));
-        }
-        launch_ksc_order(b.dev.d_scls.p, b.dev.d_off.p, b.nq, q_long, c->cfg.mink, c->d_b62c.p, b.gx.p, b.gL.p, b.gR.p, b.korder.p, c->st,
-                         b.korder_async ? c->st_side : c->st);
-        if (b.korder_async) HIP_CHECK(hipEventRecord(c->ev_korder, c->st_side));
+        b.ksc_long = q_long;
+        b.korder_ready = false;
+        if (!tune().ksc_lazy) order_queries(c, b);
     }
     b.sbeg.ensure(T), b.scnt.ensure(T), b.eff.ensure(T + 4), b.nz.ensure(T + 4), b.hoff.ensure(T + 4), b.cidx.ensure(T + 4);
     b.pcnt.ensure(Ppad), b.mark.ensure(Ppad);
@@ -208,14 +218,27 @@ const unsigned long long* chunk_qhits(so_ctx* c, Batch& b, int ci) {
     i64 threshold = ch.threshold;
     if (c->thr >= 1 || threshold == 0) threshold = c->thr;  // `thr < 1 and DB.threshold or thr`, fsearch.py:2992
     b.qhits.ensure((size_t)b.nq + 2);
-    const u32 n1 = b.korder_async ? b.q_defer : b.nq;   // (the last length class follows in chunk_qhits_deferred)
-    launch_cap(b.korder.p, b.dev.d_off.p, 0, n1, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, c->st);
-    if (c->h_qhits_cap < b.nq) {  // pinned: a pageable read of this array costs more than the kernels around it
+    if (c->h_qhits_cap < (size_t)b.nq + 1) {  // pinned: a pageable read of this array costs more than the kernels around it
         if (c->h_qhits) (void)hipHostFree(c->h_qhits);
         c->h_qhits_cap = (size_t)b.nq + 1024;
         HIP_CHECK(hipHostMalloc((void**)&c->h_qhits, c->h_qhits_cap * sizeof(unsigned long long), hipHostMallocDefault));
     }
     unsigned long long* qh = c->h_qhits;
+    if (!b.korder_ready) {
+        // no orders yet: a query that stays below its cap keeps all its windows (k_cap_all).  The first chunk in which one does not has the
+        // orders computed -- every query's: picking the open ones out costs more launches than it saves, and the longest of them would have
+        // its order computed on the critical path -- and falls through to the ordered cap, where the batch's later chunks go at once
+        launch_cap_all(b.dev.d_off.p, b.nq, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, b.qhits.p + b.nq, c->st);
+        HIP_CHECK(hipMemcpyAsync(qh, b.qhits.p, ((size_t)b.nq + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
+        HIP_CHECK(hipStreamSynchronize(c->st));
+        if (tune().debug) fprintf(stderr, "[sohit] chunk %d: %llu of %u queries reach their frequency cap\n", ci, qh[b.nq], b.nq);
+        if (!qh[b.nq]) return qh;
+        if (c->profile) c->tm["seed.kmer_orders_at_chunk"] += ci + 1;   // (tests: which chunk asked; one batch per search there)
+        order_queries(c, b);
+        HIP_CHECK(hipMemsetAsync(b.mark.p, 0, Ppad, c->st));
+    }
+    const u32 n1 = b.korder_async ? b.q_defer : b.nq;   // (the last length class follows in chunk_qhits_deferred)
+    launch_cap(b.korder.p, b.dev.d_off.p, 0, n1, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, c->st);
     HIP_CHECK(hipMemcpyAsync(qh, b.qhits.p, (size_t)n1 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
     HIP_CHECK(hipStreamSynchronize(c->st));
     return qh;

@@ -184,6 +184,31 @@ __global__ __launch_bounds__(256) void k_cap(const u32* __restrict__ korder, con
     if (lane == 0) qhits[q] = cum;  // seed hits this query will visit in this chunk
 }
 
+// The cap without the order: the loop above refuses a position only when the total of the positions BEFORE it exceeds the limit, so a
+// query whose windows' counts sum to no more than the limit keeps every window whatever the order (fsearch.py:2667-2677: the `break`
+// is never reached).  One wave per query adds the counts up; a query at or below its limit has all its windows marked and its total
+// returned, any other is counted in *over -- the host then has the k-mer orders computed (once per batch) and runs k_cap.
+__global__ __launch_bounds__(256) void k_cap_all(const u32* __restrict__ qoff, u32 nq, int mink, const u32* __restrict__ pcnt, i64 threshold,
+                                                 u8* __restrict__ mark, unsigned long long* __restrict__ qhits, unsigned long long* __restrict__ over) {
+    const u32 q = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const u32 base = qoff[q];
+    const int ql = (int)(qoff[q + 1] - base);
+    const int nk = ql - mink + 1;
+    const u32 pbase = base + q;
+    unsigned long long sum = 0;
+    for (int r = lane; r < nk; r += 64) sum += pcnt[pbase + r];
+#pragma unroll
+    for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+    if (nk > 0 && (i64)sum > threshold * (i64)ql) {
+        if (lane == 0) atomicAdd(over, 1ull);
+        return;
+    }
+    for (int r = lane; r < nk; r += 64) mark[pbase + r] = 1;
+    if (lane == 0) qhits[q] = sum;
+}
+
 // ---- effective per-seed hit counts + compaction of non-empty seeds --------------------------------
 // (a pass touches the seed slots of ITS queries only, [AS * p_lo, AS * p_hi): with several passes per chunk -- one per query length
 // class -- whole-batch sweeps per pass added up)
@@ -428,6 +453,13 @@ void launch_cap(const u32* korder, const u32* qoff, u32 q0, u32 nq /*queries [q0
                 unsigned long long* qhits, hipStream_t st) {
     if (nq <= q0) return;
     hipLaunchKernelGGL(k_cap, dim3((nq - q0 + 3) / 4), dim3(256), 0, st, korder, qoff, q0, nq, mink, pcnt, threshold, mark, qhits);
+}
+
+void launch_cap_all(const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark, unsigned long long* qhits,
+                    unsigned long long* over /*zeroed here*/, hipStream_t st) {
+    if (!nq) return;
+    HIP_CHECK(hipMemsetAsync(over, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_cap_all, dim3((nq + 3) / 4), dim3(256), 0, st, qoff, nq, mink, pcnt, threshold, mark, qhits, over);
 }
 
 void launch_effcnt(const u8* mark, const u32* scnt, int AS, u32 p_lo, u32 p_hi, u32* eff, u32* nz, hipStream_t st) {

@@ -77,6 +77,7 @@ void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, u32 q_long /*fi
                       const signed char* b62c, u64* gx, u32* gL, u32* gR /*global scratch per residue: only when q_long < nq*/, u32* korder, hipStream_t st,
                       hipStream_t st_long /*stream of the global-scratch instance: st, or a side stream the caller orders against st*/);
 int ksc_lds_max();
+void launch_cap_all(const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark, unsigned long long* qhits, unsigned long long* over, hipStream_t st);
 void launch_cap(const u32* korder, const u32* qoff, u32 q0, u32 nq /*batch slots [q0, nq)*/, int mink, const u32* pcnt, i64 threshold, u8* mark,
                 unsigned long long* qhits, hipStream_t st);
 // (these two work on the pass's seed slots only, [AS * p_lo, AS * p_hi))

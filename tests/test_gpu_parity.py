@@ -201,6 +201,35 @@ def test_sparse_pass_singletons_vs_oracle(fs, oracle, tmp_path, monkeypatch, uq)
     oracle_vs_gpu(fs, oracle, synthprot.synthprot(700, seed=93, lengths="lognormal"), kw, tmp_path)
 
 
+@pytest.mark.parametrize("lazy", ["1", "0"], ids=["orders_on_demand", "orders_with_the_batch"])
+def test_kmer_orders_on_demand_vs_oracle(fs, oracle, tmp_path, monkeypatch, lazy):
+    """The frequency cap (fsearch.py:2667-2677) walks a query's windows in k-mer score order, but a query whose windows together stay
+    below the limit keeps them all whatever the order (k_cap_all): the orders are computed by the first chunk in which a query
+    reaches its cap, never when none does.  Chunk 0 holds iid proteins (a query meets itself at most: below the cap of 1 x length),
+    family members in chunks 1 and 2 exceed it: rows and candidates are the oracle's whether the orders come on demand (default) or
+    with the batch (SOHIT_KSC_LAZY=0), and the profile key says which chunk asked; without a cap in reach nothing is ordered."""
+    from swiftortho_amd import synthprot
+    monkeypatch.setenv("SOHIT_KSC_LAZY", lazy)
+
+    def asked_at(fa, kw):
+        s, hits, _ = gpu_rows(fs, fa, fa, kw)
+        hits.close()
+        s.set_profile(True)
+        s.search(0, -1).close()
+        t = s.timing()
+        s.close()
+        return int(t.get("seed.kmer_orders_at_chunk", 0))
+
+    fa = synthprot.uniform_proteins(400, 200, 96).replace(b"|p", b"|u") + synthprot.synthprot(800, 200, 97)
+    kw = dict(ssd="11111011111", nr=oracle.AA9, ht=120000000, chk=400, step=1, v=500, expect=1e-5, flt="T", thr=1)
+    oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
+    assert asked_at(fa, kw) == (2 if lazy == "1" else 0)
+    assert asked_at(fa, dict(kw, thr=100000)) == 0
+    # mixed lengths, among them sequences whose order needs global scratch (computed on the side stream once it is asked for)
+    het = synthprot.synthprot(700, seed=99, lengths="lognormal")
+    oracle_vs_gpu(fs, oracle, het, dict(kw, chk=50000), tmp_path)
+
+
 def test_synth_2000_vs_oracle(fs, oracle, tmp_path):
     from swiftortho_amd import synthprot
     kw = dict(ssd="111111", nr=oracle.AA9, ht=120000000, chk=50000, step=1, v=500, expect=1e-5, flt="T")
