@@ -343,10 +343,14 @@ struct Batch {
     // frequency cap (and everything after it) waits for ev_korder, the classes before them do not
     u32 q_defer = 0;
     bool korder_async = false;
-    // the k-mer orders are computed by the first chunk in which a query reaches its frequency cap (chunk_qhits -> order_queries);
-    // ksc_long = first batch slot whose order needs global scratch
-    bool korder_ready = false;
+    // k-mer orders are computed when a query reaches its frequency cap (chunk_qhits): its own while such queries are few, every query's
+    // at the first chunk where they are the majority; ksc_long = first batch slot whose order needs global scratch
+    bool korder_ready = false;   // every query's order is there
     u32 ksc_long = 0;
+    DevBuf<u32> open_list;       // this chunk's queries above their cap while !korder_ready (k_cap_all), n_open of them
+    u32 n_open = 0;
+    DevBuf<u8> kord_have;        // per batch slot: its order has been computed (order_open_queries)
+    bool kord_have_clear = false;
     DevBuf<u32> d_qid, d_ocnt, d_ostart;
     SeqSet dev;              // device arrays only (d_res = masked raw, d_scls, d_off, d_words, d_pseq)
     DevBuf<u32> qbucket, korder, sbeg, scnt, pcnt, eff, nz, hoff, cidx;
@@ -543,6 +547,7 @@ const ChunkIndex::RangeTab* range_table(so_ctx* c, ChunkIndex& ch, const ChunkIn
 // host_seed.hip: batch preparation and the seed stage
 void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi);
 void order_queries(so_ctx* c, Batch& b);
+void order_open_queries(so_ctx* c, Batch& b, const unsigned long long* qh);
 void* small_host(so_ctx* c);
 u32 d2h_u32(so_ctx* c, const u32* p);
 void stash_u32(so_ctx* c, const u32* p, int slot);

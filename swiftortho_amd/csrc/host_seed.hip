@@ -3,24 +3,46 @@
 
 // The k-mer orders of the batch's queries (fsearch.py:2660-2666: windows by self score, the reference's own quicksort replayed: 1.3 ms
 // for 100 k queries).  Only the frequency cap reads them, and only for a query whose windows together exceed its limit in the chunk at
-// hand: the batch's first chunk with such a query asks for them (chunk_qhits; SOHIT_KSC_LAZY=0: prepare_batch does), a batch without
-// one never does -- the long seeds.  In a class-ordered batch the queries that need global scratch are the tail of the last class: their
-// order is computed on the side stream while the classes before them are searched.
+// hand (k_cap_all leaves it open).  chunk_qhits asks for the orders of the open queries alone while they are a minority of the batch
+// (order_open_queries: once per query and batch) and for everybody's at the first chunk where they are not (order_queries;
+// SOHIT_KSC_LAZY=0: prepare_batch does).  Either way the queries that need global scratch -- in a class-ordered batch the tail of the
+// last class -- have theirs computed on the side stream while the classes before them are searched (korder_async, q_defer).
+static void defer_long_class(so_ctx* c, Batch& b, u32 q_long) {
+    b.korder_async = q_long < b.nq && b.cls_sorted && b.qcls[q_long] != b.qcls[0];
+    if (!b.korder_async) return;
+    b.q_defer = q_long;
+    while (b.q_defer > 0 && b.qcls[b.q_defer - 1] == b.qcls[q_long]) --b.q_defer;
+    HIP_CHECK(hipEventRecord(c->ev_side_go, c->st));   // the batch's class arrays (and this chunk's list) are on the device
+    HIP_CHECK(hipStreamWaitEvent(c->st_side, c->ev_side_go, 0));
+}
+
 void order_queries(so_ctx* c, Batch& b) {
     const u32 q_long = b.ksc_long;
     const size_t nres = b.h_off[b.nq];
     if (q_long < b.nq) b.gx.ensure(nres + 4), b.gL.ensure(nres + 4), b.gR.ensure(nres + 4);
-    b.korder_async = q_long < b.nq && b.cls_sorted && b.qcls[q_long] != b.qcls[0];
-    if (b.korder_async) {
-        b.q_defer = q_long;
-        while (b.q_defer > 0 && b.qcls[b.q_defer - 1] == b.qcls[q_long]) --b.q_defer;
-        HIP_CHECK(hipEventRecord(c->ev_side_go, c->st));   // the batch's class arrays are on the device
-        HIP_CHECK(hipStreamWaitEvent(c->st_side, c->ev_side_go, 0));
-    }
+    defer_long_class(c, b, q_long);
     launch_ksc_order(b.dev.d_scls.p, b.dev.d_off.p, b.nq, q_long, c->cfg.mink, c->d_b62c.p, b.gx.p, b.gL.p, b.gR.p, b.korder.p, c->st,
                      b.korder_async ? c->st_side : c->st);
     if (b.korder_async) HIP_CHECK(hipEventRecord(c->ev_korder, c->st_side));
     b.korder_ready = true;
+}
+
+// ... of the b.n_open queries in b.open_list (qh: the host's copy of b.qhits, ~0 for those)
+void order_open_queries(so_ctx* c, Batch& b, const unsigned long long* qh) {
+    u32 q_long = b.nq;   // the first open query that needs global scratch
+    for (u32 q = b.ksc_long; q < b.nq && q_long == b.nq; ++q)
+        if (qh[q] == ~0ull && (i64)(b.h_off[q + 1] - b.h_off[q]) - c->cfg.mink + 1 > (i64)ksc_lds_max()) q_long = q;
+    const size_t nres = b.h_off[b.nq];
+    if (q_long < b.nq) b.gx.ensure(nres + 4), b.gL.ensure(nres + 4), b.gR.ensure(nres + 4);
+    if (!b.kord_have_clear) {
+        b.kord_have.ensure((size_t)b.nq + 4);
+        HIP_CHECK(hipMemsetAsync(b.kord_have.p, 0, b.nq, c->st));
+        b.kord_have_clear = true;
+    }
+    defer_long_class(c, b, q_long);
+    launch_ksc_order_list(b.dev.d_scls.p, b.dev.d_off.p, b.nq, b.open_list.p, b.n_open, b.kord_have.p, q_long, c->cfg.mink, c->d_b62c.p, b.gx.p, b.gL.p,
+                          b.gR.p, b.korder.p, c->st, b.korder_async ? c->st_side : c->st);
+    if (b.korder_async) HIP_CHECK(hipEventRecord(c->ev_korder, c->st_side));
 }
 
 void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
@@ -136,7 +158,7 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
                 }
         }
         b.ksc_long = q_long;
-        b.korder_ready = false;
+        b.korder_ready = false, b.kord_have_clear = false, b.n_open = 0;
         if (!tune().ksc_lazy) order_queries(c, b);
     }
     b.sbeg.ensure(T), b.scnt.ensure(T), b.eff.ensure(T + 4), b.nz.ensure(T + 4), b.hoff.ensure(T + 4), b.cidx.ensure(T + 4);
@@ -225,20 +247,33 @@ const unsigned long long* chunk_qhits(so_ctx* c, Batch& b, int ci) {
     }
     unsigned long long* qh = c->h_qhits;
     if (!b.korder_ready) {
-        // no orders yet: a query that stays below its cap keeps all its windows (k_cap_all).  The first chunk in which one does not has the
-        // orders computed -- every query's: picking the open ones out costs more launches than it saves, and the longest of them would have
-        // its order computed on the critical path -- and falls through to the ordered cap, where the batch's later chunks go at once
-        launch_cap_all(b.dev.d_off.p, b.nq, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, b.qhits.p + b.nq, c->st);
+        // no orders yet: a query that stays below its cap keeps all its windows (k_cap_all).  The others get their orders now and the ordered
+        // cap -- they alone while they are a minority of the batch (the long seeds: a few per cent); at the first chunk where they are not,
+        // every query's order is computed and the batch's later chunks go to the ordered cap at once
+        b.open_list.ensure((size_t)b.nq + 4);
+        launch_cap_all(b.dev.d_off.p, b.nq, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, b.qhits.p + b.nq, b.open_list.p, c->st);
         HIP_CHECK(hipMemcpyAsync(qh, b.qhits.p, ((size_t)b.nq + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
         HIP_CHECK(hipStreamSynchronize(c->st));
-        if (tune().debug) fprintf(stderr, "[sohit] chunk %d: %llu of %u queries reach their frequency cap\n", ci, qh[b.nq], b.nq);
-        if (!qh[b.nq]) return qh;
-        if (c->profile) c->tm["seed.kmer_orders_at_chunk"] += ci + 1;   // (tests: which chunk asked; one batch per search there)
+        const unsigned long long open = qh[b.nq];
+        if (tune().debug) fprintf(stderr, "[sohit] chunk %d: %llu of %u queries reach their frequency cap\n", ci, open, b.nq);
+        b.n_open = 0;
+        if (!open) return qh;
+        if (open * 2 <= b.nq) {
+            if (c->profile) c->tm["seed.kmer_orders_open_chunks"] += (double)(1u << std::min(ci, 30));   // (tests: which chunks asked; one batch per search there)
+            b.n_open = (u32)open;
+            order_open_queries(c, b, qh);
+            const u32 n1 = b.korder_async ? b.q_defer : b.nq;   // (the open queries of the last length class follow in chunk_qhits_deferred)
+            launch_cap(b.korder.p, b.dev.d_off.p, 0, n1, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, b.open_list.p, b.n_open, c->st);
+            HIP_CHECK(hipMemcpyAsync(qh, b.qhits.p, (size_t)n1 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
+            HIP_CHECK(hipStreamSynchronize(c->st));
+            return qh;
+        }
+        if (c->profile) c->tm["seed.kmer_orders_all_at_chunk"] += ci + 1;
         order_queries(c, b);
         HIP_CHECK(hipMemsetAsync(b.mark.p, 0, Ppad, c->st));
     }
     const u32 n1 = b.korder_async ? b.q_defer : b.nq;   // (the last length class follows in chunk_qhits_deferred)
-    launch_cap(b.korder.p, b.dev.d_off.p, 0, n1, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, c->st);
+    launch_cap(b.korder.p, b.dev.d_off.p, 0, n1, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, nullptr, 0, c->st);
     HIP_CHECK(hipMemcpyAsync(qh, b.qhits.p, (size_t)n1 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
     HIP_CHECK(hipStreamSynchronize(c->st));
     return qh;
@@ -251,7 +286,9 @@ void chunk_qhits_deferred(so_ctx* c, Batch& b, int ci) {
     b.korder_async = false;
     i64 threshold = ch.threshold;
     if (c->thr >= 1 || threshold == 0) threshold = c->thr;
-    launch_cap(b.korder.p, b.dev.d_off.p, b.q_defer, b.nq, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, c->st);
+    // (while only the open queries have orders -- !korder_ready -- the others of the class keep what k_cap_all gave them)
+    launch_cap(b.korder.p, b.dev.d_off.p, b.q_defer, b.nq, c->cfg.mink, b.pcnt.p, threshold, b.mark.p, b.qhits.p, b.korder_ready ? nullptr : b.open_list.p,
+               b.korder_ready ? 0 : b.n_open, c->st);
     HIP_CHECK(hipMemcpyAsync(c->h_qhits + b.q_defer, b.qhits.p + b.q_defer, (size_t)(b.nq - b.q_defer) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
     HIP_CHECK(hipStreamSynchronize(c->st));
 }

@@ -88,7 +88,9 @@ __global__ __launch_bounds__(256) void k_bounds(const u32* __restrict__ qbucket,
 
 template <int CAP, int LO>  // serves queries with LO < windows <= CAP
 __global__ __launch_bounds__(64) void k_ksc_order_lds(const u8* __restrict__ q_scls, const u32* __restrict__ qoff, u32 nq, int mink,
-                                                      const signed char* __restrict__ b62c, u32* __restrict__ korder) {
+                                                      const signed char* __restrict__ b62c, u32* __restrict__ korder,
+                                                      const u32* __restrict__ list /*or null: every query; else the grid runs over it*/,
+                                                      u8* __restrict__ have) {
     __shared__ signed char s_self[SCLS_N];
     constexpr int LEAFCAP = CAP <= 512 ? 128 : CAP <= 1024 ? 256 : WQS_LEAF;  // leaf list sized with the instance (LDS = residency)
     __shared__ u32 s_x[CAP];
@@ -96,7 +98,8 @@ __global__ __launch_bounds__(64) void k_ksc_order_lds(const u8* __restrict__ q_s
     __shared__ int s_leaf[2 * LEAFCAP];
     if (threadIdx.x < SCLS_N) s_self[threadIdx.x] = b62c[threadIdx.x * SCLS_N + threadIdx.x];
     __syncthreads();
-    const u32 q = blockIdx.x;
+    const u32 q = list ? list[blockIdx.x] : blockIdx.x;
+    if (list && have[q]) return;   // computed for an earlier chunk of this batch
     const u32 base = qoff[q];
     const int ql = (int)(qoff[q + 1] - base);
     const int nk = ql - mink + 1;
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(64) void k_ksc_order_lds(const u8* __restrict__ q_s
     __syncthreads();
     wave_ref_qsort<LEAFCAP>(s_x, nk, [](u32 v) { return (int)(v >> 12); }, 0x7fffffff, s_L, s_R, s_leaf);
     for (int i = threadIdx.x; i < nk; i += 64) korder[base + i] = s_x[i] & 0xFFFu;
+    if (list && threadIdx.x == 0) have[q] = 1;
 }
 
 // Queries with more than LDS_SORT_MAX windows (proteins above ~4100 residues): the same wave-parallel replay on 64-bit words
@@ -117,14 +121,15 @@ __global__ __launch_bounds__(64) void k_ksc_order_lds(const u8* __restrict__ q_s
 // round 4 one THREAD sorted such a query: a 30 000-residue protein took 370 ms, seven times the whole config-3 search.
 __global__ __launch_bounds__(64) void k_ksc_order_g(const u8* __restrict__ q_scls, const u32* __restrict__ qoff, u32 q0, u32 nq, int mink,
                                                     const signed char* __restrict__ b62c /*24x24*/, u64* __restrict__ gx, u32* __restrict__ gL,
-                                                    u32* __restrict__ gR, u32* __restrict__ korder) {
+                                                    u32* __restrict__ gR, u32* __restrict__ korder, const u32* __restrict__ list, u8* __restrict__ have) {
     __shared__ signed char s_self[SCLS_N];
     __shared__ u64 s_leafbuf[64 * WQS_LEAFBUF];
     __shared__ int s_leaf[2 * WQS_LEAF];
     if (threadIdx.x < SCLS_N) s_self[threadIdx.x] = b62c[threadIdx.x * SCLS_N + threadIdx.x];
     __syncthreads();
-    const u32 q = q0 + blockIdx.x;
-    if (q >= nq) return;
+    const u32 q = list ? list[blockIdx.x] : q0 + blockIdx.x;
+    if (q >= nq || q < q0) return;
+    if (list && have[q]) return;
     const u32 base = qoff[q];
     const int ql = (int)(qoff[q + 1] - base);
     const int nk = ql - mink + 1;
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(64) void k_ksc_order_g(const u8* __restrict__ q_scl
     __syncthreads();
     wave_ref_qsort<WQS_LEAF, 16>(x, nk, [](u64 v) { return (int)(v >> 32); }, 0x7fffffff, gL + base, gR + base, s_leaf, s_leafbuf);
     for (int i = threadIdx.x; i < nk; i += 64) korder[base + i] = (u32)x[i];
+    if (list && threadIdx.x == 0) have[q] = 1;
 }
 
 // ---- high-frequency cap (fsearch.py:2667-2677) ---------------------------------------------------
@@ -147,10 +153,13 @@ __global__ __launch_bounds__(64) void k_ksc_order_g(const u8* __restrict__ q_scl
 // One wave per query: 64 counts per step, wave prefix sum (u64), carried total; also returns the query's hits.
 __global__ __launch_bounds__(256) void k_cap(const u32* __restrict__ korder, const u32* __restrict__ qoff, u32 q0, u32 nq, int mink,
                                              const u32* __restrict__ pcnt, i64 threshold, u8* __restrict__ mark,
-                                             unsigned long long* __restrict__ qhits) {
-    const u32 q = q0 + blockIdx.x * 4u + (threadIdx.x >> 6);
+                                             unsigned long long* __restrict__ qhits, const u32* __restrict__ list, u32 nlist) {
+    // (with a list -- the queries k_cap_all left open --: the grid runs over it, a query outside [q0, nq) is another call's)
+    const u32 w = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (list && w >= nlist) return;
+    const u32 q = list ? list[w] : q0 + w;
     const int lane = threadIdx.x & 63;
-    if (q >= nq) return;
+    if (q >= nq || q < q0) return;
     const u32 base = qoff[q];
     const int ql = (int)(qoff[q + 1] - base);
     const int nk = ql - mink + 1;
@@ -187,9 +196,11 @@ __global__ __launch_bounds__(256) void k_cap(const u32* __restrict__ korder, con
 // The cap without the order: the loop above refuses a position only when the total of the positions BEFORE it exceeds the limit, so a
 // query whose windows' counts sum to no more than the limit keeps every window whatever the order (fsearch.py:2667-2677: the `break`
 // is never reached).  One wave per query adds the counts up; a query at or below its limit has all its windows marked and its total
-// returned, any other is counted in *over -- the host then has the k-mer orders computed (once per batch) and runs k_cap.
+// returned, any other is appended to open_list (*over counts them; their order in the list is whatever the atomics make it, and nothing
+// depends on it) -- the host then has the k-mer orders of those queries computed and runs k_cap over the list.
 __global__ __launch_bounds__(256) void k_cap_all(const u32* __restrict__ qoff, u32 nq, int mink, const u32* __restrict__ pcnt, i64 threshold,
-                                                 u8* __restrict__ mark, unsigned long long* __restrict__ qhits, unsigned long long* __restrict__ over) {
+                                                 u8* __restrict__ mark, unsigned long long* __restrict__ qhits, unsigned long long* __restrict__ over,
+                                                 u32* __restrict__ open_list) {
     const u32 q = blockIdx.x * 4u + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= nq) return;
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(256) void k_cap_all(const u32* __restrict__ qoff, u
 #pragma unroll
     for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
     if (nk > 0 && (i64)sum > threshold * (i64)ql) {
-        if (lane == 0) atomicAdd(over, 1ull);
+        if (lane == 0) open_list[atomicAdd(over, 1ull)] = q, qhits[q] = ~0ull;
         return;
     }
     for (int r = lane; r < nk; r += 64) mark[pbase + r] = 1;
@@ -442,24 +453,37 @@ void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, u32 q_long /*fi
                       hipStream_t st_long /*where the global-scratch instance runs (the caller orders it against st)*/) {
     if (!nq) return;
     // (one wave per query: the instance for the typical protein keeps 4 KB of LDS so that a CU holds 32 of them)
-    hipLaunchKernelGGL((k_ksc_order_lds<512, 0>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
-    hipLaunchKernelGGL((k_ksc_order_lds<1024, 512>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
-    hipLaunchKernelGGL((k_ksc_order_lds<LDS_SORT_MAX, 1024>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder);
-    if (q_long < nq) hipLaunchKernelGGL(k_ksc_order_g, dim3(nq - q_long), dim3(64), 0, st_long, q_scls, qoff, q_long, nq, mink, b62c, gx, gL, gR, korder);
+    hipLaunchKernelGGL((k_ksc_order_lds<512, 0>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder, nullptr, nullptr);
+    hipLaunchKernelGGL((k_ksc_order_lds<1024, 512>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder, nullptr, nullptr);
+    hipLaunchKernelGGL((k_ksc_order_lds<LDS_SORT_MAX, 1024>), dim3(nq), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder, nullptr, nullptr);
+    if (q_long < nq)
+        hipLaunchKernelGGL(k_ksc_order_g, dim3(nq - q_long), dim3(64), 0, st_long, q_scls, qoff, q_long, nq, mink, b62c, gx, gL, gR, korder, nullptr, nullptr);
+}
+// ... of the listed queries that do not have theirs yet (have[q] == 0; set here); the global-scratch instance only when the caller saw a
+// listed query that needs it (q_long < nq: slots from q_long on)
+void launch_ksc_order_list(const u8* q_scls, const u32* qoff, u32 nq, const u32* list, u32 nlist, u8* have, u32 q_long, int mink, const signed char* b62c,
+                           u64* gx, u32* gL, u32* gR, u32* korder, hipStream_t st, hipStream_t st_long) {
+    if (!nlist) return;
+    hipLaunchKernelGGL((k_ksc_order_lds<512, 0>), dim3(nlist), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder, list, have);
+    hipLaunchKernelGGL((k_ksc_order_lds<1024, 512>), dim3(nlist), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder, list, have);
+    hipLaunchKernelGGL((k_ksc_order_lds<LDS_SORT_MAX, 1024>), dim3(nlist), dim3(64), 0, st, q_scls, qoff, nq, mink, b62c, korder, list, have);
+    if (q_long < nq)
+        hipLaunchKernelGGL(k_ksc_order_g, dim3(nlist), dim3(64), 0, st_long, q_scls, qoff, q_long, nq, mink, b62c, gx, gL, gR, korder, list, have);
 }
 int ksc_lds_max() { return LDS_SORT_MAX; }
 
 void launch_cap(const u32* korder, const u32* qoff, u32 q0, u32 nq /*queries [q0, nq)*/, int mink, const u32* pcnt, i64 threshold, u8* mark,
-                unsigned long long* qhits, hipStream_t st) {
-    if (nq <= q0) return;
-    hipLaunchKernelGGL(k_cap, dim3((nq - q0 + 3) / 4), dim3(256), 0, st, korder, qoff, q0, nq, mink, pcnt, threshold, mark, qhits);
+                unsigned long long* qhits, const u32* list /*or null; else: those of the nlist listed queries that lie in [q0, nq)*/, u32 nlist, hipStream_t st) {
+    if (nq <= q0 || (list && !nlist)) return;
+    const u32 n = list ? nlist : nq - q0;
+    hipLaunchKernelGGL(k_cap, dim3((n + 3) / 4), dim3(256), 0, st, korder, qoff, q0, nq, mink, pcnt, threshold, mark, qhits, list, nlist);
 }
 
 void launch_cap_all(const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark, unsigned long long* qhits,
-                    unsigned long long* over /*zeroed here*/, hipStream_t st) {
+                    unsigned long long* over /*zeroed here*/, u32* open_list /*nq slots*/, hipStream_t st) {
     if (!nq) return;
     HIP_CHECK(hipMemsetAsync(over, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_cap_all, dim3((nq + 3) / 4), dim3(256), 0, st, qoff, nq, mink, pcnt, threshold, mark, qhits, over);
+    hipLaunchKernelGGL(k_cap_all, dim3((nq + 3) / 4), dim3(256), 0, st, qoff, nq, mink, pcnt, threshold, mark, qhits, over, open_list);
 }
 
 void launch_effcnt(const u8* mark, const u32* scnt, int AS, u32 p_lo, u32 p_hi, u32* eff, u32* nz, hipStream_t st) {

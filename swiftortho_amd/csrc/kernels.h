@@ -77,9 +77,12 @@ void launch_ksc_order(const u8* q_scls, const u32* qoff, u32 nq, u32 q_long /*fi
                       const signed char* b62c, u64* gx, u32* gL, u32* gR /*global scratch per residue: only when q_long < nq*/, u32* korder, hipStream_t st,
                       hipStream_t st_long /*stream of the global-scratch instance: st, or a side stream the caller orders against st*/);
 int ksc_lds_max();
-void launch_cap_all(const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark, unsigned long long* qhits, unsigned long long* over, hipStream_t st);
+void launch_ksc_order_list(const u8* q_scls, const u32* qoff, u32 nq, const u32* list, u32 nlist, u8* have, u32 q_long, int mink, const signed char* b62c,
+                           u64* gx, u32* gL, u32* gR, u32* korder, hipStream_t st, hipStream_t st_long);
+void launch_cap_all(const u32* qoff, u32 nq, int mink, const u32* pcnt, i64 threshold, u8* mark, unsigned long long* qhits, unsigned long long* over,
+                    u32* open_list, hipStream_t st);
 void launch_cap(const u32* korder, const u32* qoff, u32 q0, u32 nq /*batch slots [q0, nq)*/, int mink, const u32* pcnt, i64 threshold, u8* mark,
-                unsigned long long* qhits, hipStream_t st);
+                unsigned long long* qhits, const u32* list, u32 nlist, hipStream_t st);
 // (these two work on the pass's seed slots only, [AS * p_lo, AS * p_hi))
 void launch_effcnt(const u8* mark, const u32* scnt, int AS, u32 p_lo, u32 p_hi, u32* eff, u32* nz, hipStream_t st);
 void launch_compact_seeds(const u32* eff, const u32* hoff, const u32* cidx, const u32* sbeg, const u32* q_pseq, const u32* qoff,

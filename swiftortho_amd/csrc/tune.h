@@ -23,7 +23,7 @@
     X(B, lk_wide, "SOHIT_LK_WIDE", 0, "8-byte index addends whatever the field widths")                                                                        \
     X(B, qclass, "SOHIT_QCLASS", 1, "queries of a batch in length-class order (0: file order)")                                                                \
     X(B, pass_merge, "SOHIT_PASS_MERGE", 1, "neighbouring length classes that take the sorted path anyway share one pass")                                     \
-    X(B, ksc_lazy, "SOHIT_KSC_LAZY", 1, "k-mer orders of a batch's queries computed at the first chunk where a query reaches its frequency cap (a query below it keeps every window whatever the order; 0: with the batch)") \
+    X(B, ksc_lazy, "SOHIT_KSC_LAZY", 1, "k-mer orders computed for the queries that reach their frequency cap, when they do (a query below it keeps every window whatever the order; 0: for every query, with the batch)") \
     X(B, bounds_ahead, "SOHIT_BOUNDS_AHEAD", 1, "the next chunk's bucket bounds (k_bounds) on the side stream beside this chunk's seed stage (0: in front of its own)")     \
     X(I, segsort, "SOHIT_SEGSORT", 1, "sorted path: segmented sort of the keys inside each query (0: device-wide sort)")                                        \
     X(I, write_threads, "SOHIT_WRITE_THREADS", 48, "so_write_sc: formatter threads (at most the host's cores)")                                                                          \

@@ -204,30 +204,42 @@ def test_sparse_pass_singletons_vs_oracle(fs, oracle, tmp_path, monkeypatch, uq)
 @pytest.mark.parametrize("lazy", ["1", "0"], ids=["orders_on_demand", "orders_with_the_batch"])
 def test_kmer_orders_on_demand_vs_oracle(fs, oracle, tmp_path, monkeypatch, lazy):
     """The frequency cap (fsearch.py:2667-2677) walks a query's windows in k-mer score order, but a query whose windows together stay
-    below the limit keeps them all whatever the order (k_cap_all): the orders are computed by the first chunk in which a query
-    reaches its cap, never when none does.  Chunk 0 holds iid proteins (a query meets itself at most: below the cap of 1 x length),
-    family members in chunks 1 and 2 exceed it: rows and candidates are the oracle's whether the orders come on demand (default) or
-    with the batch (SOHIT_KSC_LAZY=0), and the profile key says which chunk asked; without a cap in reach nothing is ordered."""
+    below the limit keeps them all whatever the order (k_cap_all): orders are computed for the queries that reach their cap, in the
+    chunk where they do -- or for every query at the first chunk where such queries are the majority.  Chunk 0 holds iid proteins (a
+    query meets itself at most: below the cap of 1 x length), family members in chunks 1 and 2 exceed it: rows and candidates are the
+    oracle's whether the orders come on demand (default) or with the batch (SOHIT_KSC_LAZY=0), and the profile keys say which chunks
+    asked.  A set in which every protein occurs twice has every query over its cap; without a cap in reach nothing is ordered; a
+    mixed-length set has open queries whose order needs global scratch (side stream, their class's cap deferred)."""
     from swiftortho_amd import synthprot
     monkeypatch.setenv("SOHIT_KSC_LAZY", lazy)
 
-    def asked_at(fa, kw):
+    def asked(fa, kw):
         s, hits, _ = gpu_rows(fs, fa, fa, kw)
         hits.close()
         s.set_profile(True)
         s.search(0, -1).close()
         t = s.timing()
         s.close()
-        return int(t.get("seed.kmer_orders_at_chunk", 0))
+        return int(t.get("seed.kmer_orders_open_chunks", 0)), int(t.get("seed.kmer_orders_all_at_chunk", 0))
 
     fa = synthprot.uniform_proteins(400, 200, 96).replace(b"|p", b"|u") + synthprot.synthprot(800, 200, 97)
     kw = dict(ssd="11111011111", nr=oracle.AA9, ht=120000000, chk=400, step=1, v=500, expect=1e-5, flt="T", thr=1)
     oracle_vs_gpu(fs, oracle, fa, kw, tmp_path)
-    assert asked_at(fa, kw) == (2 if lazy == "1" else 0)
-    assert asked_at(fa, dict(kw, thr=100000)) == 0
-    # mixed lengths, among them sequences whose order needs global scratch (computed on the side stream once it is asked for)
-    het = synthprot.synthprot(700, seed=99, lengths="lognormal")
-    oracle_vs_gpu(fs, oracle, het, dict(kw, chk=50000), tmp_path)
+    some, everybody = asked(fa, kw)
+    if lazy == "1":
+        assert some & 1 == 0 and some & 6 != 0 and everybody == 0, (some, everybody)
+    else:
+        assert (some, everybody) == (0, 0)
+    assert asked(fa, dict(kw, thr=100000)) == (0, 0)
+    twice = synthprot.synthprot(300, 200, 98)
+    twice = twice + twice.replace(b"|p", b"|d")
+    kw1 = dict(kw, chk=50000)   # (one chunk: both copies in it)
+    oracle_vs_gpu(fs, oracle, twice, kw1, tmp_path)
+    assert asked(twice, kw1) == ((0, 1) if lazy == "1" else (0, 0))
+    het = synthprot.synthprot(1200, seed=99, lengths="lognormal")
+    oracle_vs_gpu(fs, oracle, het, dict(kw1, chk=500), tmp_path)
+    if lazy == "1":
+        assert asked(het, dict(kw1, chk=500))[0] != 0
 
 
 def test_synth_2000_vs_oracle(fs, oracle, tmp_path):
