@@ -229,3 +229,31 @@ def test_row_formatter_equals_printf_and_oracle_f2s(oracle):
         f, e = row.split("\t")
         assert f == "%f" % x, (x, f)
         assert e == oracle.f2s(x), (x, e, oracle.f2s(x))
+
+
+def test_frequency_cap_keeps_every_window_when_their_total_fits():
+    """What k_cap_all (csrc/k_seed.hip) relies on to skip the k-mer orders: the reference's cap walks a query's windows in score order and
+    tests the running total BEFORE adding the window's bucket size (fsearch.py:2667-2677), so when all bucket sizes together stay at or
+    below the limit no window is ever refused -- in any order.  Above the limit the kept set does depend on the order."""
+    rng = np.random.default_rng(5)
+
+    def capped(counts, order, limit):   # the reference's loop: `if total > limit: break; total += n; keep`
+        kept, total = [], 0
+        for p in order:
+            if total > limit:
+                break
+            total += int(counts[p])
+            kept.append(int(p))
+        return sorted(kept)
+
+    order_matters = 0
+    for _ in range(300):
+        n = int(rng.integers(1, 60))
+        counts = rng.integers(0, 40, size=n)
+        limit = int(rng.integers(0, 1200))
+        a, b = capped(counts, rng.permutation(n), limit), capped(counts, rng.permutation(n), limit)
+        if int(counts.sum()) <= limit:
+            assert a == b == list(range(n))
+        else:
+            order_matters += a != b
+    assert order_matters > 0
