@@ -161,12 +161,12 @@ void prepare_batch(so_ctx* c, Batch& b, i64 q_lo, i64 q_hi) {
         b.korder_ready = false, b.kord_have_clear = false, b.n_open = 0;
         if (!tune().ksc_lazy) order_queries(c, b);
     }
-    b.sbeg.ensure(T), b.scnt.ensure(T), b.eff.ensure(T + 4), b.nz.ensure(T + 4), b.hoff.ensure(T + 4), b.cidx.ensure(T + 4);
+    b.sbeg.ensure(T), b.scnt.ensure(T), b.hoff.ensure(T + 4), b.cidx.ensure(T + 4);   // (eff / nz: only with several alphabets or patterns, seed_pass)
     b.pcnt.ensure(Ppad), b.mark.ensure(Ppad);
     b.counters.ensure(8);
     b.ucount.ensure(4);
     HIP_CHECK(hipMemsetAsync(b.ucount.p, 0, 4 * sizeof(unsigned long long), c->st));
-    c->d_scan_tmp.ensure(scan_u32_temp_elems(std::max<size_t>(T, (size_t)c->nc + 1)) + 8);
+    c->d_scan_tmp.ensure(std::max(scan_u32_temp_elems(std::max<size_t>(T, (size_t)c->nc + 1)), effscan_temp_elems(T)) + 8);
     // seed windows hashed (valid or not): one per (as, residue)
     c->cnt.seed_windows += (i64)AS * (i64)nres;
 }
@@ -396,12 +396,22 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     u32* qcnt = b.ccnt.p + (size_t)ci * b.nq;
     // hit counts, their scan (hit ordinals) and the seed compaction run over the pass's own seed slots [t_lo, t_lo + Tp)
     const size_t t_lo = (size_t)AS * p_lo, Tp = (size_t)AS * (p_hi - p_lo);
-    launch_effcnt(b.mark.p, b.scnt.p, AS, p_lo, p_hi, b.eff.p, b.nz.p, c->st);
-    const u32* dH = scan_u32(b.eff.p + t_lo, b.hoff.p + t_lo, Tp, false, c->d_scan_tmp.p, c->st);
-    stash_u32(c, dH, 0);  // the scan's total lives in d_scan_tmp: park it before the next scan
-    const u32* dK = scan_u32(b.nz.p + t_lo, b.cidx.p + t_lo, Tp, false, c->d_scan_tmp.p, c->st);
     u32 H, K;
-    d2h_pair(c, dK, H, K);
+    if (AS == 1) {   // (slot = packed position: both prefixes from mark / scnt in one 64-bit scan, k_util.hip)
+        c->d_scan_tmp.ensure(effscan_temp_elems(Tp) + 8);
+        const u32* dHK = effscan(b.mark.p + p_lo, b.scnt.p + t_lo, Tp, b.hoff.p + t_lo, b.cidx.p + t_lo, c->d_scan_tmp.p, c->st);
+        u32* v = (u32*)small_host(c);
+        HIP_CHECK(hipMemcpyAsync(v, dHK, 2 * sizeof(u32), hipMemcpyDeviceToHost, c->st));
+        HIP_CHECK(hipStreamSynchronize(c->st));
+        H = v[0], K = v[1];
+    } else {
+        b.eff.ensure((size_t)AS * b.dev.Ppad + 4), b.nz.ensure((size_t)AS * b.dev.Ppad + 4);
+        launch_effcnt(b.mark.p, b.scnt.p, AS, p_lo, p_hi, b.eff.p, b.nz.p, c->st);
+        const u32* dH = scan_u32(b.eff.p + t_lo, b.hoff.p + t_lo, Tp, false, c->d_scan_tmp.p, c->st);
+        stash_u32(c, dH, 0);  // the scan's total lives in d_scan_tmp: park it before the next scan
+        const u32* dK = scan_u32(b.nz.p + t_lo, b.cidx.p + t_lo, Tp, false, c->d_scan_tmp.p, c->st);
+        d2h_pair(c, dK, H, K);
+    }
     sc.lap("seed.bounds_cap_scan");
     c->cnt.seed_hits += H;
     if (H == 0 || K == 0) {
@@ -457,7 +467,7 @@ void seed_pass(so_ctx* c, Batch& b, int ci, u32 qa, u32 qb, double t0, StageCloc
     if (klr.sh_subj + klr.bs > 64) throw SoError("pass-record key exceeds 64 bits: sequences too long for this build");
     if (kl.ba + kl.bp + ft_bits_entry > 64) throw SoError("first-touch key exceeds 64 bits: sequences too long for this build");
     b.cs_hoff.ensure((size_t)K + 2), b.cs_beg.ensure((size_t)K + 2), b.cs_kbase.ensure((size_t)K + 2);
-    launch_compact_seeds(b.eff.p, b.hoff.p, b.cidx.p, b.sbeg.p, b.dev.d_pseq.p, b.dev.d_off.p, p_lo, p_hi, AS, kl, b.cs_hoff.p, b.cs_beg.p,
+    launch_compact_seeds(b.mark.p, b.scnt.p, b.hoff.p, b.cidx.p, b.sbeg.p, b.dev.d_pseq.p, b.dev.d_off.p, p_lo, p_hi, AS, kl, b.cs_hoff.p, b.cs_beg.p,
                          b.cs_kbase.p, c->st);
     // per-entry key addends: the 4-byte compact form whenever the fields fit, else 8-byte ones for this layout
     const u32* dk32 = compact ? enc->dk32.p : nullptr;

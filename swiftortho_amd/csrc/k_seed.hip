@@ -238,15 +238,15 @@ __global__ __launch_bounds__(256) void k_effcnt(const u8* __restrict__ mark, con
 // slot cs_base + h, u32 wrap-around intended), cs_kbase = the part of the sort key that does not
 // depend on the index entry: q, qpos (twice: diagonal field and position field) and as.  Per hit
 //   key = kbase + D(entry)      (k_index.hip: k_encode_delta).
-__global__ __launch_bounds__(256) void k_compact_seeds(const u32* __restrict__ eff, const u32* __restrict__ hoff,
+__global__ __launch_bounds__(256) void k_compact_seeds(const u8* __restrict__ mark, const u32* __restrict__ scnt, const u32* __restrict__ hoff,
                                                        const u32* __restrict__ cidx, const u32* __restrict__ sbeg,
                                                        const u32* __restrict__ q_pseq, const u32* __restrict__ qoff, size_t t_lo, size_t t_hi, int AS,
                                                        KeyLayout kl, u32* __restrict__ cs_hoff, u32* __restrict__ cs_base,
                                                        u64* __restrict__ cs_kbase) {
     const size_t t = t_lo + (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= t_hi) return;
-    if (!eff[t]) return;
     const u32 as = (u32)(t % AS), p = (u32)(t / AS);
+    if (!mark[p] || !scnt[t]) return;   // the slot's effective count (k_effcnt's rule)
     const u32 k = cidx[t];
     const u32 q = q_pseq[p];
     const u32 qpos = p - (qoff[q] + q);
@@ -492,11 +492,11 @@ void launch_effcnt(const u8* mark, const u32* scnt, int AS, u32 p_lo, u32 p_hi, 
     hipLaunchKernelGGL(k_effcnt, dim3((unsigned)((t_hi - t_lo + 255) / 256)), dim3(256), 0, st, mark, scnt, AS, t_lo, t_hi, eff, nz);
 }
 
-void launch_compact_seeds(const u32* eff, const u32* hoff, const u32* cidx, const u32* sbeg, const u32* q_pseq, const u32* qoff,
+void launch_compact_seeds(const u8* mark, const u32* scnt, const u32* hoff, const u32* cidx, const u32* sbeg, const u32* q_pseq, const u32* qoff,
                           u32 p_lo, u32 p_hi, int AS, const KeyLayout& kl, u32* cs_hoff, u32* cs_base, u64* cs_kbase, hipStream_t st) {
     const size_t t_lo = (size_t)AS * p_lo, t_hi = (size_t)AS * p_hi;
     if (t_hi <= t_lo) return;
-    hipLaunchKernelGGL(k_compact_seeds, dim3((unsigned)((t_hi - t_lo + 255) / 256)), dim3(256), 0, st, eff, hoff, cidx, sbeg, q_pseq, qoff,
+    hipLaunchKernelGGL(k_compact_seeds, dim3((unsigned)((t_hi - t_lo + 255) / 256)), dim3(256), 0, st, mark, scnt, hoff, cidx, sbeg, q_pseq, qoff,
                        t_lo, t_hi, AS, kl, cs_hoff, cs_base, cs_kbase);
 }
 

@@ -112,6 +112,122 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* __restri
     }
 }
 
+// ---- the seed slots' two scans in one (seed_pass, one alphabet x one pattern) ----------------------------------------------------
+// A pass needs, per seed slot t, the exclusive prefix of its effective hit count c(t) = mark[t] ? scnt[t] : 0 (hit ordinals) and of
+// [c(t) != 0] (compacted seed index).  Until round 6: k_effcnt wrote c and the flag to two arrays and two scans read them back -- 37
+// bytes per slot through six launches.  Here the pair travels as ONE 64-bit value, flag count << 32 | hits (a pass holds fewer than 2^32
+// hits: seed_stage), computed from mark / scnt where it is needed: 5 bytes read by the reduce, 5 read + 8 written by the apply.
+__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u64 t = __shfl_up((unsigned long long)v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ u64 block_excl_scan_u64(u64 v, u64* lds4, u64* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const u64 inc = wave_incl_scan_u64(v, lane);
+    if (lane == 63) lds4[w] = inc;
+    __syncthreads();
+    u64 base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_THREADS / 64; ++k) {
+        const u64 s = lds4[k];
+        if (k < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+// four slots from i on: their effective counts (0 beyond n)
+__device__ __forceinline__ uint4 eff4(const u8* __restrict__ mark, const u32* __restrict__ scnt, size_t i, size_t n) {
+    uint4 c = make_uint4(0, 0, 0, 0);
+    if (i + 3 < n) {
+        u32 m;
+        __builtin_memcpy(&m, mark + i, 4);
+        const uint4 v = ld4(scnt + i);
+        c.x = (m & 0xFFu) ? v.x : 0u, c.y = (m & 0xFF00u) ? v.y : 0u, c.z = (m & 0xFF0000u) ? v.z : 0u, c.w = (m & 0xFF000000u) ? v.w : 0u;
+    } else {
+        if (i < n) c.x = mark[i] ? scnt[i] : 0u;
+        if (i + 1 < n) c.y = mark[i + 1] ? scnt[i + 1] : 0u;
+        if (i + 2 < n) c.z = mark[i + 2] ? scnt[i + 2] : 0u;
+    }
+    return c;
+}
+__device__ __forceinline__ u64 pair4(const uint4& c) {
+    return ((u64)((c.x != 0) + (c.y != 0) + (c.z != 0) + (c.w != 0)) << 32) + (u64)c.x + c.y + c.z + c.w;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_effscan_reduce(const u8* __restrict__ mark, const u32* __restrict__ scnt, size_t n,
+                                                                 u64* __restrict__ blocksums) {
+    __shared__ u64 lds4[4];
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE;
+    u64 s = 0;
+#pragma unroll
+    for (int it = 0; it < SCAN_ITERS; ++it) s += pair4(eff4(mark, scnt, base + (size_t)it * SCAN_THREADS * 4 + (size_t)threadIdx.x * 4, n));
+    u64 tot;
+    block_excl_scan_u64(s, lds4, &tot);
+    if (threadIdx.x == 0) blocksums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_blocksums64(u64* __restrict__ blocksums, size_t nb) {
+    __shared__ u64 lds4[4];
+    u64 carry = 0;
+    for (size_t b0 = 0; b0 < nb; b0 += SCAN_THREADS) {
+        const size_t i = b0 + threadIdx.x;
+        const u64 v = i < nb ? blocksums[i] : 0;
+        u64 tot;
+        const u64 ex = block_excl_scan_u64(v, lds4, &tot);
+        if (i < nb) blocksums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) blocksums[nb] = carry;   // low word: the pass's hits, high word: its non-empty seeds
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_effscan_apply(const u8* __restrict__ mark, const u32* __restrict__ scnt, size_t n,
+                                                                const u64* __restrict__ blocksums, u32* __restrict__ hoff, u32* __restrict__ cidx) {
+    __shared__ u64 lds4[4];
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE;
+    u64 carry = blocksums[blockIdx.x];
+#pragma unroll 1
+    for (int it = 0; it < SCAN_ITERS; ++it) {
+        const size_t i = base + (size_t)it * SCAN_THREADS * 4 + (size_t)threadIdx.x * 4;
+        const uint4 c = eff4(mark, scnt, i, n);
+        u64 tot;
+        const u64 ex = carry + block_excl_scan_u64(pair4(c), lds4, &tot);
+        const u32 h0 = (u32)ex, h1 = h0 + c.x, h2 = h1 + c.y, h3 = h2 + c.z;
+        const u32 k0 = (u32)(ex >> 32), k1 = k0 + (c.x != 0), k2 = k1 + (c.y != 0), k3 = k2 + (c.z != 0);
+        if (i + 3 < n) {
+            st4(hoff + i, make_uint4(h0, h1, h2, h3));
+            st4(cidx + i, make_uint4(k0, k1, k2, k3));
+        } else {
+            if (i < n) hoff[i] = h0, cidx[i] = k0;
+            if (i + 1 < n) hoff[i + 1] = h1, cidx[i + 1] = k1;
+            if (i + 2 < n) hoff[i + 2] = h2, cidx[i + 2] = k2;
+        }
+        carry += tot;
+    }
+}
+
+size_t effscan_temp_elems(size_t n) { return 2 * ((n + SCAN_TILE - 1) / SCAN_TILE + 2) + 2; }   // in u32 (the buffer is used as u64)
+
+// hoff / cidx = exclusive prefixes of c(t) / [c(t) != 0] over the n slots at mark / scnt; returns the device address of the totals,
+// two u32: {hits, non-empty seeds}.  temp: effscan_temp_elems(n) u32, 8-byte aligned.
+const u32* effscan(const u8* mark, const u32* scnt, size_t n, u32* hoff, u32* cidx, u32* temp, hipStream_t st) {
+    const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    u64* t64 = reinterpret_cast<u64*>(temp);
+    if (nb == 0) {
+        HIP_CHECK(hipMemsetAsync(t64, 0, sizeof(u64), st));
+        return temp;
+    }
+    hipLaunchKernelGGL(k_effscan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, mark, scnt, n, t64);
+    hipLaunchKernelGGL(k_scan_blocksums64, dim3(1), dim3(SCAN_THREADS), 0, st, t64, nb);
+    hipLaunchKernelGGL(k_effscan_apply, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, mark, scnt, n, t64, hoff, cidx);
+    return reinterpret_cast<const u32*>(t64 + nb);
+}
+
 // short inputs (per-query counters: one value per query of a batch): ONE block of 1024 threads walks the input 16 K values at a
 // time with a running carry -- one launch instead of three.  Sixteen values per thread (four 16-byte loads issued together): a
 // 100 k-query batch is seven steps, ~15 us (round 3, before: 256 threads x 4 values, 98 steps, 70 us per scan, 16 scans per step).

@@ -6,6 +6,8 @@ struct HashLut;
 
 // k_util.hip
 size_t scan_u32_temp_elems(size_t n);
+size_t effscan_temp_elems(size_t n);
+const u32* effscan(const u8* mark, const u32* scnt, size_t n, u32* hoff, u32* cidx, u32* temp, hipStream_t st);
 const u32* scan_u32(const u32* in, u32* out, size_t n, bool inclusive, u32* temp, hipStream_t st);  // returns device ptr to total
 void fill_u32(u32* p, size_t n, u32 v, hipStream_t st);
 
@@ -85,7 +87,7 @@ void launch_cap(const u32* korder, const u32* qoff, u32 q0, u32 nq /*batch slots
                 unsigned long long* qhits, const u32* list, u32 nlist, hipStream_t st);
 // (these two work on the pass's seed slots only, [AS * p_lo, AS * p_hi))
 void launch_effcnt(const u8* mark, const u32* scnt, int AS, u32 p_lo, u32 p_hi, u32* eff, u32* nz, hipStream_t st);
-void launch_compact_seeds(const u32* eff, const u32* hoff, const u32* cidx, const u32* sbeg, const u32* q_pseq, const u32* qoff,
+void launch_compact_seeds(const u8* mark, const u32* scnt, const u32* hoff, const u32* cidx, const u32* sbeg, const u32* q_pseq, const u32* qoff,
                           u32 p_lo, u32 p_hi, int AS, const KeyLayout& kl, u32* cs_hoff, u32* cs_beg, u64* cs_kbase, hipStream_t st);
 u32 lookup_num_blocks(u32 H);
 void launch_lookup_blockfirst(const u32* cs_hoff, u32 K, u32 H, u32* wave_first, hipStream_t st);
